@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  The
+reference's Python is imported from where it lies (PYTHONPATH), never copied; only
+input/output vectors are written.  Recipe: SURVEY.md Appendix D.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+
+What is patched in the reference: ONLY the RNG primitive — ``torch.nn.functional.dropout``
+is replaced by the shared Philox mask (oracle/philox.py), which the reference's
+``MCDropout.forward`` resolves at call time (SA/models/resnet18/resnet18.py:210).
+``torchvision`` / ``KDEpy`` (absent here) are stubbed so that ``train.results_analyzer``
+imports; nothing from the stubs is executed on the path.
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/Software_Artifact/software"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from oracle import philox  # noqa: E402
+from oracle.layers import MCContext, philox_dropout  # noqa: E402
+from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _stub_modules():
+    tv = types.ModuleType("torchvision")
+    tv.datasets = types.ModuleType("torchvision.datasets")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.transforms.InterpolationMode = types.SimpleNamespace(BICUBIC=3)
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.datasets"] = tv.datasets
+    sys.modules["torchvision.transforms"] = tv.transforms
+    kde = types.ModuleType("KDEpy")
+    kde.FFTKDE = None
+    sys.modules["KDEpy"] = kde
+
+
+_stub_modules()
+import utils as ref_utils  # noqa: E402  (reference SA/utils.py)
+from models.resnet18.resnet18 import ResNet18MCEarlyExit, ResNet18MC, ResNet18EarlyExit  # noqa: E402
+import models as ref_models  # noqa: E402
+from train.results_analyzer import FullAnalysis  # noqa: E402
+from train.loss.base_classes import _MultiExitAccuracy  # noqa: E402
+
+CTX = MCContext()
+_orig_dropout = torch.nn.functional.dropout
+
+
+def _patched_dropout(x, p=0.5, training=True, inplace=False):
+    assert training
+    return philox_dropout(CTX, x, p)
+
+
+class philox_patch:
+    def __enter__(self):
+        torch.nn.functional.dropout = _patched_dropout
+
+    def __exit__(self, *a):
+        torch.nn.functional.dropout = _orig_dropout
+
+
+def state_checksum(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd.keys()):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def ref_passes(model, x, T, seed, reset_cnt=True):
+    """T forwards of the reference model under the Philox patch -> float32 [T,E,B,C]."""
+    model.eval()
+    if reset_cnt:
+        for m in model.modules():
+            if hasattr(m, "cnt"):
+                m.cnt = 0
+    outs = []
+    with torch.no_grad(), philox_patch():
+        for t in range(T):
+            CTX.begin_forward(seed, t)
+            outs.append(np.stack([o.numpy() for o in model(x)]))
+    return np.stack(outs)
+
+
+RESNET_CASES = {
+    # name: (ctor kwargs, B, T)
+    "exit_only": (dict(dropout_exit=True, dropout=None, dropout_p=0.25, out_dim=10), 4, 6),
+    "block_exit": (dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10), 4, 6),
+    "block_noexit": (dict(dropout_exit=False, dropout="block", dropout_p=0.5, out_dim=10), 3, 4),
+    "layer_exit": (dict(dropout_exit=True, dropout="layer", dropout_p=0.125, out_dim=10), 4, 4),
+    "mask4_block_exit": (dict(dropout_exit=True, dropout="block", mask_type="mask", num_masks=4, mask_scale=4.0,
+                              out_dim=10), 4, 10),
+    "mask8_exit_c100": (dict(dropout_exit=True, dropout=None, mask_type="mask", num_masks=8, mask_scale=4.0,
+                             out_dim=100), 2, 8),
+}
+
+
+def gen_resnet():
+    for name, (kw, B, T) in RESNET_CASES.items():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model = ResNet18MCEarlyExit(**kw)
+        init_sum = state_checksum(model.state_dict())
+        synthetic_weights_(model, 0)
+        x = synthetic_images(B, seed=1234)
+        seed = 42
+        logits = ref_passes(model, x, T, seed)
+        # the reference's own T-loop (FullAnalysis._get_output) on the same stream
+        fa = FullAnalysis.__new__(FullAnalysis)
+        fa.model, fa.mc_dropout, fa.mc_passes = model, True, T
+        fa.outputs = list(range(model.n_exits))
+        fa.device = torch.device("cpu")
+        for m in model.modules():
+            if hasattr(m, "cnt"):
+                m.cnt = 0
+        state = {"t": 0}
+
+        def pre(mod, inp):
+            CTX.begin_forward(seed, state["t"])
+            state["t"] += 1
+        hnd = model.register_forward_pre_hook(pre)
+        with torch.no_grad(), philox_patch():
+            out, out_sm, out_sm_np, ens_out, ens_sm = fa._get_output(x)
+        hnd.remove()
+        masks = {k: v.numpy().astype(np.uint8) for k, v in model.state_dict().items() if k.endswith(".masks")}
+        np.savez_compressed(
+            os.path.join(OUT, f"resnet18_{name}.npz"),
+            kwargs=repr(kw), B=B, T=T, seed=seed, init_checksum=init_sum,
+            weights_checksum=state_checksum(model.state_dict()),
+            logits=logits.astype(np.float32),
+            go_output=np.stack([o.numpy() for o in out]),
+            go_output_sm=np.stack([o.numpy() for o in out_sm]),
+            go_output_sm_np=np.asarray(out_sm_np),
+            go_ensemble_output=np.stack([o.numpy() for o in ens_out]),
+            go_ensemble_output_sm=np.stack([o.numpy() for o in ens_sm]),
+            **{"mask__" + k: v for k, v in masks.items()},
+        )
+        print("resnet18", name, logits.shape, init_sum[:12])
+
+    # single-exit ResNet18MC and the deterministic early-exit net
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = ResNet18MC(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    init_sum = state_checksum(m.state_dict())
+    synthetic_weights_(m, 0)
+    x = synthetic_images(3, seed=1234)
+    np.savez_compressed(os.path.join(OUT, "resnet18mc_block_exit.npz"), B=3, T=4, seed=7, init_checksum=init_sum,
+                        logits=ref_passes(m, x, 4, 7).astype(np.float32))
+    torch.manual_seed(0)
+    m = ResNet18EarlyExit(out_dim=10)
+    init_sum = state_checksum(m.state_dict())
+    synthetic_weights_(m, 0)
+    m.eval()
+    with torch.no_grad():
+        lg = np.stack([o.numpy() for o in m(x)])
+    np.savez_compressed(os.path.join(OUT, "resnet18_early_exit.npz"), B=3, init_checksum=init_sum,
+                        logits=lg.astype(np.float32))
+    # factory dispatch (SA/models/model_loader.py:8-24)
+    hp = dict(call="ResNet18", resnet_type="mc_early_exit", load_model=None, out_dim=10, image_size=32,
+              dropout="block", dropout_exit=True, dropout_p=0.25, n_exits=4, mask_type="mc", num_masks=4,
+              mask_scale=4.0)
+    torch.manual_seed(0)
+    net = ref_models.get_network(hp)
+    np.savez_compressed(os.path.join(OUT, "factory.npz"), hp=repr(hp), cls=type(net).__name__,
+                        keys=np.array(sorted(net.state_dict().keys())),
+                        init_checksum=state_checksum(net.state_dict()))
+    print("factory", type(net).__name__)
+
+
+def gen_masksembles():
+    np.random.seed(3)
+    m2 = ref_utils.Masksembles2D(16, 4, 2.0).eval()
+    m1 = ref_utils.Masksembles1D(32, 4, 2.0).eval()
+    g = torch.Generator().manual_seed(5)
+    x2 = torch.randn(3, 16, 5, 5, generator=g)
+    x1 = torch.randn(3, 32, generator=g)
+    y2 = np.stack([m2(x2).numpy() for _ in range(8)])
+    y1 = np.stack([m1(x1).numpy() for _ in range(8)])
+    props = []
+    for (c, n, s) in [(512, 4, 4.0), (512, 8, 4.0), (64, 4, 4.0), (128, 4, 4.0), (256, 4, 4.0), (64, 4, 3.0),
+                      (512, 4, 6.0)]:
+        np.random.seed(11)
+        mk = ref_utils.generation_wrapper(c, n, s)
+        props.append((c, n, s, mk.shape[0], mk.shape[1], int(mk.sum(1)[0]), int((mk.sum(1) == mk.sum(1)[0]).all()),
+                      hashlib.sha256(mk.astype(np.uint8).tobytes()).hexdigest()))
+    np.savez_compressed(os.path.join(OUT, "masksembles.npz"),
+                        masks2=m2.masks.numpy(), masks1=m1.masks.numpy(), x2=x2.numpy(), x1=x1.numpy(), y2=y2, y1=y1,
+                        props=np.array(props, dtype=object), allow_pickle=True)
+    print("masksembles ok")
+
+
+def gen_metrics():
+    rng = np.random.RandomState(17)
+    N, C = 2000, 10
+    p = rng.dirichlet(np.ones(C) * 0.3, size=N)
+    y = rng.randint(0, C, size=N)
+    # make ~70 % of the argmaxes correct so the set is not degenerate
+    am = p.argmax(1)
+    flip = rng.rand(N) < 0.7
+    y = np.where(flip, am, y)
+    onehot = np.eye(C)[y]
+    fa = FullAnalysis.__new__(FullAnalysis)
+    ece = float(fa.ece_hist_binary(p, onehot).item())
+    mse = np.mean(np.sum((p - onehot) ** 2, 1))                       # results_analyzer.py:498
+    pc = np.clip(p, 1e-256, 1 - 1e-256)
+    nll = -np.sum(onehot * np.log(pc)) / N                              # :500-501
+    acc = np.sum((np.argmax(pc, 1) - np.array([np.where(r == 1)[0][0] for r in onehot])) == 0) / N   # :502
+    # _metrics accuracy vector
+    g = torch.Generator().manual_seed(23)
+    logits_list = [torch.randn(64, C, generator=g) * 2 for _ in range(4)]
+    yy = torch.randint(0, C, (64,), generator=g)
+    acc_vec4 = [float(v) for v in _MultiExitAccuracy(4, acc_tops=(1, 5))._metrics(logits_list, yy)]
+    acc_vec1 = [float(v) for v in _MultiExitAccuracy(1, acc_tops=(1, 5))._metrics(logits_list, yy)]
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), p=p, onehot=onehot, ece_hist=ece, nll=nll, mse=mse, acc=acc,
+                        logits=np.stack([l.numpy() for l in logits_list]), y=yy.numpy(),
+                        acc_vec4=np.array(acc_vec4), acc_vec1=np.array(acc_vec1))
+    print("metrics", ece, nll, mse, acc)
+
+
+def gen_philox():
+    """Mask bits of the shared convention for a few (seed, site, t, p, shape) — pins the
+    layout rule (NHWC-linear element order) independently of the model fixtures."""
+    cases = []
+    for (seed, site, t, p, shape) in [(42, 0, 0, 0.25, (2, 8, 3, 3)), (42, 3, 7, 0.5, (3, 12)),
+                                       ((1 << 40) + 5, 1, 99, 0.125, (1, 4, 2, 5)), (0, 0, 0, 0.0, (1, 8)),
+                                       (9, 2, 1, 1.0, (1, 8))]:
+        cases.append(dict(seed=seed, site=site, t=t, p=p, shape=shape,
+                          mask=philox.elementwise_mask(shape, seed, site, t, p).astype(np.uint8)))
+    np.savez_compressed(os.path.join(OUT, "philox_masks.npz"), cases=np.array(cases, dtype=object), allow_pickle=True)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_philox()
+    gen_masksembles()
+    gen_metrics()
+    gen_resnet()
