@@ -1,0 +1,105 @@
+"""ctypes binding of libbayesnn_fpga_amd.so (C ABI in include/bayesnn_fpga_amd.h).
+
+There is NO CPU fallback: if the library is missing or cannot be loaded, every product entry
+point raises.  Build it with ``python -m bayesnn_fpga_amd._build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbayesnn_fpga_amd.so")
+
+BMI_OK = 0
+SITE_NONE, SITE_ELEMENTWISE, SITE_CHANNEL, SITE_MASKSEMBLE = 0, 1, 2, 3
+OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL = 1, 2, 3, 4, 5
+PROFILE_SLOTS = 8
+PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
+                 6: "moments", 7: "finalize"}
+
+
+class Site(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("site_id", C.c_int32), ("p", C.c_float), ("num_masks", C.c_int32),
+                ("masks", C.c_void_p)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_", C.c_int32), ("out", C.c_int32), ("residual", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32),
+                ("weight", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("n_tensors", C.c_int32), ("tensors", C.POINTER(TensorDesc)), ("n_ops", C.c_int32),
+                ("ops", C.POINTER(OpDesc)), ("n_exits", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class BmiError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what} failed: {error_string(code)} ({code})")
+
+
+_lib = None
+
+_PROTOS = {
+    "bmi_version": (C.c_int, []),
+    "bmi_error_string": (C.c_char_p, [C.c_int]),
+    "bmi_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    "bmi_destroy": (C.c_int, [C.c_void_p]),
+    "bmi_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "bmi_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                            C.POINTER(C.c_int32)]),
+    "bmi_forward_mcd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bmi_finalize": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    "bmi_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bmi_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "bmi_philox_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "bmi_stem_conv_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 9 + [C.c_void_p]),
+    "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
+                                                                         C.c_uint64, C.c_int32, C.c_void_p]),
+    "bmi_mask_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
+                                 C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
+    "bmi_maxpool2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "bmi_pool_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
+                                C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
+    "bmi_linear_softmax": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
+    "bmi_moments_accumulate": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
+}
+
+EXPORTS = tuple(_PROTOS.keys())
+
+
+def lib():
+    """Loads the library (once).  Raises if it is absent — there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP library has not been built "
+                "(run `python -m bayesnn_fpga_amd._build`).  bayesnn_fpga_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def error_string(code):
+    return lib().bmi_error_string(int(code)).decode()
+
+
+def check(code, what):
+    if code != BMI_OK:
+        raise BmiError(code, what)
+
+
+def make_site(kind=SITE_NONE, site_id=0, p=0.0, num_masks=0, masks_ptr=None):
+    return Site(int(kind), int(site_id), float(p), int(num_masks), masks_ptr)

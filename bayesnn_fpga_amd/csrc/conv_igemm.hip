@@ -1,0 +1,235 @@
+// Implicit-GEMM convolution for gfx950, fp16 operands / fp32 accumulate, NHWC activations.
+//
+//   D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],   k = (ky*ks + kx)*Cin + ci
+//
+// Orientation: output CHANNELS ride the MFMA row axis (A operand = weights), PIXELS the column
+// axis (B operand = activations).  With v_mfma_f32_32x32x16_f16 a lane then owns one pixel and,
+// per accumulator quad (reg & 3), four CONSECUTIVE channels: one Philox4x32 call masks exactly
+// those four values, BN scale/bias come in as float4, and the NHWC store is an 8-byte write.
+// Both operands are K-contiguous per row (weights [Cout][k], activations [pixel][Cin]) so each
+// fragment is one ds_read_b128.
+//
+// Tile: BC channels x BP pixels x 64 deep, 256 threads (4 waves, WC x WP), double-buffered LDS
+// (one barrier per K-step), register-staged global loads issued before the MFMAs of the current
+// step.  LDS rows are 128 B; 16-byte chunk c of row r lives at chunk (c ^ ((r >> 1) & 7)), which
+// makes every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) hit 16 distinct 16-B slots.
+// Epilogue (fused): folded-BN scale/bias, residual add, ReLU, stochastic site (MCDropout via
+// Philox, channel dropout, or Masksembles channel mask), fp16 store.
+// Reference semantics: BasicBlock.forward SA/models/resnet18/resnet18.py:32-48, exit-head convs
+// :306-308/:318-319/:329, MCDropout :207-210, Masksembles2D SA/utils.py:165-169.
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 64
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int BC, int BP, int WC, int WP>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int TI = BC / WC / 32;   // 32x32 MFMA tiles per wave along channels
+    constexpr int TJ = BP / WP / 32;   // ... along pixels
+    constexpr int WROWS = BC / 32;     // weight rows staged per thread
+    constexpr int XROWS = BP / 32;     // pixel rows staged per thread
+    constexpr int TILE = (BC + BP) * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wc = wave / WP, wp = wave % WP;
+
+    // blockIdx.x walks channel tiles fastest so that the blocks sharing one pixel tile are
+    // adjacent in dispatch order.
+    const int n_ctiles = a.Cout / BC;
+    const int ctile = blockIdx.x % n_ctiles;
+    const int ptile = blockIdx.x / n_ctiles;
+    const int ch0 = ctile * BC;
+    const int pix0 = ptile * BP;
+
+    const int HoWo = a.Ho * a.Wo;
+    const int Ktot = a.ksize * a.ksize * a.Cin;
+
+    // ---- staging geometry (per thread: one 16-byte chunk of WROWS + XROWS rows) -------------
+    const int chunk = tid & 7;
+    const int r0 = tid >> 3;
+    const int st_off = r0 * 128 + ((chunk ^ ((r0 >> 1) & 7)) << 4);
+    const _Float16* wptr = a.wgt + (size_t)(ch0 + r0) * Ktot + chunk * 8;
+
+    int iy0[XROWS], ix0[XROWS];
+    const _Float16* xbase[XROWS];
+    bool vm[XROWS];
+#pragma unroll
+    for (int j = 0; j < XROWS; ++j) {
+        const int m = pix0 + r0 + 32 * j;
+        vm[j] = m < a.M;
+        const int mm = vm[j] ? m : 0;
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        iy0[j] = oy * a.stride - a.pad;
+        ix0[j] = ox * a.stride - a.pad;
+        xbase[j] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + chunk * 8;
+    }
+
+    uint4 wreg[WROWS], xreg[XROWS];
+    auto gload = [&](int ky, int kx, int c0) {
+        const int koff = (ky * a.ksize + kx) * a.Cin + c0;
+#pragma unroll
+        for (int j = 0; j < WROWS; ++j) wreg[j] = *(const uint4*)(wptr + (size_t)(32 * j) * Ktot + koff);
+#pragma unroll
+        for (int j = 0; j < XROWS; ++j) {
+            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+            const bool ok = vm[j] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *(const uint4*)(xbase[j] + (size_t)(iy * a.W + ix) * a.Cin + c0);
+            xreg[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * TILE;
+#pragma unroll
+        for (int j = 0; j < WROWS; ++j) *(uint4*)(base + st_off + j * 32 * 128) = wreg[j];
+#pragma unroll
+        for (int j = 0; j < XROWS; ++j) *(uint4*)(base + BC * 128 + st_off + j * 32 * 128) = xreg[j];
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nK = a.ksize * a.ksize * (a.Cin / BK);
+    int ky = 0, kx = 0, c0 = 0;
+    gload(ky, kx, c0);
+    lstore(0);
+    __syncthreads();
+
+    const int sw_r = (r >> 1) & 7;
+    const int a_row0 = wc * (BC / WC) + r;
+    const int b_row0 = wp * (BP / WP) + r;
+
+    for (int ks = 0; ks < nK; ++ks) {
+        const int buf = ks & 1;
+        const bool more = ks + 1 < nK;
+        if (more) {
+            c0 += BK;
+            if (c0 == a.Cin) {
+                c0 = 0;
+                if (++kx == a.ksize) { kx = 0; ++ky; }
+            }
+            gload(ky, kx, c0);
+        }
+        const char* wt = smem + buf * TILE;
+        const char* xt = wt + BC * 128;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int coff = (((2 * kk + hh) ^ sw_r) << 4);
+            half8 af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wt + (a_row0 + 32 * i) * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(xt + (b_row0 + 32 * j) * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    const int BHW = a.B * HoWo;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int m = pix0 + wp * (BP / WP) + 32 * j + r;
+        if (m >= a.M) continue;
+        const int n = m / HoWo;
+        const int rem = m - n * HoWo;
+        const int tl = m / BHW;
+        const int e_pix = m - tl * BHW;
+        const int t = a.t0 + tl;
+        const _Float16* resp = a.res ? a.res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout : nullptr;
+        _Float16* outp = a.out + (size_t)m * a.Cout;
+        const float* mrow = nullptr;
+        if (a.site.kind == BMI_SITE_MASKSEMBLE)
+            mrow = a.site.masks + (size_t)((a.site.cnt0 + t) % a.site.num_masks) * a.Cout;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c4 = ch0 + wc * (BC / WC) + 32 * i + 8 * g4 + 4 * hh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
+                if (a.scale) {
+                    const float4 s4 = *(const float4*)(a.scale + c4);
+                    v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
+                }
+                if (a.bias) {
+                    const float4 b4 = *(const float4*)(a.bias + c4);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (resp) {
+                    const half4 r4 = *(const half4*)(resp + c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.site.kind == BMI_SITE_ELEMENTWISE) {
+                    const uint64_t g = ((uint64_t)e_pix * a.Cout + c4) >> 2;
+                    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t,
+                                                     (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[e] * a.site.scale : 0.f;
+                } else if (a.site.kind == BMI_SITE_CHANNEL) {
+                    const int b = e_pix / HoWo;
+                    const uint64_t g = ((uint64_t)b * a.Cout + c4) >> 2;
+                    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t,
+                                                     (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[e] * a.site.scale : 0.f;
+                } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
+                    const float4 k4 = *(const float4*)(mrow + c4);
+                    v[0] *= k4.x; v[1] *= k4.y; v[2] *= k4.z; v[3] *= k4.w;
+                }
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                *(half4*)(outp + c4) = o;
+            }
+        }
+    }
+}
+
+template <int BC, int BP, int WC, int WP>
+static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+    const int n_ctiles = a.Cout / BC;
+    const long n_ptiles = ((long)a.M + BP - 1) / BP;
+    const long blocks = n_ptiles * n_ctiles;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_INVALID;
+    hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+    if (a.Cin % BK != 0 || a.Cout % 64 != 0) return BMI_ERR_UNSUPPORTED;
+    if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
+    if (a.res && a.res_mod <= 0) return BMI_ERR_INVALID;
+    if (a.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2>(a, s);
+    return launch_cfg<64, 128, 1, 4>(a, s);
+}

@@ -1,0 +1,541 @@
+// Graph executor behind the C ABI (include/bayesnn_fpga_amd.h).
+//
+// What it replaces in the reference: the Python T-loop of FullAnalysis._get_output
+// (SA/train/results_analyzer.py:236-248) around ResNet18MCEarlyExit.forward
+// (SA/models/resnet18/resnet18.py:302-346).  Instead of T sequential full-model forwards it
+//   1. marks every tensor that does not depend on a stochastic site as DETERMINISTIC and runs
+//      that prefix once per batch (the reference's own cost model assumes exactly this split,
+//      results_analyzer.py:632-637);
+//   2. folds `chunk` Monte-Carlo samples into the GEMM M dimension of every suffix op
+//      (image index n = t_local * B + b), so weights are read once per chunk;
+//   3. accumulates softmax moments per exit in float64 on the device.
+// Activation buffers live in ONE caller-owned workspace; the suffix tensors are packed by
+// live range (first-fit) so a chunk's working set stays small enough for the Infinity Cache.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+struct TensorInfo {
+    int h = 0, w = 0, c = 0;
+    bool stoch = false;
+    int first = -1, last = -1;  // suffix op indices (stochastic tensors only)
+    size_t offset = 0;          // byte offset in the workspace
+};
+
+struct OpInfo {
+    bmi_op_desc d;
+    bool stoch = false;
+    int ho = 0, wo = 0, cout = 0;
+};
+
+struct ProfRec {
+    int slot;
+    hipEvent_t a, b;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct bmi_engine_s {
+    std::vector<TensorInfo> tensors;
+    std::vector<OpInfo> prefix, suffix;
+    int n_exits = 0, out_dim = 0;
+    int64_t prefix_macs = 0, suffix_macs = 0;
+    // plan
+    int max_batch = 0, chunk = 0;
+    size_t ws_bytes = 0, feat_off = 0, probs_off = 0, logits_off = 0;
+    int max_head_k = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+};
+
+SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
+    SiteArgs s;
+    std::memset(&s, 0, sizeof(s));
+    s.scale = 1.f;
+    if (!site) return s;
+    s.kind = site->kind;
+    s.site_id = site->site_id;
+    s.seed_lo = (uint32_t)seed;
+    s.seed_hi = (uint32_t)(seed >> 32);
+    if (site->kind == BMI_SITE_ELEMENTWISE || site->kind == BMI_SITE_CHANNEL) {
+        s.thresh = bmi_drop_threshold(site->p, &s.drop_all);
+        s.scale = bmi_drop_scale(site->p);
+    } else if (site->kind == BMI_SITE_MASKSEMBLE) {
+        s.masks = site->masks;
+        s.num_masks = site->num_masks;
+        s.cnt0 = mask_cnt0;
+    }
+    return s;
+}
+
+static bool site_ok(const bmi_site& s) {
+    switch (s.kind) {
+        case BMI_SITE_NONE: return true;
+        case BMI_SITE_ELEMENTWISE:
+        case BMI_SITE_CHANNEL: return s.p >= 0.f && s.p <= 1.f && s.site_id >= 0;
+        case BMI_SITE_MASKSEMBLE: return s.num_masks > 0 && s.masks != nullptr && s.site_id >= 0;
+        default: return false;
+    }
+}
+
+extern "C" {
+
+int bmi_version(void) { return BMI_VERSION; }
+
+const char* bmi_error_string(int code) {
+    switch (code) {
+        case BMI_OK: return "ok";
+        case BMI_ERR_INVALID: return "invalid argument or descriptor";
+        case BMI_ERR_NOMEM: return "workspace too small";
+        case BMI_ERR_HIP: return "HIP runtime / launch failure";
+        case BMI_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+        default: return "unknown error";
+    }
+}
+
+int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
+    if (!desc || !out || desc->n_tensors < 2 || desc->n_ops < 1 || !desc->tensors || !desc->ops) return BMI_ERR_INVALID;
+    if (desc->n_exits < 1 || desc->out_dim < 1) return BMI_ERR_INVALID;
+    if (desc->out_dim > 128) return BMI_ERR_UNSUPPORTED;
+    bmi_engine_s* e = new (std::nothrow) bmi_engine_s();
+    if (!e) return BMI_ERR_NOMEM;
+    e->n_exits = desc->n_exits;
+    e->out_dim = desc->out_dim;
+    e->tensors.resize(desc->n_tensors);
+    for (int i = 0; i < desc->n_tensors; ++i) {
+        const bmi_tensor_desc& t = desc->tensors[i];
+        if (t.h < 1 || t.w < 1 || t.c < 1) { delete e; return BMI_ERR_INVALID; }
+        e->tensors[i].h = t.h; e->tensors[i].w = t.w; e->tensors[i].c = t.c;
+    }
+    std::vector<char> written(desc->n_tensors, 0);
+    written[0] = 1;  // network input
+    std::vector<char> exit_seen(desc->n_exits, 0);
+    int rc = BMI_OK;
+    for (int k = 0; k < desc->n_ops && rc == BMI_OK; ++k) {
+        OpInfo op;
+        op.d = desc->ops[k];
+        const bmi_op_desc& d = op.d;
+        auto tensor_ok = [&](int id) { return id >= 0 && id < desc->n_tensors; };
+        if (!tensor_ok(d.in) || !written[d.in] || !site_ok(d.site)) { rc = BMI_ERR_INVALID; break; }
+        const TensorInfo tin = e->tensors[d.in];
+        bool in_st = tin.stoch;
+        switch (d.kind) {
+            case BMI_OP_STEM:
+            case BMI_OP_CONV: {
+                if (!tensor_ok(d.out) || d.out == 0 || written[d.out] || !d.weight || d.ksize < 1 || d.stride < 1 || d.pad < 0) {
+                    rc = BMI_ERR_INVALID; break;
+                }
+                if ((d.kind == BMI_OP_STEM) != (d.in == 0)) { rc = BMI_ERR_INVALID; break; }
+                const TensorInfo to = e->tensors[d.out];  // by value: the split below grows the vector
+                op.ho = (tin.h + 2 * d.pad - d.ksize) / d.stride + 1;
+                op.wo = (tin.w + 2 * d.pad - d.ksize) / d.stride + 1;
+                op.cout = to.c;
+                if (op.ho != to.h || op.wo != to.w) { rc = BMI_ERR_INVALID; break; }
+                if (d.kind == BMI_OP_CONV && (tin.c % 64 != 0 || to.c % 64 != 0)) { rc = BMI_ERR_UNSUPPORTED; break; }
+                if (d.kind == BMI_OP_STEM && (to.c % 8 != 0 || to.c * d.ksize * d.ksize * tin.c > 4096 || d.residual >= 0)) {
+                    rc = BMI_ERR_UNSUPPORTED; break;
+                }
+                if (d.residual >= 0) {
+                    if (!tensor_ok(d.residual) || !written[d.residual] || d.residual == 0) { rc = BMI_ERR_INVALID; break; }
+                    const TensorInfo& tr = e->tensors[d.residual];
+                    if (tr.h != to.h || tr.w != to.w || tr.c != to.c) { rc = BMI_ERR_INVALID; break; }
+                    in_st = in_st || tr.stoch;
+                }
+                const int64_t macs = (int64_t)op.ho * op.wo * op.cout * d.ksize * d.ksize * tin.c;
+                if (!in_st && d.site.kind != BMI_SITE_NONE) {
+                    // deterministic conv feeding a site: keep the conv in the once-per-batch prefix
+                    // and apply the site while expanding to the folded sample batch.
+                    TensorInfo tmp = to;
+                    tmp.stoch = false;
+                    e->tensors.push_back(tmp);
+                    const int tmp_id = (int)e->tensors.size() - 1;
+                    OpInfo conv = op;
+                    conv.d.out = tmp_id;
+                    conv.d.site.kind = BMI_SITE_NONE;
+                    conv.stoch = false;
+                    e->prefix.push_back(conv);
+                    e->prefix_macs += macs;
+                    OpInfo m;
+                    std::memset(&m.d, 0, sizeof(m.d));
+                    m.d.kind = BMI_OP_MASK;
+                    m.d.in = tmp_id;
+                    m.d.out = d.out;
+                    m.d.residual = -1;
+                    m.d.site = d.site;
+                    m.stoch = true;
+                    m.ho = to.h; m.wo = to.w; m.cout = to.c;
+                    e->suffix.push_back(m);
+                    e->tensors[d.out].stoch = true;
+                } else {
+                    op.stoch = in_st || d.site.kind != BMI_SITE_NONE;
+                    e->tensors[d.out].stoch = op.stoch;
+                    (op.stoch ? e->suffix : e->prefix).push_back(op);
+                    (op.stoch ? e->suffix_macs : e->prefix_macs) += macs;
+                }
+                written[d.out] = 1;
+                break;
+            }
+            case BMI_OP_MASK: {
+                if (!tensor_ok(d.out) || d.out == 0 || written[d.out] || d.in == 0 || d.site.kind == BMI_SITE_NONE) {
+                    rc = BMI_ERR_INVALID; break;
+                }
+                const TensorInfo& to = e->tensors[d.out];
+                if (to.h != tin.h || to.w != tin.w || to.c != tin.c) { rc = BMI_ERR_INVALID; break; }
+                if (tin.c % 8 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                op.stoch = true;
+                op.ho = to.h; op.wo = to.w; op.cout = to.c;
+                e->tensors[d.out].stoch = true;
+                e->suffix.push_back(op);
+                written[d.out] = 1;
+                break;
+            }
+            case BMI_OP_MAXPOOL: {
+                if (!tensor_ok(d.out) || d.out == 0 || written[d.out] || d.in == 0) { rc = BMI_ERR_INVALID; break; }
+                const TensorInfo& to = e->tensors[d.out];
+                if (to.h * 2 != tin.h || to.w * 2 != tin.w || to.c != tin.c) { rc = BMI_ERR_INVALID; break; }
+                if (tin.c % 8 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                op.stoch = in_st;
+                op.ho = to.h; op.wo = to.w; op.cout = to.c;
+                e->tensors[d.out].stoch = in_st;
+                (in_st ? e->suffix : e->prefix).push_back(op);
+                written[d.out] = 1;
+                break;
+            }
+            case BMI_OP_HEAD: {
+                if (d.in == 0 || d.out < 0 || d.out >= desc->n_exits || exit_seen[d.out] || !d.weight || !d.bias) {
+                    rc = BMI_ERR_INVALID; break;
+                }
+                if (tin.c % 8 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                exit_seen[d.out] = 1;
+                op.stoch = true;  // heads always run per sample (they emit per-sample softmax)
+                op.cout = desc->out_dim;
+                e->suffix.push_back(op);
+                e->suffix_macs += (int64_t)tin.c * desc->out_dim;
+                e->max_head_k = std::max(e->max_head_k, tin.c);
+                break;
+            }
+            default: rc = BMI_ERR_INVALID;
+        }
+    }
+    if (rc == BMI_OK)
+        for (int x = 0; x < desc->n_exits; ++x)
+            if (!exit_seen[x]) rc = BMI_ERR_INVALID;
+    if (rc != BMI_OK) { delete e; return rc; }
+    // live ranges of the stochastic tensors over the suffix
+    for (int k = 0; k < (int)e->suffix.size(); ++k) {
+        const bmi_op_desc& d = e->suffix[k].d;
+        auto touch = [&](int id) {
+            if (id < 0) return;
+            TensorInfo& t = e->tensors[id];
+            if (!t.stoch) return;
+            if (t.first < 0) t.first = k;
+            t.last = k;
+        };
+        touch(d.in);
+        if (d.kind == BMI_OP_CONV) touch(d.residual);
+        if (d.kind != BMI_OP_HEAD) touch(d.out);
+    }
+    *out = e;
+    return BMI_OK;
+}
+
+int bmi_destroy(bmi_handle h) {
+    if (!h) return BMI_ERR_INVALID;
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& ev : h->pool) (void)hipEventDestroy(ev);
+    delete h;
+    return BMI_OK;
+}
+
+int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* workspace_bytes) {
+    if (!h || max_batch < 1 || chunk_samples < 1 || !workspace_bytes) return BMI_ERR_INVALID;
+    const size_t B = (size_t)max_batch, NS = (size_t)max_batch * chunk_samples;
+    for (const TensorInfo& t : h->tensors)  // pixel indices (N * H * W) stay inside int32
+        if (NS * t.h * t.w >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;
+    size_t off = 0;
+    for (size_t i = 1; i < h->tensors.size(); ++i) {
+        TensorInfo& t = h->tensors[i];
+        if (t.stoch) continue;
+        t.offset = off;
+        off += align_up(B * t.h * t.w * t.c * 2, 256);
+    }
+    // first-fit packing of the suffix tensors by live range
+    struct Blk { size_t off, size; int last; };
+    std::vector<Blk> live;
+    std::vector<int> order;
+    for (size_t i = 1; i < h->tensors.size(); ++i)
+        if (h->tensors[i].stoch && h->tensors[i].first >= 0) order.push_back((int)i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return h->tensors[a].first < h->tensors[b].first; });
+    const size_t st_base = off;
+    size_t st_peak = 0;
+    for (int id : order) {
+        TensorInfo& t = h->tensors[id];
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.last < t.first; }), live.end());
+        std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        const size_t size = align_up(NS * t.h * t.w * t.c * 2, 256);
+        size_t pos = 0;
+        for (const Blk& b : live) {
+            if (pos + size <= b.off) break;
+            pos = std::max(pos, b.off + b.size);
+        }
+        t.offset = st_base + pos;
+        live.push_back({pos, size, t.last});
+        st_peak = std::max(st_peak, pos + size);
+    }
+    off = st_base + st_peak;
+    h->feat_off = off;
+    off += align_up(NS * (size_t)std::max(h->max_head_k, 8) * 4, 256);
+    h->probs_off = off;
+    off += align_up((size_t)h->n_exits * NS * h->out_dim * 4, 256);
+    h->logits_off = off;
+    off += align_up((size_t)h->n_exits * NS * h->out_dim * 4, 256);
+    h->ws_bytes = off;
+    h->max_batch = max_batch;
+    h->chunk = chunk_samples;
+    *workspace_bytes = off;
+    return BMI_OK;
+}
+
+int bmi_query(bmi_handle h, int64_t* prefix_macs, int64_t* suffix_macs, int32_t* n_prefix_ops, int32_t* n_suffix_ops) {
+    if (!h) return BMI_ERR_INVALID;
+    if (prefix_macs) *prefix_macs = h->prefix_macs;
+    if (suffix_macs) *suffix_macs = h->suffix_macs;
+    if (n_prefix_ops) *n_prefix_ops = (int32_t)h->prefix.size();
+    if (n_suffix_ops) *n_suffix_ops = (int32_t)h->suffix.size();
+    return BMI_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct ProfScope {
+    bmi_engine_s* e;
+    hipStream_t s;
+    ProfRec r;
+    bool on;
+    ProfScope(bmi_engine_s* e_, int slot, hipStream_t s_) : e(e_), s(s_), on(e_->profiling) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t ev;
+            if (!e->pool.empty()) { ev = e->pool.back(); e->pool.pop_back(); }
+            else (void)hipEventCreate(&ev);
+            return ev;
+        };
+        r.slot = slot; r.a = get(); r.b = get();
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        e->recs.push_back(r);
+    }
+};
+
+int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, int B, int t0, uint64_t seed, int cnt0,
+           float* feat, float* probs, float* logits, hipStream_t s) {
+    const bmi_op_desc& d = op.d;
+    const TensorInfo& tin = e->tensors[d.in];
+    ProfScope prof(e, d.kind, s);
+    switch (d.kind) {
+        case BMI_OP_STEM:
+            return launch_stem_conv(x, (const float*)d.weight, d.scale, d.bias, (_Float16*)(ws + e->tensors[d.out].offset), N,
+                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, s);
+        case BMI_OP_CONV: {
+            ConvArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.in = (const _Float16*)(ws + tin.offset);
+            a.wgt = (const _Float16*)d.weight;
+            a.scale = d.scale; a.bias = d.bias;
+            a.out = (_Float16*)(ws + e->tensors[d.out].offset);
+            a.N = N;
+            a.in_mod = tin.stoch ? N : B;
+            if (d.residual >= 0) {
+                a.res = (const _Float16*)(ws + e->tensors[d.residual].offset);
+                a.res_mod = e->tensors[d.residual].stoch ? N : B;
+            }
+            a.H = tin.h; a.W = tin.w; a.Cin = tin.c;
+            a.Ho = op.ho; a.Wo = op.wo; a.Cout = op.cout;
+            a.ksize = d.ksize; a.stride = d.stride; a.pad = d.pad; a.relu = d.relu;
+            a.M = N * op.ho * op.wo;
+            a.B = B; a.t0 = t0;
+            a.site = resolve_site(&d.site, seed, cnt0);
+            return launch_conv_igemm(a, s);
+        }
+        case BMI_OP_MASK: {
+            EltArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.in = (const _Float16*)(ws + tin.offset);
+            a.out = ws + e->tensors[d.out].offset;
+            a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
+            a.site = resolve_site(&d.site, seed, cnt0);
+            return launch_mask_apply(a, s);
+        }
+        case BMI_OP_MAXPOOL:
+            return launch_maxpool2((const _Float16*)(ws + tin.offset), (_Float16*)(ws + e->tensors[d.out].offset), N, tin.h,
+                                   tin.w, tin.c, s);
+        case BMI_OP_HEAD: {
+            EltArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.in = (const _Float16*)(ws + tin.offset);
+            a.out = feat;
+            a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
+            a.site = resolve_site(&d.site, seed, cnt0);
+            int rc = launch_pool_mask(a, s);
+            if (rc != BMI_OK) return rc;
+            const size_t eo = (size_t)d.out * N * e->out_dim;
+            return launch_linear_softmax(feat, (const float*)d.weight, d.bias, logits + eo, probs + eo, N, tin.c, e->out_dim, s);
+        }
+    }
+    return BMI_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_begin, int32_t t_count, uint64_t seed,
+                    int32_t mask_cnt0, double* S1, double* S2, double* SL, void* workspace, size_t workspace_bytes,
+                    bmi_stream stream) {
+    if (!h || !x_nchw || !S1 || !S2 || !SL || !workspace) return BMI_ERR_INVALID;
+    if (batch < 1 || t_count < 1 || t_begin < 0 || mask_cnt0 < 0) return BMI_ERR_INVALID;
+    if (h->max_batch == 0 || batch > h->max_batch) return BMI_ERR_INVALID;
+    if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* feat = (float*)(ws + h->feat_off);
+    float* probs = (float*)(ws + h->probs_off);
+    float* logits = (float*)(ws + h->logits_off);
+    for (const OpInfo& op : h->prefix) {
+        const int rc = run_op(h, op, x_nchw, ws, batch, batch, 0, seed, mask_cnt0, feat, probs, logits, s);
+        if (rc != BMI_OK) return rc;
+    }
+    for (int t0 = t_begin; t0 < t_begin + t_count; t0 += h->chunk) {
+        const int tc = std::min(h->chunk, t_begin + t_count - t0);
+        const int N = tc * batch;
+        for (const OpInfo& op : h->suffix) {
+            const int rc = run_op(h, op, x_nchw, ws, N, batch, t0, seed, mask_cnt0, feat, probs, logits, s);
+            if (rc != BMI_OK) return rc;
+        }
+        ProfScope prof(h, 6, s);
+        const int rc = launch_moments(probs, logits, S1, S2, SL, tc, batch, h->out_dim, h->n_exits,
+                                      (size_t)N * h->out_dim, (size_t)batch * h->out_dim, s);
+        if (rc != BMI_OK) return rc;
+    }
+    return BMI_OK;
+}
+
+int bmi_finalize(int64_t n, int32_t t_total, const double* S1, const double* S2, const double* SL, double* mean,
+                 double* var, double* logit_mean, bmi_stream stream) {
+    if (!S1 || !S2 || !SL || !mean || !var || !logit_mean) return BMI_ERR_INVALID;
+    return launch_finalize(n, t_total, S1, S2, SL, mean, var, logit_mean, (hipStream_t)stream);
+}
+
+int bmi_profile_enable(bmi_handle h, int32_t enable) {
+    if (!h) return BMI_ERR_INVALID;
+    h->profiling = enable != 0;
+    return BMI_OK;
+}
+
+int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launches[BMI_PROFILE_SLOTS]) {
+    if (!h || !ms || !launches) return BMI_ERR_INVALID;
+    for (int i = 0; i < BMI_PROFILE_SLOTS; ++i) { ms[i] = 0; launches[i] = 0; }
+    int rc = BMI_OK;
+    for (auto& r : h->recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = BMI_ERR_HIP;
+        if (r.slot >= 0 && r.slot < BMI_PROFILE_SLOTS) { ms[r.slot] += t; launches[r.slot] += 1; }
+        h->pool.push_back(r.a);
+        h->pool.push_back(r.b);
+    }
+    h->recs.clear();
+    return rc;
+}
+
+// ---- single-kernel entry points -------------------------------------------------------------
+
+int bmi_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int32_t site, int32_t t, float p, bmi_stream stream) {
+    if (!keep) return BMI_ERR_INVALID;
+    return launch_philox_mask(keep, n, seed, site, t, p, (hipStream_t)stream);
+}
+
+int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* scale, const float* bias, void* out_nhwc,
+                      int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t ksize, int32_t stride,
+                      int32_t pad, int32_t relu, bmi_stream stream) {
+    if (!x_nchw || !weight || !out_nhwc) return BMI_ERR_INVALID;
+    return launch_stem_conv(x_nchw, weight, scale, bias, (_Float16*)out_nhwc, n, cin, h, w, cout, ksize, stride, pad, relu,
+                            (hipStream_t)stream);
+}
+
+int bmi_conv_igemm_fwd(const void* in, const void* weight, const float* scale, const float* bias, const void* res,
+                       void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
+                       int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
+                       int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
+    if (!in || !weight || !out || ksize < 1 || stride < 1 || pad < 0) return BMI_ERR_INVALID;
+    if (site && !site_ok(*site)) return BMI_ERR_INVALID;
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.scale = scale; a.bias = bias;
+    a.res = (const _Float16*)res; a.out = (_Float16*)out;
+    a.N = n; a.in_mod = in_mod; a.res_mod = res_mod;
+    a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
+    a.Ho = (h + 2 * pad - ksize) / stride + 1;
+    a.Wo = (w + 2 * pad - ksize) / stride + 1;
+    a.ksize = ksize; a.stride = stride; a.pad = pad; a.relu = relu;
+    a.M = n * a.Ho * a.Wo;
+    a.B = batch; a.t0 = t0;
+    a.site = resolve_site(site, seed, mask_cnt0);
+    return launch_conv_igemm(a, (hipStream_t)stream);
+}
+
+static int elt_args(EltArgs& a, const void* in, void* out, int n, int in_mod, int hw, int c, const bmi_site* site, int batch,
+                    int t0, uint64_t seed, int cnt0) {
+    if (!in || !out) return BMI_ERR_INVALID;
+    if (site && !site_ok(*site)) return BMI_ERR_INVALID;
+    std::memset(&a, 0, sizeof(a));
+    a.in = (const _Float16*)in; a.out = out; a.N = n; a.in_mod = in_mod; a.HW = hw; a.C = c; a.B = batch; a.t0 = t0;
+    a.site = resolve_site(site, seed, cnt0);
+    return BMI_OK;
+}
+
+int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
+                   int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
+    EltArgs a;
+    const int rc = elt_args(a, in, out, n, in_mod, hw, c, site, batch, t0, seed, mask_cnt0);
+    return rc != BMI_OK ? rc : launch_mask_apply(a, (hipStream_t)stream);
+}
+
+int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c, bmi_stream stream) {
+    if (!in || !out) return BMI_ERR_INVALID;
+    return launch_maxpool2((const _Float16*)in, (_Float16*)out, n, h, w, c, (hipStream_t)stream);
+}
+
+int bmi_pool_mask(const void* in, float* feat, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
+                  int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
+    EltArgs a;
+    const int rc = elt_args(a, in, feat, n, in_mod, hw, c, site, batch, t0, seed, mask_cnt0);
+    return rc != BMI_OK ? rc : launch_pool_mask(a, (hipStream_t)stream);
+}
+
+int bmi_linear_softmax(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
+                       int32_t n, int32_t k, int32_t out_dim, bmi_stream stream) {
+    if (!feat || !weight_pad || !bias || !logits || !probs) return BMI_ERR_INVALID;
+    return launch_linear_softmax(feat, weight_pad, bias, logits, probs, n, k, out_dim, (hipStream_t)stream);
+}
+
+int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,
+                           int32_t batch, int32_t out_dim, bmi_stream stream) {
+    if (!probs || !logits || !S1 || !S2 || !SL) return BMI_ERR_INVALID;
+    return launch_moments(probs, logits, S1, S2, SL, tc, batch, out_dim, 1, 0, 0, (hipStream_t)stream);
+}
+
+}  // extern "C"

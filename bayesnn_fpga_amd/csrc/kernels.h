@@ -1,0 +1,57 @@
+// Internal launch interfaces shared by the kernels and the engine (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bayesnn_fpga_amd.h"
+#include "philox.h"
+
+struct ConvArgs {
+    const _Float16* in;
+    const _Float16* wgt;  // [Cout][k*k*Cin]
+    const float* scale;   // may be null
+    const float* bias;    // may be null
+    const _Float16* res;  // may be null
+    _Float16* out;
+    int N;        // output images in this launch (= samples_in_chunk * B in the suffix)
+    int in_mod;   // input image = n % in_mod  (B when the input is deterministic)
+    int res_mod;
+    int H, W, Cin;
+    int Ho, Wo, Cout;
+    int ksize, stride, pad;
+    int relu;
+    int M;         // N * Ho * Wo
+    int B;         // images per Monte-Carlo sample
+    int t0;        // first sample index of this launch
+    SiteArgs site;
+};
+
+struct EltArgs {  // MASK / POOL ops
+    const _Float16* in;
+    void* out;    // MASK: fp16 [N][HW][C]; POOL: fp32 [N][C]
+    int N, in_mod, HW, C;
+    int B, t0;
+    SiteArgs site;
+};
+
+int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
+                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s);
+int launch_mask_apply(const EltArgs& a, hipStream_t s);
+int launch_pool_mask(const EltArgs& a, hipStream_t s);
+int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, hipStream_t s);
+int launch_linear_softmax(const float* feat, const float* w, const float* bias, float* logits, float* probs, int n,
+                          int k, int out_dim, hipStream_t s);
+int launch_moments(const float* probs, const float* logits, double* S1, double* S2, double* SL, int tc, int batch,
+                   int out_dim, int n_exits, size_t exit_stride_scratch, size_t exit_stride_S, hipStream_t s);
+int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
+                    double* var, double* lm, hipStream_t s);
+int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
+
+SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0);
+
+#define BMI_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return BMI_ERR_HIP;          \
+    } while (0)

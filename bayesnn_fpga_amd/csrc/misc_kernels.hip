@@ -1,0 +1,278 @@
+// Non-GEMM kernels of the path (all HBM/L2-bound, 16-byte accesses per lane):
+//   stem_conv      fp32 NCHW network input -> conv(Cin<=4)+BN(+ReLU) -> fp16 NHWC
+//                  (ResNet stem, SA/models/resnet18/resnet18.py:303: no ReLU after bn1)
+//   mask_apply     stand-alone stochastic site; also expands a deterministic tensor [B,...] to
+//                  the folded [samples*B,...] batch (MCDropout :207-210 / Masksembles2D utils.py:165-169)
+//   pool_mask      F.avg_pool2d(F.relu(x), HxW) + flatten + exit dropout (:309-313) -> fp32 features
+//   maxpool2       VGG block-end MaxPool2d(2,2) (SA/models/vgg19/vgg19.py:127)
+//   moments        S1 += p, S2 += p^2, SL += logit over the samples of a chunk (float64;
+//                  results_analyzer.py:247-248 averages in float64)
+//   finalize       mean / variance / mean logit
+//   philox_mask    keep bits, for unit tests
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void site_mask8(const SiteArgs& s, float v[8], uint64_t elem0, int t, const float* mrow) {
+    // elem0: element index of v[0] (multiple of 8 within the site's index space)
+    if (s.kind == BMI_SITE_ELEMENTWISE || s.kind == BMI_SITE_CHANNEL) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint64_t g = (elem0 >> 2) + q;
+            const philox4 rn =
+                philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t, (uint32_t)s.site_id, s.seed_lo, s.seed_hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[4 * q + e] = (!s.drop_all && rn.w[e] >= s.thresh) ? v[4 * q + e] * s.scale : 0.f;
+        }
+    } else if (s.kind == BMI_SITE_MASKSEMBLE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= mrow[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_apply_kernel(EltArgs a) {
+    const int cg = a.C >> 3;  // 8-channel groups per pixel
+    const long total = (long)a.N * a.HW * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg) * 8;
+        const long pix = i / cg;  // n*HW + p
+        const int n = (int)(pix / a.HW);
+        const int p = (int)(pix - (long)n * a.HW);
+        const int tl = n / a.B, b = n - tl * a.B;
+        const int t = a.t0 + tl;
+        const half8 x = *(const half8*)(a.in + ((size_t)(n % a.in_mod) * a.HW + p) * a.C + c8);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+        const uint64_t elem0 = a.site.kind == BMI_SITE_CHANNEL ? (uint64_t)b * a.C + c8
+                                                                : ((uint64_t)b * a.HW + p) * a.C + c8;
+        const float* mrow = a.site.kind == BMI_SITE_MASKSEMBLE
+                                ? a.site.masks + (size_t)((a.site.cnt0 + t) % a.site.num_masks) * a.C + c8
+                                : nullptr;
+        site_mask8(a.site, v, elem0, t, mrow);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+        *(half8*)((_Float16*)a.out + ((size_t)n * a.HW + p) * a.C + c8) = o;
+    }
+}
+
+int launch_mask_apply(const EltArgs& a, hipStream_t s) {
+    if (a.C % 8 != 0) return BMI_ERR_UNSUPPORTED;
+    if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
+    const long total = (long)a.N * a.HW * (a.C >> 3);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_mask_kernel(EltArgs a) {
+    const int cg = a.C >> 3;
+    const long total = (long)a.N * cg;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % cg) * 8;
+    const int n = (int)(i / cg);
+    const int tl = n / a.B, b = n - tl * a.B;
+    const int t = a.t0 + tl;
+    const _Float16* src = a.in + (size_t)(n % a.in_mod) * a.HW * a.C + c8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < a.HW; ++p) {
+        const half8 x = *(const half8*)(src + (size_t)p * a.C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += fmaxf((float)x[e], 0.f);  // F.relu before the pool
+    }
+    const float inv = 1.0f / (float)a.HW;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= inv;
+    const float* mrow = a.site.kind == BMI_SITE_MASKSEMBLE
+                            ? a.site.masks + (size_t)((a.site.cnt0 + t) % a.site.num_masks) * a.C + c8
+                            : nullptr;
+    site_mask8(a.site, v, (uint64_t)b * a.C + c8, t, mrow);  // [B, C] tensor: element = b*C + c
+    float* o = (float*)a.out + (size_t)n * a.C + c8;
+    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+int launch_pool_mask(const EltArgs& a, hipStream_t s) {
+    if (a.C % 8 != 0) return BMI_ERR_UNSUPPORTED;
+    if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || a.HW <= 0) return BMI_ERR_INVALID;
+    const long total = (long)a.N * (a.C >> 3);
+    hipLaunchKernelGGL(pool_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C) {
+    const int cg = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg) * 8;
+        long q = i / cg;
+        const int ox = (int)(q % Wo); q /= Wo;
+        const int oy = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        const _Float16* p = in + (((size_t)n * H + 2 * oy) * W + 2 * ox) * C + c8;
+        const half8 a0 = *(const half8*)p, a1 = *(const half8*)(p + C);
+        const half8 a2 = *(const half8*)(p + (size_t)W * C), a3 = *(const half8*)(p + (size_t)W * C + C);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float m = fmaxf(fmaxf((float)a0[e], (float)a1[e]), fmaxf((float)a2[e], (float)a3[e]));
+            o[e] = (_Float16)m;
+        }
+        *(half8*)(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c8) = o;
+    }
+}
+
+int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, hipStream_t s) {
+    if (c % 8 != 0 || (h & 1) || (w & 1)) return BMI_ERR_UNSUPPORTED;
+    const long total = (long)n * (h / 2) * (w / 2) * (c / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks <= 0) return BMI_ERR_INVALID;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n, h, w, c);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct convolution for the 3-channel network input.  One thread = one output pixel x 8 output
+// channels; weights [Cout][k][k][Cin] fp32 staged in LDS.  fp32 math, fp16 NHWC store.
+#define STEM_MAX_W 4096  // floats of weight in LDS (64 x 3x3x3 = 1728)
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ bias,
+                                                        _Float16* __restrict__ out, int N, int Cin, int H, int W, int Cout,
+                                                        int ks, int stride, int pad, int Ho, int Wo, int relu) {
+    __shared__ float wl[STEM_MAX_W];
+    const int kvol = ks * ks * Cin;
+    for (int i = threadIdx.x; i < Cout * kvol; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    const int cg = Cout >> 3;
+    const long total = (long)N * Ho * Wo * cg;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % cg) * 8;
+    long q = i / cg;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ky = 0; ky < ks; ++ky) {
+        const int iy = oy * stride - pad + ky;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < ks; ++kx) {
+            const int ix = ox * stride - pad + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float xv = x[(((size_t)n * Cin + ci) * H + iy) * W + ix];
+                const int wk = (ky * ks + kx) * Cin + ci;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(xv, wl[(c8 + e) * kvol + wk], acc[e]);
+            }
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = acc[e];
+        if (scale) v *= scale[c8 + e];
+        if (bias) v += bias[c8 + e];
+        if (relu) v = fmaxf(v, 0.f);
+        o[e] = (_Float16)v;
+    }
+    *(half8*)(out + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c8) = o;
+}
+
+int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
+                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s) {
+    if (cout % 8 != 0 || cout * ksize * ksize * cin > STEM_MAX_W) return BMI_ERR_UNSUPPORTED;
+    if (n <= 0) return BMI_ERR_INVALID;
+    const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wdt + 2 * pad - ksize) / stride + 1;
+    const long total = (long)n * ho * wo * (cout / 8);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, bias, out,
+                       n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
+                                                      double* S1, double* S2, double* SL, int tc, int BC_,
+                                                      size_t exit_stride_scratch, size_t exit_stride_S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // b*C + c
+    if (i >= BC_) return;
+    const int e = blockIdx.y;
+    const float* p = probs + e * exit_stride_scratch + i;
+    const float* l = logits + e * exit_stride_scratch + i;
+    double s1 = 0, s2 = 0, sl = 0;
+    for (int t = 0; t < tc; ++t) {
+        const double pv = (double)p[(size_t)t * BC_];
+        s1 += pv;
+        s2 += pv * pv;
+        sl += (double)l[(size_t)t * BC_];
+    }
+    const size_t o = e * exit_stride_S + i;
+    S1[o] += s1;
+    S2[o] += s2;
+    SL[o] += sl;
+}
+
+int launch_moments(const float* probs, const float* logits, double* S1, double* S2, double* SL, int tc, int batch,
+                   int out_dim, int n_exits, size_t exit_stride_scratch, size_t exit_stride_S, hipStream_t s) {
+    const int bc = batch * out_dim;
+    if (bc <= 0 || tc <= 0 || n_exits <= 0) return BMI_ERR_INVALID;
+    hipLaunchKernelGGL(moments_kernel, dim3((bc + 255) / 256, n_exits), dim3(256), 0, s, probs, logits, S1, S2, SL, tc, bc,
+                       exit_stride_scratch, exit_stride_S);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+__global__ void finalize_kernel(long n, double inv_t, const double* S1, const double* S2, const double* SL, double* mean,
+                                double* var, double* lm) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double m = S1[i] * inv_t;
+    const double v = S2[i] * inv_t - m * m;
+    mean[i] = m;
+    var[i] = v > 0 ? v : 0;
+    lm[i] = SL[i] * inv_t;
+}
+
+int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
+                    double* var, double* lm, hipStream_t s) {
+    if (n <= 0 || t_total <= 0) return BMI_ERR_INVALID;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (long)n, 1.0 / t_total, S1,
+                       S2, SL, mean, var, lm);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void philox_mask_kernel(uint8_t* keep, long n, uint32_t k0, uint32_t k1, int site, int t, uint32_t thresh,
+                                   int drop_all) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g * 4 >= n) return;
+    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)t, (uint32_t)site, k0, k1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (g * 4 + e < n) keep[g * 4 + e] = (!drop_all && rn.w[e] >= thresh) ? 1 : 0;
+}
+
+int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s) {
+    if (n <= 0) return BMI_ERR_INVALID;
+    int drop_all = 0;
+    const uint32_t thresh = bmi_drop_threshold(p, &drop_all);
+    const long groups = (n + 3) / 4;
+    hipLaunchKernelGGL(philox_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, keep, (long)n,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), site, t, thresh, drop_all);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}

@@ -1,0 +1,305 @@
+"""Host side of the MI355X MCD engine: compiles a model of ``bayesnn_fpga_amd.models`` into the
+C-ABI graph (include/bayesnn_fpga_amd.h), owns the device buffers, and drives the library.
+
+PyTorch is plumbing here (device memory, streams, ``torch.distributed``); all arithmetic of the
+path runs in ``libbayesnn_fpga_amd.so``.  What this replaces in the reference:
+
+* ``GraphBuilder``       — the op sequence of ``ResNet18MCEarlyExit.forward``
+                           (SA/models/resnet18/resnet18.py:302-346; single-exit :246-258, :195-204),
+                           with eval-mode BatchNorm folded to per-channel scale/bias and the
+                           stochastic layers turned into *sites* numbered in call order
+                           (SURVEY.md Appendix C).
+* ``MCDEngine.predict``  — ``FullAnalysis._get_output`` (SA/train/results_analyzer.py:236-270): T passes,
+                           per-exit softmax, float64 mean over T (+ build-defined variance).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .utils import Masksembles1D, Masksembles2D
+
+DEFAULT_CHUNK_IMAGES = 1024      # image-samples folded into one suffix launch (tuned on MI355X)
+
+
+def _is_site(m):
+    return isinstance(m, (nn.Dropout, Masksembles1D, Masksembles2D))
+
+
+def fold_bn(bn, conv_bias=None):
+    """eval-mode BatchNorm2d -> (scale, bias) fp32:  y = conv * scale + bias."""
+    with torch.no_grad():
+        scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        bias = bn.bias.double() - bn.running_mean.double() * scale
+        if conv_bias is not None:
+            bias = bias + conv_bias.double() * scale
+    return scale.float(), bias.float()
+
+
+class GraphBuilder:
+    """Collects tensors / ops / device-resident weights for one model on one device."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensors = []          # (h, w, c)
+        self.ops = []              # dicts
+        self.keep = []             # device tensors that must outlive the engine
+        self.site_count = 0
+
+    def tensor(self, h, w, c):
+        self.tensors.append((int(h), int(w), int(c)))
+        return len(self.tensors) - 1
+
+    def dev(self, t, dtype):
+        d = t.detach().to(device=self.device, dtype=dtype).contiguous()
+        self.keep.append(d)
+        return d
+
+    def site(self, module):
+        """Allocates the next site id (call order) for a stochastic layer, or none."""
+        if module is None:
+            return None
+        sid = self.site_count
+        self.site_count += 1
+        if isinstance(module, (Masksembles1D, Masksembles2D)):
+            masks = self.dev(module.masks, torch.float32)
+            return dict(kind=_lib.SITE_MASKSEMBLE, site_id=sid, num_masks=module.n, masks=masks)
+        return dict(kind=_lib.SITE_ELEMENTWISE, site_id=sid, p=float(module.p))
+
+    def conv(self, x, conv, bn, relu, residual=-1, site=None, stem=False):
+        h, w, cin = self.tensors[x]
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        out = self.tensor(ho, wo, conv.out_channels)
+        if bn is not None:
+            scale, bias = fold_bn(bn, conv.bias)
+        else:
+            scale = torch.ones(conv.out_channels)
+            bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels)
+        wk = conv.weight.detach().permute(0, 2, 3, 1)          # [Cout][ky][kx][Cin]
+        self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
+                             stride=s, pad=p, relu=int(relu),
+                             weight=self.dev(wk, torch.float32 if stem else torch.float16),
+                             scale=self.dev(scale, torch.float32), bias=self.dev(bias, torch.float32), site=site))
+        return out
+
+    def mask(self, x, site):
+        h, w, c = self.tensors[x]
+        out = self.tensor(h, w, c)
+        self.ops.append(dict(kind=_lib.OP_MASK, in_=x, out=out, residual=-1, site=site))
+        return out
+
+    def maxpool(self, x):
+        h, w, c = self.tensors[x]
+        out = self.tensor(h // 2, w // 2, c)
+        self.ops.append(dict(kind=_lib.OP_MAXPOOL, in_=x, out=out, residual=-1))
+        return out
+
+    def head(self, x, linear, exit_index, site=None):
+        c_in = self.tensors[x][2]
+        if linear.in_features != c_in:
+            raise ValueError(f"classifier expects {linear.in_features} features, pooled tensor has {c_in}")
+        cpad = (linear.out_features + 31) // 32 * 32
+        w = torch.zeros(cpad, c_in)
+        w[:linear.out_features] = linear.weight.detach().float()
+        self.ops.append(dict(kind=_lib.OP_HEAD, in_=x, out=exit_index, residual=-1,
+                             weight=self.dev(w, torch.float32), bias=self.dev(linear.bias, torch.float32), site=site))
+
+
+def _unwrap(module):
+    """Sequential(inner, site) wrappers made by the dropout-insertion rules -> (inner, site | None)."""
+    if isinstance(module, nn.Sequential) and len(module) == 2 and _is_site(module[1]):
+        return module[0], module[1]
+    return module, None
+
+
+def build_resnet_graph(model, g):
+    """Op sequence of the ResNet family forwards (reference resnet18.py:302-346 / :246-258 / :195-204)."""
+    x = g.tensor(32, 32, 3)                                   # tensor 0: network input (fp32 NCHW)
+    x = g.conv(x, model.conv1, model.bn1, relu=False, stem=True)   # no ReLU after the stem (:303)
+    multi = getattr(model, "multi_exit", True)
+    dropout_exit = getattr(model, "dropout_exit", False)
+    exit_sites = {1: "exit1_dropout", 2: "exit2_dropout", 3: "exit3_dropout"}
+    for si in range(1, 5):
+        stage, stage_site = _unwrap(getattr(model, f"layer{si}"))
+        blocks = list(stage)
+        for bi, blk in enumerate(blocks):
+            blk, blk_site = _unwrap(blk)
+            site_mod = blk_site if blk_site is not None else (stage_site if bi == len(blocks) - 1 else None)
+            a = g.conv(x, blk.conv1, blk.bn1, relu=True)
+            res = x
+            if blk.downsample is not None:
+                res = g.conv(x, blk.downsample[0], blk.downsample[1], relu=False)
+            # site ids follow call order: a block's site is allocated when the block finishes
+            x = g.conv(a, blk.conv2, blk.bn2, relu=True, residual=res, site=g.site(site_mod))
+        if multi and si < 4:
+            # exit head si: relu -> conv s2 -> bn chain, relu, avg-pool, [exit dropout], linear
+            # (F.relu on a stage output is idempotent: it is already >= 0 and masks keep the sign)
+            y = x
+            n_conv = 4 - si
+            for j in range(1, n_conv + 1):
+                y = g.conv(y, getattr(model, f"ex{si}conv{j}"), getattr(model, f"ex{si}bn{j}"), relu=True)
+            sm = getattr(model, exit_sites[si], None) if dropout_exit else None
+            g.head(y, getattr(model, f"ex{si}linear"), si - 1, site=g.site(sm))
+    sm = getattr(model, "exit_dropout", None) if dropout_exit else None
+    g.head(x, model.linear, (model_exits(model) - 1), site=g.site(sm))
+
+
+def model_exits(model):
+    """Number of logits tensors the reference forward returns (4 multi-exit, 1 single-exit)."""
+    if getattr(model, "family", "") == "vgg":
+        return 5 if getattr(model, "multi_exit", True) else 1
+    return 4 if getattr(model, "multi_exit", True) else 1
+
+
+def build_graph(model, device):
+    g = GraphBuilder(device)
+    fam = getattr(model, "family", None)
+    if fam == "resnet":
+        build_resnet_graph(model, g)
+    elif fam == "vgg":
+        from .models.vgg19.vgg19 import build_vgg_graph
+        build_vgg_graph(model, g)
+    elif hasattr(model, "build_graph"):
+        model.build_graph(g)
+    else:
+        raise TypeError(f"{type(model).__name__} is not a bayesnn_fpga_amd model")
+    return g
+
+
+class CompiledGraph:
+    """Host-only half of the engine: graph -> C descriptors -> bmi_create / bmi_plan / bmi_query.
+    Touches no GPU API (weights only need to be addressable), so it also runs on a CPU-only box."""
+
+    def __init__(self, model, device, max_batch, chunk_samples=None):
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        self.n_exits = model_exits(model)
+        self.out_dim = int(model.out_dim)
+        self.graph = build_graph(model, self.device)
+        self.max_batch = int(max_batch)
+        if chunk_samples is None:
+            chunk_samples = max(1, DEFAULT_CHUNK_IMAGES // self.max_batch)
+        self.chunk_samples = int(chunk_samples)
+        self._desc_keep = self._make_desc()
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.bmi_create(C.byref(self._desc_keep[0]), C.byref(self.handle)), "bmi_create")
+        ws = C.c_size_t()
+        _lib.check(self.lib.bmi_plan(self.handle, self.max_batch, self.chunk_samples, C.byref(ws)), "bmi_plan")
+        self.workspace_bytes = ws.value
+        pm, sm, npo, nso = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.bmi_query(self.handle, C.byref(pm), C.byref(sm), C.byref(npo), C.byref(nso)), "bmi_query")
+        self.prefix_macs, self.suffix_macs = pm.value, sm.value
+        self.n_prefix_ops, self.n_suffix_ops = npo.value, nso.value
+
+    def _make_desc(self):
+        g = self.graph
+        tarr = (_lib.TensorDesc * len(g.tensors))(*[_lib.TensorDesc(*t) for t in g.tensors])
+        oarr = (_lib.OpDesc * len(g.ops))()
+        for i, op in enumerate(g.ops):
+            d = oarr[i]
+            d.kind, d.in_, d.out, d.residual = op["kind"], op["in_"], op["out"], op.get("residual", -1)
+            d.ksize, d.stride, d.pad, d.relu = op.get("ksize", 0), op.get("stride", 0), op.get("pad", 0), op.get("relu", 0)
+            for f in ("weight", "scale", "bias"):
+                t = op.get(f)
+                setattr(d, f, t.data_ptr() if t is not None else None)
+            s = op.get("site")
+            if s:
+                d.site = _lib.make_site(s["kind"], s["site_id"], s.get("p", 0.0), s.get("num_masks", 0),
+                                        s["masks"].data_ptr() if "masks" in s else None)
+            else:
+                d.site = _lib.make_site()
+        desc = _lib.ModelDesc(len(g.tensors), tarr, len(g.ops), oarr, self.n_exits, self.out_dim)
+        return (desc, tarr, oarr)
+
+    def flops_per_batch(self, batch, T):
+        """Executed-algorithmic FLOPs (prefix once + T x suffix), conv + linear only, 1 MAC = 2 FLOP."""
+        return 2 * batch * (self.prefix_macs + T * self.suffix_macs)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.bmi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MCDEngine(CompiledGraph):
+    """One model compiled for one GPU.  All methods are asynchronous on the current torch stream
+    (the stream handle is what the C ABI receives); results are device tensors."""
+
+    def __init__(self, model, device, max_batch=256, chunk_samples=None):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("MCDEngine needs a HIP device (torch device type 'cuda' on ROCm); there is no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        super().__init__(model, device, max_batch, chunk_samples)
+        self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
+
+    # ---- the path ------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_x(self, x):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.device == self.device):
+            raise RuntimeError(f"input must live on {self.device}")
+        if x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
+            raise ValueError(f"expected float32 [B,3,32,32] like the reference's loaders, got {x.dtype} {tuple(x.shape)}")
+        if x.shape[0] > self.max_batch:
+            raise ValueError(f"batch {x.shape[0]} exceeds the engine's max_batch {self.max_batch}")
+        return x.contiguous()
+
+    def new_moments(self, batch):
+        """Zeroed float64 accumulators S1 = sum p, S2 = sum p^2, SL = sum logit, each [E, B, C]."""
+        return torch.zeros(3, self.n_exits, batch, self.out_dim, dtype=torch.float64, device=self.device)
+
+    def accumulate(self, x, S, t_begin, t_count, seed=0, cnt0=0):
+        """Adds samples t_begin .. t_begin+t_count-1 of batch ``x`` into the moment buffer ``S``."""
+        x = self._check_x(x)
+        B = x.shape[0]
+        if tuple(S.shape) != (3, self.n_exits, B, self.out_dim) or S.dtype != torch.float64 or not S.is_contiguous():
+            raise ValueError("moment buffer must be contiguous float64 [3, E, B, C]")
+        with torch.cuda.device(self.device):
+            rc = self.lib.bmi_forward_mcd(self.handle, x.data_ptr(), B, int(t_begin), int(t_count),
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, int(cnt0), S[0].data_ptr(), S[1].data_ptr(),
+                                          S[2].data_ptr(), self.workspace.data_ptr(), self.workspace_bytes, self._stream())
+        _lib.check(rc, "bmi_forward_mcd")
+        return S
+
+    def finalize(self, S, t_total):
+        """mean / var (ddof=0) / mean logit, float64 [E, B, C] each."""
+        out = torch.empty_like(S)
+        n = S[0].numel()
+        with torch.cuda.device(self.device):
+            rc = self.lib.bmi_finalize(n, int(t_total), S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
+                                       out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._stream())
+        _lib.check(rc, "bmi_finalize")
+        return dict(mean=out[0], var=out[1], logit_mean=out[2])
+
+    def predict(self, x, T, seed=0, t_begin=0, cnt0=0):
+        S = self.new_moments(x.shape[0])
+        self.accumulate(x, S, t_begin, T, seed, cnt0)
+        return self.finalize(S, T)
+
+    def forward_once(self, x, seed=0, t=0, cnt0=0):
+        """One stochastic pass -> list of fp32 logits [B, C] per exit (the reference forward's return)."""
+        S = self.new_moments(x.shape[0])
+        self.accumulate(x, S, t, 1, seed, cnt0)
+        return [S[2, e].float() for e in range(self.n_exits)]
+
+    # ---- measurement helpers ---------------------------------------------------------------------
+    def profile(self, enable):
+        _lib.check(self.lib.bmi_profile_enable(self.handle, int(bool(enable))), "bmi_profile_enable")
+
+    def profile_read(self):
+        ms = (C.c_double * _lib.PROFILE_SLOTS)()
+        n = (C.c_int64 * _lib.PROFILE_SLOTS)()
+        _lib.check(self.lib.bmi_profile_read(self.handle, ms, n), "bmi_profile_read")
+        return {_lib.PROFILE_NAMES.get(i, str(i)): (ms[i], n[i]) for i in range(_lib.PROFILE_SLOTS) if n[i]}

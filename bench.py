@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCD-samples/s (T x images / s) + ECE, ResNet-18 multi-exit, T = 100.
+
+Workload (BASELINE.json configs[2]): ResNet18MCEarlyExit, CIFAR-10 shape (C=10), dropout="block" +
+exit dropout, p=0.25, batch 250 (the reference's test batch, SA/train/hyperparameters.py:265-266),
+T=100 Monte-Carlo samples, synthetic N(0,1) images and seeded synthetic weights.
+
+One "step" = one batch through the whole hot path: deterministic prefix once, T masked suffix
+passes (folded into the GEMM M dimension in chunks), per-exit softmax moments, finalize to
+mean / variance.  Inputs are resident in HBM before the timed region.  With N GPUs the T samples
+are sharded across ranks (strong scaling, total work fixed) and the float64 moment buffers are
+combined with ONE all-reduce over RCCL per step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus 8 --steps 10 --warmup 3
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (conv_igemm, all launches of
+a step): algorithmic conv FLOPs / HIP-event time of those launches, measured on the launch stream in
+a separate profiled step right after the timed region (event records around every launch would
+perturb the timed steps).  `cpu_baseline` is the CPU oracle (a port of the reference loop) timed on
+this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16, MI355X_MICROARCH.md §Chip-level parameters
+MODEL_KW = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=250)
+    ap.add_argument("--T", type=int, default=100)
+    ap.add_argument("--chunk", type=int, default=0, help="MC samples folded per suffix launch (0 = engine default)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-T", type=int, default=10, help="MC passes of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, T, seed):
+    """The oracle (port of FullAnalysis._get_output, T sequential full forwards per batch, fp32) on
+    the host cores.  Returns (MCD-samples/s, threads, mean probs)."""
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
+    from oracle import mcd
+    from oracle import resnet18 as oresnet
+    torch.manual_seed(0)
+    m = synthetic_weights_(oresnet.ResNet18MCEarlyExit(**MODEL_KW), 0)
+    x = synthetic_images(batch, seed=1234)
+    mcd.mcd_predict(m, x[:8], 1, seed)          # warm the allocator / oneDNN primitives
+    t0 = time.perf_counter()
+    r = mcd.mcd_predict(m, x, T, seed)
+    dt = time.perf_counter() - t0
+    return batch * T / dt, torch.get_num_threads(), r["mean"]
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+    from bayesnn_fpga_amd.sharding import shard_range
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
+    from bayesnn_fpga_amd.train.metrics import ece_hist_binary
+
+    torch.manual_seed(0)
+    model = synthetic_weights_(ResNet18MCEarlyExit(**MODEL_KW), 0).to(dev).eval()
+    B, T = a.batch, a.T
+    eng = model.engine(dev, max_batch=B, chunk_samples=a.chunk or None)
+    x = synthetic_images(B, seed=1234).to(dev)
+    t_lo, t_hi = shard_range(T, rank, world)
+    S = eng.new_moments(B)
+
+    def step():
+        S.zero_()
+        if t_hi > t_lo:
+            eng.accumulate(x, S, t_lo, t_hi - t_lo, a.seed)
+        if dist is not None:
+            dist.all_reduce(S)                  # one RCCL all-reduce of [3,E,B,C] float64 over xGMI
+        return eng.finalize(S, T)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- per-kernel profile (rank 0's share of the samples), outside the timed region ----------
+    eng.profile(True)
+    step()
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile(False)
+
+    if rank == 0:
+        samples = B * T * a.steps
+        value = samples / dt
+        my_T = t_hi - t_lo
+        # conv FLOPs of rank 0's profiled step: prefix convs once + suffix convs x its samples
+        head_macs = 4 * 512 * MODEL_KW["out_dim"]
+        conv_flops = 2.0 * B * ((eng.prefix_macs) + my_T * (eng.suffix_macs - head_macs))
+        conv_ms, conv_launches = prof.get("conv_igemm", (0.0, 0))
+        stem_ms = prof.get("stem", (0.0, 0))[0]
+        conv_flops -= 2.0 * B * 1769472              # the 3-channel stem runs in its own direct kernel
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        mean = out["mean"].cpu().numpy()
+        labels = synthetic_labels(B, MODEL_KW["out_dim"], seed=1235).numpy()
+        onehot = np.eye(MODEL_KW["out_dim"])[labels]
+        line = {
+            "metric": "MCD-samples/sec (T x images/s) + ECE, ResNet-18 multi-exit T=100",
+            "value": round(value, 1), "unit": "MCD-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "ResNet18MCEarlyExit C=10 dropout=block+exit p=0.25, batch 250 x T=100 "
+                                   "(BASELINE configs[2])",
+                       "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
+                       "sharding": f"T over {world} rank(s), one float64 all-reduce per batch"},
+            "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
+            "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),
+            "tflops_naive_equiv": round(2.0 * (eng.prefix_macs + eng.suffix_macs) * samples / dt / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one step)",
+                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                         "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
+        }
+        if not a.no_cpu_baseline:
+            cpu_val, threads, cpu_mean = cpu_baseline(B, a.cpu_T, a.seed)
+            gpu_same = eng.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()
+            line["cpu_baseline"] = {
+                "value": round(cpu_val, 1), "unit": "MCD-samples/s", "cores": threads, "kind": "port",
+                "sample": f"oracle (port of FullAnalysis._get_output loop), 1 batch of {B} images x T={a.cpu_T}, fp32, "
+                          f"torch {torch.__version__} CPU, {os.cpu_count()} logical CPUs",
+                "ece_hist_final_exit_cpu": round(ece_hist_binary(cpu_mean[-1], onehot), 6),
+                "ece_hist_final_exit_gpu_same_T": round(ece_hist_binary(gpu_same[-1], onehot), 6),
+                "max_abs_mean_diff_gpu_vs_cpu": float(np.abs(gpu_same - cpu_mean).max()),
+            }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

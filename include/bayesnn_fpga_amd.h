@@ -1,0 +1,183 @@
+/*
+ * bayesnn_fpga_amd.h — C ABI of libbayesnn_fpga_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of os-hxfan/BayesNN_FPGA: the Monte-Carlo-dropout /
+ * Masksembles multi-exit inference forward pass and its T-sample per-exit moment
+ * reduction.  The reference has no FFI of its own: its boundary is the
+ * Python API of Software_Artifact/software (abbreviated SA/), so every entry point below
+ * cites the reference code it replaces:
+ *
+ *   bmi_create / bmi_plan      the layer graph that SA/models/resnet18/resnet18.py:260-300
+ *                              (ResNet18MCEarlyExit.__init__), :212-244 (ResNet18MC) and
+ *                              SA/models/vgg19/vgg19.py:327-382 build as nn.Modules
+ *   bmi_forward_mcd            the T-pass loop of FullAnalysis._get_output,
+ *                              SA/train/results_analyzer.py:236-246: `for i in range(mc_passes):
+ *                              output = self.model(b_x)` + per-exit softmax, i.e. T x
+ *                              ResNet18MCEarlyExit.forward (resnet18.py:302-346) with
+ *                              MCDropout.forward (:207-210) / Masksembles*.forward
+ *                              (SA/utils.py:156-169, :218-231) at every stochastic site
+ *   bmi_finalize               np.average over the T passes, results_analyzer.py:247-248, plus
+ *                              the build-defined T-sample variance (ddof = 0)
+ *   bmi_philox_mask            the RNG primitive under F.dropout (resnet18.py:210), replaced by
+ *                              the counter-based Philox convention of csrc/philox.h
+ *   bmi_stem_conv_fwd, bmi_conv_igemm_fwd   conv+BN(+residual)(+ReLU) of BasicBlock.forward
+ *                              (resnet18.py:32-48) and of the exit heads (:306-308,:318-319,:329)
+ *   bmi_mask_apply             MCDropout / Masksembles2D on a stage output (:278-280)
+ *   bmi_pool_mask              F.avg_pool2d(F.relu(.),4) + flatten + exit dropout (:309-313)
+ *   bmi_linear_softmax         ex{1,2,3}linear / linear (:314,:325,:335,:344) + softmax
+ *                              (results_analyzer.py:242)
+ *   bmi_moments_accumulate     the accumulation behind np.average (:247-248)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 or a negative
+ * errno-style code (no exceptions cross the ABI); all device buffers are owned by the
+ * caller; every launch is asynchronous on the caller's hipStream_t (passed as void*);
+ * no allocation or synchronisation happens inside a launch function, so a caller may
+ * capture bmi_forward_mcd into a hipGraph.  One host thread per GPU.
+ *
+ * Data layout in HBM: activations are NHWC fp16 ([image][y][x][channel]); conv weights
+ * fp16 [Cout][ky][kx][Cin]; folded-BN scale/bias fp32 [Cout]; classifier weights fp32
+ * [ceil32(C)][K] (rows >= C zero); the network input is fp32 NCHW exactly as the reference
+ * receives it; moment accumulators are float64 [E][B][C].
+ */
+#ifndef BAYESNN_FPGA_AMD_H
+#define BAYESNN_FPGA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMI_VERSION 100
+
+#define BMI_OK 0
+#define BMI_ERR_INVALID (-22)      /* EINVAL: bad descriptor / argument            */
+#define BMI_ERR_NOMEM (-12)        /* ENOMEM: workspace too small                  */
+#define BMI_ERR_HIP (-5)           /* EIO: a HIP runtime call or launch failed     */
+#define BMI_ERR_UNSUPPORTED (-95)  /* EOPNOTSUPP: shape outside the kernels' range */
+
+typedef struct bmi_engine_s* bmi_handle;
+typedef void* bmi_stream; /* hipStream_t */
+
+/* stochastic-site kinds */
+#define BMI_SITE_NONE 0
+#define BMI_SITE_ELEMENTWISE 1 /* MCDropout: x * keep / (1-p), one Bernoulli per element      */
+#define BMI_SITE_CHANNEL 2     /* dropout2d semantics: one Bernoulli per (image, channel)      */
+#define BMI_SITE_MASKSEMBLE 3  /* x * masks[(cnt0 + t) mod M][channel], no rescale             */
+
+typedef struct bmi_site {
+    int32_t kind;        /* BMI_SITE_*                                                  */
+    int32_t site_id;     /* call-order index of the stochastic layer inside one forward */
+    float p;             /* drop probability (ELEMENTWISE / CHANNEL)                    */
+    int32_t num_masks;   /* MASKSEMBLE: M                                               */
+    const float* masks;  /* MASKSEMBLE: device fp32 [M][C] of 0/1                       */
+} bmi_site;
+
+/* op kinds */
+#define BMI_OP_STEM 1  /* direct conv on the fp32 NCHW network input (Cin <= 4)        */
+#define BMI_OP_CONV 2  /* implicit-GEMM conv (Cin % 64 == 0, Cout % 64 == 0)           */
+#define BMI_OP_MASK 3  /* stand-alone stochastic site on a tensor                      */
+#define BMI_OP_HEAD 4  /* global avg-pool + site + Linear + softmax -> exit `out`      */
+#define BMI_OP_MAXPOOL 5 /* 2x2 stride-2 max-pool                                      */
+
+typedef struct bmi_tensor_desc {
+    int32_t h, w, c; /* per-image NHWC extent; tensor 0 is the network input */
+} bmi_tensor_desc;
+
+typedef struct bmi_op_desc {
+    int32_t kind;
+    int32_t in;        /* input tensor id                                              */
+    int32_t out;       /* output tensor id; HEAD: exit index                           */
+    int32_t residual;  /* CONV: tensor added before the ReLU, or -1                    */
+    int32_t ksize, stride, pad;
+    int32_t relu;      /* apply ReLU after scale/bias(+residual)                       */
+    const void* weight;  /* device; CONV fp16 [Cout][k][k][Cin]; STEM fp32 [Cout][k][k][Cin];
+                            HEAD fp32 [ceil32(out_dim)][Cin]                           */
+    const float* scale;  /* device fp32 [Cout] folded BN scale (NULL = 1)              */
+    const float* bias;   /* device fp32 [Cout] folded BN bias / Linear bias            */
+    bmi_site site;       /* CONV/STEM/MASK: applied to the op's output; HEAD: applied to
+                            the pooled features before the Linear                      */
+} bmi_op_desc;
+
+typedef struct bmi_model_desc {
+    int32_t n_tensors;
+    const bmi_tensor_desc* tensors;
+    int32_t n_ops;
+    const bmi_op_desc* ops;
+    int32_t n_exits;
+    int32_t out_dim;
+} bmi_model_desc;
+
+/* per-op-kind device time, filled by bmi_profile_read */
+#define BMI_PROFILE_SLOTS 8 /* index = BMI_OP_*; slot 6 = moments, slot 7 = finalize */
+
+int bmi_version(void);
+const char* bmi_error_string(int code);
+
+/* Host-only: validates and copies the graph, marks which tensors are stochastic, splits a
+ * conv that carries a site but has only deterministic inputs into conv + MASK (so the
+ * deterministic prefix runs once per batch).  No HIP call. */
+int bmi_create(const bmi_model_desc* desc, bmi_handle* out);
+int bmi_destroy(bmi_handle h);
+
+/* Host-only: lays the activation buffers out for batches of up to `max_batch` images and
+ * chunks of up to `chunk_samples` Monte-Carlo samples folded into the GEMM M dimension. */
+int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* workspace_bytes);
+
+/* MACs (conv + linear) per image of the deterministic prefix and per (image, sample) of the
+ * stochastic suffix; and the op counts after the split. */
+int bmi_query(bmi_handle h, int64_t* prefix_macs, int64_t* suffix_macs, int32_t* n_prefix_ops, int32_t* n_suffix_ops);
+
+/* Runs samples t_begin .. t_begin+t_count-1 for one batch and ADDS, per exit e, image b and
+ * class c:  S1 += softmax_p, S2 += softmax_p^2, SL += logit   (float64 [E][B][C]). */
+int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_begin, int32_t t_count,
+                    uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL, void* workspace,
+                    size_t workspace_bytes, bmi_stream stream);
+
+/* mean = S1/T, var = S2/T - mean^2 (clamped at 0), logit_mean = SL/T; n = E*B*C. */
+int bmi_finalize(int64_t n, int32_t t_total, const double* S1, const double* S2, const double* SL, double* mean,
+                 double* var, double* logit_mean, bmi_stream stream);
+
+/* Per-op-kind HIP-event timing of bmi_forward_mcd (off by default; adds two event records per
+ * launch).  bmi_profile_read synchronises the recorded events and resets the accumulators. */
+int bmi_profile_enable(bmi_handle h, int32_t enable);
+int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launches[BMI_PROFILE_SLOTS]);
+
+/* ---- single-kernel entry points (unit parity tests) -------------------------------------- */
+
+/* keep bits (0/1 bytes) of elements 0..n-1 of stream (seed, site, t). */
+int bmi_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int32_t site, int32_t t, float p, bmi_stream stream);
+
+int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* scale, const float* bias, void* out_nhwc,
+                      int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t ksize, int32_t stride,
+                      int32_t pad, int32_t relu, bmi_stream stream);
+
+/* out[n] = conv(in[n % in_mod]) * scale + bias (+ res[n % res_mod]) (ReLU) (site); `batch` is
+ * the per-sample image count B used by the site's element index (n = t_local*B + b). */
+int bmi_conv_igemm_fwd(const void* in, const void* weight, const float* scale, const float* bias, const void* res,
+                       void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
+                       int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
+                       int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
+
+int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
+                   int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
+
+int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c, bmi_stream stream);
+
+/* feat[n][c] = mean_hw(in[n % in_mod][hw][c]) (site)   -> fp32 [n][c] */
+int bmi_pool_mask(const void* in, float* feat, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
+                  int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
+
+/* logits[n][c] = feat[n] . weight[c] + bias[c];  probs = softmax(logits)   (fp32 [n][out_dim]) */
+int bmi_linear_softmax(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
+                       int32_t n, int32_t k, int32_t out_dim, bmi_stream stream);
+
+/* S1/S2/SL [batch][out_dim] += sum over the tc samples of probs / probs^2 / logits ([tc][batch][out_dim]) */
+int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,
+                           int32_t batch, int32_t out_dim, bmi_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYESNN_FPGA_AMD_H */

@@ -9,7 +9,7 @@ Mask convention shared by oracle and HIP kernels (bayesnn_fpga_amd/csrc/philox.h
   key      = (seed & 0xffffffff, seed >> 32)
   counter  = (g & 0xffffffff, g >> 32, t, site)          g = element_index // 4
   element  e uses output word  r[e % 4]
-  keep(e)  = r[e % 4] >= thresh,   thresh = min(round(p * 2**32), 2**32)   (u64 compare)
+  keep(e)  = r[e % 4] >= thresh,   thresh = min(floor(fl32(p) * 2**32 + 0.5), 2**32)   (u64 compare)
   out      = x * keep * fl32(1 / fl32(1 - p))            (MCDropout: F.dropout, always on,
                                                           SA/models/resnet18/resnet18.py:209-210)
 
@@ -51,7 +51,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def drop_threshold(p):
     """u64 threshold: keep iff r >= thresh.  P(drop) = thresh / 2**32."""
-    return min(int(np.floor(float(p) * 4294967296.0 + 0.5)), 1 << 32)
+    return min(int(np.floor(float(np.float32(p)) * 4294967296.0 + 0.5)), 1 << 32)
 
 
 def drop_scale(p):

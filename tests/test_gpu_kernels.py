@@ -1,0 +1,213 @@
+"""-m gpu: every HIP kernel, through the C ABI, against the CPU oracle / a torch fp32 reference
+of the same op on the same (fp16-rounded) operands."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from bayesnn_fpga_amd import _lib
+from oracle import philox
+from tests import gpu_helpers as gh
+
+pytestmark = pytest.mark.gpu
+DEV = gh.DEV
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("seed,site,t,p,n", [(42, 0, 0, 0.25, 4096), (7, 3, 99, 0.5, 1003), ((1 << 40) + 5, 6, 5, 0.125, 64),
+                                              (1, 1, 1, 0.0, 16), (1, 1, 1, 1.0, 16), (3, 2, 17, 0.2, 777)])
+def test_philox_mask_bit_exact(seed, site, t, p, n):
+    lib = _lib.lib()
+    keep = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.bmi_philox_mask(gh.ptr(keep), n, seed, site, t, p, gh.stream()), "bmi_philox_mask")
+    torch.cuda.synchronize()
+    assert np.array_equal(keep.cpu().numpy().astype(bool), philox.keep_bits(n, seed, site, t, p))
+
+
+# (Cin, Cout, H, k, stride, pad) — one per GEMM shape class of SURVEY.md Appendix A
+SHAPES = {
+    "S1": (64, 64, 32, 3, 1, 1), "D2": (64, 128, 32, 3, 2, 1), "P2": (64, 128, 32, 1, 2, 0),
+    "S2": (128, 128, 16, 3, 1, 1), "D3": (128, 256, 16, 3, 2, 1), "P3": (128, 256, 16, 1, 2, 0),
+    "S3": (256, 256, 8, 3, 1, 1), "D4": (256, 512, 8, 3, 2, 1), "P4": (256, 512, 8, 1, 2, 0),
+    "S4": (512, 512, 4, 3, 1, 1),
+}
+
+
+def _conv_inputs(cin, cout, H, k, n_in, seed, with_res, n_res=None):
+    g = _gen(seed)
+    x = (torch.randn(n_in, H, H, cin, generator=g)).to(torch.float16).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(torch.float16).to(DEV)
+    scale = (0.5 + torch.rand(cout, generator=g)).to(DEV)
+    bias = (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    return x, w, scale, bias, g
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_conv_shape_classes(name):
+    cin, cout, H, k, s, p = SHAPES[name]
+    n = 3                                        # 3 images: M is never a multiple of the 128-pixel tile for the 4x4 maps
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, n, 11, False)
+    ho = (H + 2 * p - k) // s + 1
+    res = torch.randn(n, ho, ho, cout, generator=g).to(torch.float16).to(DEV)
+    out = gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n)
+    ref = gh.conv_ref(x, w, scale, bias, res, True, s, p, n, n, n)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_conv_no_epilogue_terms_and_no_relu():
+    cin, cout, H, k, s, p = SHAPES["S2"]
+    x, w, _, _, _ = _conv_inputs(cin, cout, H, k, 2, 5, False)
+    out = gh.run_conv(x, w, None, None, None, False, s, p, 2, 2, 1)
+    ref = gh.conv_ref(x, w, None, None, None, False, s, p, 2, 2, 1)
+    assert (ref < 0).any()
+    torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_conv_broadcast_input_over_samples():
+    """suffix launch reading a deterministic tensor: image n reads input n % B, residual n % B."""
+    cin, cout, H, k, s, p = SHAPES["D3"]
+    B, tc = 3, 4
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, B, 9, True)
+    res = torch.randn(B, 8, 8, cout, generator=g).to(torch.float16).to(DEV)
+    out = gh.run_conv(x, w, scale, bias, res, True, s, p, B * tc, B, B, batch=B)
+    ref = gh.conv_ref(x, w, scale, bias, res, True, s, p, B * tc, B, B)
+    torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=2e-3)
+    assert torch.equal(out[:B], out[B:2 * B])
+
+
+@pytest.mark.parametrize("kind", ["elementwise", "channel", "masksemble"])
+def test_conv_fused_site(kind):
+    """fused mask + MFMA conv: the epilogue's site must reproduce the oracle's mask bit for bit
+    (every dropped element is exactly 0, every kept one is scaled)."""
+    cin, cout, H, k, s, p = SHAPES["S3"]
+    B, tc, t0, seed, cnt0 = 3, 3, 5, (7 << 32) + 42, 2
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, B * tc, 21, False)
+    if kind == "elementwise":
+        site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=4, p=0.25)
+    elif kind == "channel":
+        site = dict(kind=_lib.SITE_CHANNEL, site_id=2, p=0.5)
+    else:
+        rng = np.random.RandomState(0)
+        site = dict(kind=_lib.SITE_MASKSEMBLE, site_id=1, masks=(rng.rand(4, cout) < 0.4).astype(np.float32))
+    out = gh.run_conv(x, w, scale, bias, None, True, s, p, B * tc, B * tc, 1, site=site, batch=B, t0=t0, seed=seed, cnt0=cnt0)
+    ref = gh.conv_ref(x, w, scale, bias, None, True, s, p, B * tc, B * tc, 1)
+    mult = gh.folded_site_mask(site, B, cout, 8, 8, tc, t0, seed, cnt0)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref * mult, rtol=2e-3, atol=2e-3)
+    assert torch.equal(got[mult == 0], torch.zeros_like(got[mult == 0]))
+    assert (mult == 0).any() and (mult != 0).any()
+
+
+def test_conv_rejects_unsupported_shapes():
+    lib = _lib.lib()
+    x = torch.zeros(1, 8, 8, 48, dtype=torch.float16, device=DEV)
+    w = torch.zeros(64, 3, 3, 48, dtype=torch.float16, device=DEV)
+    o = torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=DEV)
+    rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), gh.ptr(w), None, None, None, gh.ptr(o), 1, 1, 1, 8, 8, 48, 64, 3, 1, 1, 0, None, 1,
+                                0, 0, 0, gh.stream())
+    assert rc == -95
+
+
+def test_stem_conv():
+    lib = _lib.lib()
+    g = _gen(3)
+    n = 5
+    x = torch.randn(n, 3, 32, 32, generator=g).to(DEV)
+    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.3)           # [Cout][ky][kx][Cin]
+    scale = (0.5 + torch.rand(64, generator=g))
+    bias = 0.2 * torch.randn(64, generator=g)
+    out = torch.empty(n, 32, 32, 64, dtype=torch.float16, device=DEV)
+    _lib.check(lib.bmi_stem_conv_fwd(gh.ptr(x), gh.ptr(w.to(DEV)), gh.ptr(scale.to(DEV)), gh.ptr(bias.to(DEV)), gh.ptr(out),
+                                     n, 3, 32, 32, 64, 3, 1, 1, 0, gh.stream()), "bmi_stem_conv_fwd")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.cpu(), w.permute(0, 3, 1, 2), padding=1) * scale[None, :, None, None] + bias[None, :, None, None]
+    assert (ref < 0).any()
+    torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("kind", ["elementwise", "masksemble"])
+def test_mask_apply_expands_and_masks(kind):
+    lib = _lib.lib()
+    B, tc, H, Cc, t0, seed, cnt0 = 3, 4, 6, 64, 2, 99, 3
+    g = _gen(4)
+    x = torch.randn(B, H, H, Cc, generator=g).to(torch.float16).to(DEV)
+    if kind == "elementwise":
+        site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=0, p=0.375)
+    else:
+        site = dict(kind=_lib.SITE_MASKSEMBLE, site_id=0, masks=(np.random.RandomState(1).rand(4, Cc) < 0.5).astype(np.float32))
+    keep = []
+    s = gh.site_struct(site, keep)
+    out = torch.empty(B * tc, H, H, Cc, dtype=torch.float16, device=DEV)
+    _lib.check(lib.bmi_mask_apply(gh.ptr(x), gh.ptr(out), B * tc, B, H * H, Cc, C.byref(s), B, t0, seed, cnt0, gh.stream()),
+               "bmi_mask_apply")
+    torch.cuda.synchronize()
+    mult = gh.folded_site_mask(site, B, Cc, H, H, tc, t0, seed, cnt0)
+    xin = x.float().cpu().permute(0, 3, 1, 2).repeat(tc, 1, 1, 1)
+    ref = (xin * mult).to(torch.float16).float()
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)        # one rounding, bit-exact
+
+
+def test_pool_mask_and_linear_softmax_and_moments():
+    lib = _lib.lib()
+    B, tc, Cc, K, t0, seed = 5, 3, 10, 512, 4, 1234
+    N = B * tc
+    g = _gen(8)
+    x = torch.randn(N, 4, 4, K, generator=g).to(torch.float16).to(DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=6, p=0.25)
+    keep = []
+    s = gh.site_struct(site, keep)
+    feat = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    _lib.check(lib.bmi_pool_mask(gh.ptr(x), gh.ptr(feat), N, N, 16, K, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_pool_mask")
+    mult = gh.folded_site_mask(site, B, K, 1, 1, tc, t0, seed).reshape(N, K)
+    pooled = torch.relu(x.float().cpu()).mean(dim=(1, 2))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(feat.cpu(), pooled * mult, rtol=1e-6, atol=1e-6)
+    assert torch.equal(feat.cpu()[mult == 0], torch.zeros(int((mult == 0).sum())))
+
+    for out_dim in (10, 100):
+        w = torch.zeros((out_dim + 31) // 32 * 32, K)
+        w[:out_dim] = 0.4 * torch.randn(out_dim, K, generator=g)
+        b = 0.2 * torch.randn(out_dim, generator=g)
+        logits = torch.empty(N, out_dim, device=DEV)
+        probs = torch.empty(N, out_dim, device=DEV)
+        _lib.check(lib.bmi_linear_softmax(gh.ptr(feat), gh.ptr(w.to(DEV)), gh.ptr(b.to(DEV)), gh.ptr(logits), gh.ptr(probs), N, K,
+                                          out_dim, gh.stream()), "bmi_linear_softmax")
+        torch.cuda.synchronize()
+        ref_l = feat.cpu().double() @ w[:out_dim].double().T + b.double()
+        torch.testing.assert_close(logits.cpu().double(), ref_l, rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(probs.cpu().double(), torch.softmax(ref_l, 1), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(probs.sum(1).cpu(), torch.ones(N), atol=1e-5)
+
+        S = torch.zeros(3, B, out_dim, dtype=torch.float64, device=DEV)
+        for _ in range(2):   # accumulates (+=)
+            _lib.check(lib.bmi_moments_accumulate(gh.ptr(probs), gh.ptr(logits), gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), tc, B,
+                                                  out_dim, gh.stream()), "bmi_moments_accumulate")
+        torch.cuda.synchronize()
+        p = probs.cpu().double().reshape(tc, B, out_dim)
+        l = logits.cpu().double().reshape(tc, B, out_dim)
+        torch.testing.assert_close(S[0].cpu(), 2 * p.sum(0), rtol=1e-13, atol=1e-13)
+        torch.testing.assert_close(S[1].cpu(), 2 * (p * p).sum(0), rtol=1e-13, atol=1e-13)
+        torch.testing.assert_close(S[2].cpu(), 2 * l.sum(0), rtol=1e-13, atol=1e-13)
+        out = torch.empty(3, B, out_dim, dtype=torch.float64, device=DEV)
+        _lib.check(lib.bmi_finalize(B * out_dim, 2 * tc, gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), gh.ptr(out[0]), gh.ptr(out[1]),
+                                    gh.ptr(out[2]), gh.stream()), "bmi_finalize")
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out[0].cpu(), p.mean(0), rtol=1e-12, atol=1e-14)
+        torch.testing.assert_close(out[1].cpu(), p.var(0, unbiased=False), rtol=1e-9, atol=1e-14)
+        torch.testing.assert_close(out[2].cpu(), l.mean(0), rtol=1e-12, atol=1e-14)
+
+
+def test_maxpool2():
+    lib = _lib.lib()
+    x = torch.randn(3, 8, 8, 64, generator=_gen(2)).to(torch.float16).to(DEV)
+    out = torch.empty(3, 4, 4, 64, dtype=torch.float16, device=DEV)
+    _lib.check(lib.bmi_maxpool2(gh.ptr(x), gh.ptr(out), 3, 8, 8, 64, gh.stream()), "bmi_maxpool2")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.max_pool2d(x.float().cpu().permute(0, 3, 1, 2), 2)
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)

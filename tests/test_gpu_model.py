@@ -1,0 +1,131 @@
+"""-m gpu: the whole path (bmi_forward_mcd / bmi_finalize through the Python mirror) against
+(a) the golden vectors the reference itself produced and (b) the CPU oracle on larger seeded inputs.
+
+Tolerance (BASELINE.json north_star): predictive mean / variance within 1e-3 of the fp32 CPU
+path on the same inputs and the same masks.  Activations are fp16 with fp32 accumulation, so
+per-pass logits get a looser 2e-2 and per-pass probabilities 2e-3."""
+import numpy as np
+import pytest
+import torch
+
+from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18EarlyExit, ResNet18MC, ResNet18MCEarlyExit
+from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
+from oracle import mcd
+from oracle import resnet18 as oresnet
+from tests.helpers import build_seeded, golden_kwargs, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3
+
+CASES = ["exit_only", "block_exit", "block_noexit", "layer_exit", "mask4_block_exit", "mask8_exit_c100"]
+
+
+def _product(cls, kw):
+    m = build_seeded(cls, kw)
+    synthetic_weights_(m, 0)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_against_reference_golden(name):
+    g = load_golden(f"resnet18_{name}.npz")
+    kw = golden_kwargs(g)
+    B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
+    model = _product(ResNet18MCEarlyExit, kw)
+    model.mc_seed = seed
+    x = synthetic_images(B, seed=1234).to(DEV)
+    # (1) T calls of model(x), exactly how FullAnalysis._get_output drives the reference
+    passes = np.stack([np.stack([o.cpu().numpy() for o in model(x)]) for _ in range(T)])
+    assert passes.shape == g["logits"].shape
+    np.testing.assert_allclose(passes, g["logits"], rtol=0, atol=2e-2)
+    probs = torch.softmax(torch.from_numpy(passes), -1).numpy()
+    ref_probs = torch.softmax(torch.from_numpy(g["logits"]), -1).numpy()
+    np.testing.assert_allclose(probs, ref_probs, rtol=0, atol=2e-3)
+    # (2) the fused T-folded path
+    eng = model.engine(x.device, max_batch=B)
+    r = eng.predict(x, T, seed=seed, cnt0=0)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), g["go_output_sm"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(r["logit_mean"].cpu().numpy(), g["go_output"], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(r["var"].cpu().numpy(), np.var(ref_probs.astype(np.float64), axis=0), rtol=0, atol=TOL)
+    # the two routes see the same masks: T-mean of (1) equals (2)
+    np.testing.assert_allclose(probs.astype(np.float64).mean(0), r["mean"].cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_single_exit_and_deterministic_nets():
+    g = load_golden("resnet18mc_block_exit.npz")
+    m = _product(ResNet18MC, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    m.mc_seed = int(g["seed"])
+    x = synthetic_images(int(g["B"]), seed=1234).to(DEV)
+    passes = np.stack([np.stack([o.cpu().numpy() for o in m(x)]) for _ in range(int(g["T"]))])
+    np.testing.assert_allclose(passes, g["logits"], rtol=0, atol=2e-2)
+    g = load_golden("resnet18_early_exit.npz")
+    m = _product(ResNet18EarlyExit, dict(out_dim=10))
+    out = np.stack([o.cpu().numpy() for o in m(x)])
+    np.testing.assert_allclose(out, g["logits"], rtol=0, atol=2e-2)
+    assert np.array_equal(out, np.stack([o.cpu().numpy() for o in m(x)]))     # no stochastic site -> deterministic
+
+
+@pytest.mark.parametrize("kw,B,T", [
+    (dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10), 37, 7),      # ragged batch, T not a chunk multiple
+    (dict(dropout_exit=True, dropout="block", mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=100), 16, 6),
+])
+def test_against_oracle_larger(kw, B, T):
+    seed = (3 << 32) + 17
+    model = _product(ResNet18MCEarlyExit, kw)
+    oracle_model = build_seeded(oresnet.ResNet18MCEarlyExit, kw)
+    synthetic_weights_(oracle_model, 0)
+    x = synthetic_images(B, seed=99)
+    ref = mcd.mcd_predict(oracle_model, x, T, seed)
+    eng = model.engine(torch.device(DEV), max_batch=B, chunk_samples=3)
+    r = eng.predict(x.to(DEV), T, seed=seed, cnt0=0)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(r["var"].cpu().numpy(), ref["var"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(r["logit_mean"].cpu().numpy(), ref["logit_mean"], rtol=0, atol=2e-2)
+
+
+def test_chunking_and_sharding_invariance():
+    """Size-independent properties: the result does not depend on how the T samples are chunked
+    or sharded — (a) chunk 1 / 3 / 8 give bit-identical moments, (b) two t-ranges accumulated into
+    one buffer equal the single run (what the multi-GPU reduce relies on)."""
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    model = _product(ResNet18MCEarlyExit, kw)
+    B, T, seed = 8, 8, 5
+    x = synthetic_images(B, seed=7).to(DEV)
+    S = []
+    for chunk in (1, 3, 8):
+        eng = model.engine(x.device, max_batch=B, chunk_samples=chunk)
+        S.append(eng.accumulate(x, eng.new_moments(B), 0, T, seed).cpu())
+    assert torch.equal(S[0], S[1]) and torch.equal(S[0], S[2])
+    eng = model.engine(x.device, max_batch=B, chunk_samples=3)
+    Sa = eng.new_moments(B)
+    eng.accumulate(x, Sa, 0, 5, seed)
+    eng.accumulate(x, Sa, 5, 3, seed)
+    torch.testing.assert_close(Sa.cpu(), S[0], rtol=1e-13, atol=1e-13)
+    # different seed / different t-range -> different masks
+    assert not torch.equal(eng.accumulate(x, eng.new_moments(B), 0, T, seed + 1).cpu(), S[0])
+    # probabilities are a distribution, variance is non-negative and non-trivial
+    r = eng.finalize(S[0].to(DEV), T)
+    assert torch.allclose(r["mean"].sum(-1), torch.ones_like(r["mean"].sum(-1)), atol=1e-6)
+    assert (r["var"] >= 0).all() and r["var"].max() > 1e-4
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 3 at full size (B=250, T=100 is the bench; here T=12 keeps the test short):
+    checks finiteness / normalisation and that sample sharding reproduces the single run."""
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    model = _product(ResNet18MCEarlyExit, kw)
+    B, T = 250, 12
+    x = synthetic_images(B, seed=1234).to(DEV)
+    eng = model.engine(x.device, max_batch=B)
+    S = eng.accumulate(x, eng.new_moments(B), 0, T, 42)
+    r = eng.finalize(S, T)
+    assert torch.isfinite(r["mean"]).all() and torch.isfinite(r["logit_mean"]).all()
+    assert torch.allclose(r["mean"].sum(-1), torch.ones(4, B, dtype=torch.float64, device=DEV), atol=1e-6)
+    S2 = eng.new_moments(B)
+    for g0, g1 in ((0, 3), (3, 6), (6, 9), (9, 12)):        # 4 ranks' worth of t-shards
+        eng.accumulate(x, S2, g0, g1 - g0, 42)
+    torch.testing.assert_close(S2, S, rtol=1e-12, atol=1e-12)
+    # row 0 of the big batch equals a batch-of-one run (mask index depends on (b, ...) only)
+    r1 = eng.predict(x[:1].contiguous(), T, seed=42)
+    torch.testing.assert_close(r1["mean"][:, 0], r["mean"][:, 0], rtol=0, atol=1e-6)
