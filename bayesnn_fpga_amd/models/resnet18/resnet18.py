@@ -126,8 +126,11 @@ class ResNet(nn.Module):
             m.cnt = (m.cnt + passes) % m.n
 
     def mask_cnt0(self):
+        """Masksembles counter value that corresponds to MC sample t = 0 of the current stream: the
+        engine selects mask (cnt0 + t) mod M for global sample index t (so t-shards on different
+        GPUs agree), and sample ``mc_pass`` must see the layer's current ``cnt``."""
         ml = self.mask_layers()
-        return ml[0].cnt if ml else 0
+        return (ml[0].cnt - self.mc_pass) % ml[0].n if ml else 0
 
     def forward(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):

@@ -123,7 +123,8 @@ def test_stem_conv():
     scale = (0.5 + torch.rand(64, generator=g))
     bias = 0.2 * torch.randn(64, generator=g)
     out = torch.empty(n, 32, 32, 64, dtype=torch.float16, device=DEV)
-    _lib.check(lib.bmi_stem_conv_fwd(gh.ptr(x), gh.ptr(w.to(DEV)), gh.ptr(scale.to(DEV)), gh.ptr(bias.to(DEV)), gh.ptr(out),
+    wd, sd, bd = w.to(DEV), scale.to(DEV), bias.to(DEV)       # keep the device copies alive across the launch
+    _lib.check(lib.bmi_stem_conv_fwd(gh.ptr(x), gh.ptr(wd), gh.ptr(sd), gh.ptr(bd), gh.ptr(out),
                                      n, 3, 32, 32, 64, 3, 1, 1, 0, gh.stream()), "bmi_stem_conv_fwd")
     torch.cuda.synchronize()
     ref = torch.nn.functional.conv2d(x.cpu(), w.permute(0, 3, 1, 2), padding=1) * scale[None, :, None, None] + bias[None, :, None, None]
@@ -176,7 +177,8 @@ def test_pool_mask_and_linear_softmax_and_moments():
         b = 0.2 * torch.randn(out_dim, generator=g)
         logits = torch.empty(N, out_dim, device=DEV)
         probs = torch.empty(N, out_dim, device=DEV)
-        _lib.check(lib.bmi_linear_softmax(gh.ptr(feat), gh.ptr(w.to(DEV)), gh.ptr(b.to(DEV)), gh.ptr(logits), gh.ptr(probs), N, K,
+        wd, bd = w.to(DEV), b.to(DEV)
+        _lib.check(lib.bmi_linear_softmax(gh.ptr(feat), gh.ptr(wd), gh.ptr(bd), gh.ptr(logits), gh.ptr(probs), N, K,
                                           out_dim, gh.stream()), "bmi_linear_softmax")
         torch.cuda.synchronize()
         ref_l = feat.cpu().double() @ w[:out_dim].double().T + b.double()

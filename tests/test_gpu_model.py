@@ -86,8 +86,9 @@ def test_against_oracle_larger(kw, B, T):
 
 def test_chunking_and_sharding_invariance():
     """Size-independent properties: the result does not depend on how the T samples are chunked
-    or sharded — (a) chunk 1 / 3 / 8 give bit-identical moments, (b) two t-ranges accumulated into
-    one buffer equal the single run (what the multi-GPU reduce relies on)."""
+    or sharded — (a) chunk 1 / 3 / 8 give the same moments (every per-sample value is bit-identical;
+    only the float64 summation order over t differs, so the bar is 1e-12), (b) two t-ranges
+    accumulated into one buffer equal the single run (what the multi-GPU reduce relies on)."""
     kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
     model = _product(ResNet18MCEarlyExit, kw)
     B, T, seed = 8, 8, 5
@@ -96,7 +97,8 @@ def test_chunking_and_sharding_invariance():
     for chunk in (1, 3, 8):
         eng = model.engine(x.device, max_batch=B, chunk_samples=chunk)
         S.append(eng.accumulate(x, eng.new_moments(B), 0, T, seed).cpu())
-    assert torch.equal(S[0], S[1]) and torch.equal(S[0], S[2])
+    torch.testing.assert_close(S[1], S[0], rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(S[2], S[0], rtol=1e-12, atol=1e-12)
     eng = model.engine(x.device, max_batch=B, chunk_samples=3)
     Sa = eng.new_moments(B)
     eng.accumulate(x, Sa, 0, 5, seed)
