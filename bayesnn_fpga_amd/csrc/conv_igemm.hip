@@ -22,6 +22,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 16-byte vector (HIP's uint4 is a struct)
 
 #define BK 64
 
@@ -75,27 +76,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         xbase[j] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + chunk * 8;
     }
 
-    uint4 wreg[WROWS], xreg[XROWS];
-    auto gload = [&](int ky, int kx, int c0) {
-        const int koff = (ky * a.ksize + kx) * a.Cin + c0;
-#pragma unroll
-        for (int j = 0; j < WROWS; ++j) wreg[j] = *(const uint4*)(wptr + (size_t)(32 * j) * Ktot + koff);
-#pragma unroll
-        for (int j = 0; j < XROWS; ++j) {
-            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-            const bool ok = vm[j] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *(const uint4*)(xbase[j] + (size_t)(iy * a.W + ix) * a.Cin + c0);
-            xreg[j] = v;
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* base = smem + buf * TILE;
-#pragma unroll
-        for (int j = 0; j < WROWS; ++j) *(uint4*)(base + st_off + j * 32 * 128) = wreg[j];
-#pragma unroll
-        for (int j = 0; j < XROWS; ++j) *(uint4*)(base + BC * 128 + st_off + j * 32 * 128) = xreg[j];
-    };
+    // NOTE: staging registers are filled/drained by macros, not lambdas: with by-reference lambda
+    // captures hipcc fails to scalarise the arrays and "promotes" them to LDS (an extra 16 KB and a
+    // round trip through LDS per K-step).
+    u32x4 wreg[WROWS], xreg[XROWS];
+#define GLOAD(KY, KX, C0)                                                                                  \
+    {                                                                                                      \
+        const int koff_ = ((KY) * a.ksize + (KX)) * a.Cin + (C0);                                          \
+        _Pragma("unroll") for (int j = 0; j < WROWS; ++j)                                                  \
+            wreg[j] = *(const u32x4*)(wptr + (size_t)(32 * j) * Ktot + koff_);                             \
+        _Pragma("unroll") for (int j = 0; j < XROWS; ++j) {                                                \
+            const int iy_ = iy0[j] + (KY), ix_ = ix0[j] + (KX);                                            \
+            const bool ok_ = vm[j] && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;      \
+            u32x4 v_ = {0u, 0u, 0u, 0u};                                                                   \
+            if (ok_) v_ = *(const u32x4*)(xbase[j] + (size_t)(iy_ * a.W + ix_) * a.Cin + (C0));           \
+            xreg[j] = v_;                                                                                  \
+        }                                                                                                  \
+    }
+#define LSTORE(BUF)                                                                                        \
+    {                                                                                                      \
+        char* base_ = smem + (BUF) * TILE;                                                                 \
+        _Pragma("unroll") for (int j = 0; j < WROWS; ++j) *(u32x4*)(base_ + st_off + j * 32 * 128) = wreg[j];   \
+        _Pragma("unroll") for (int j = 0; j < XROWS; ++j)                                                  \
+            *(u32x4*)(base_ + BC * 128 + st_off + j * 32 * 128) = xreg[j];                                 \
+    }
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     const int nK = a.ksize * a.ksize * (a.Cin / BK);
     int ky = 0, kx = 0, c0 = 0;
-    gload(ky, kx, c0);
-    lstore(0);
+    GLOAD(ky, kx, c0);
+    LSTORE(0);
     __syncthreads();
 
     const int sw_r = (r >> 1) & 7;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 c0 = 0;
                 if (++kx == a.ksize) { kx = 0; ++ky; }
             }
-            gload(ky, kx, c0);
+            GLOAD(ky, kx, c0);
         }
         const char* wt = smem + buf * TILE;
         const char* xt = wt + BC * 128;
@@ -142,10 +146,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(buf ^ 1);
+        if (more) LSTORE(buf ^ 1);
         __syncthreads();
     }
 
+#undef GLOAD
+#undef LSTORE
     // ---- epilogue ---------------------------------------------------------------------------
     const int BHW = a.B * HoWo;
 #pragma unroll

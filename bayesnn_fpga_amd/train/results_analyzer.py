@@ -1,0 +1,154 @@
+"""Result collation for the MCD path, mirroring ``FullAnalysis`` of SA/train/results_analyzer.py.
+
+What is mirrored (same method names, argument meaning and return shapes):
+  * ``_get_output(b_x)``            :236-270 — 5-tuple (T-mean logits, T-mean probs, probs ndarray [E,B,C],
+                                      exit-ensembled logits, exit-ensembled probs); the T passes, softmax and the
+                                      float64 means run on the GPU (``MCDEngine.predict``), the cumulative
+                                      exit means are host collation like the reference's.
+  * ``sdn_get_detailed_results()``  :113-177 — ``preds`` / ``ensemble_preds`` float64 [E,N,C], one-hot ``labels``,
+                                      per-exit correct / wrong instance sets, predictions and confidences.
+  * ``all_experiments`` + ``saver`` :288-337, :508-541 — per-exit and per-ensemble accuracy, cumulative /
+                                      unique correct, destructive overthinking, ECE, NLL, MSE; the
+                                      ``test_evaluation_log_*.txt`` CSV rows and the 3-array ``.npy`` file.
+Differences, on purpose: ECE is the 15-bin equal-mass histogram ECE (``ece_hist_binary`` :446-495) because
+the reference's KDE-ECE needs KDEpy (parity unpinned); trackers are vectorised instead of the
+per-instance Python loop (:272-286); the extra output ``var`` (T-sample variance) is kept in ``self.var``.
+Out of scope here: confidence-threshold exiting and the analytical FLOP model (:543-734).
+"""
+import numpy as np
+import torch
+
+from .metrics import ece_hist_binary, nll_mse_acc
+
+
+def get_device(gpu):
+    """SA/train/train_utils.py:10-11."""
+    return torch.device(f"cuda:{gpu}" if gpu >= 0 else "cpu")
+
+
+def exit_ensembles(per_exit):
+    """Entry i = mean over exits 0..i (results_analyzer.py:260-269, :163-165)."""
+    c = np.cumsum(per_exit, axis=0)
+    return c / np.arange(1, per_exit.shape[0] + 1).reshape((-1,) + (1,) * (per_exit.ndim - 1))
+
+
+class FullAnalysis:
+    def __init__(self, model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="", seed=0):
+        self.model = model
+        self.loader = test_loader
+        self.gpu = gpu
+        self.mc_dropout = mc_dropout
+        self.mc_passes = mc_passes if mc_dropout else 1
+        self.filename_suffix = suffix
+        self.seed = seed
+        self.device = get_device(gpu)
+        self._batch_index = 0
+        if test_loader is not None:
+            self.sdn_get_detailed_results()
+
+    # -- device side -------------------------------------------------------------------------
+    def _predict(self, b_x):
+        """T folded passes on the GPU -> dict of float64 numpy arrays [E,B,C]."""
+        eng = self.model.engine(b_x.device, max_batch=b_x.shape[0])
+        r = eng.predict(b_x, self.mc_passes, seed=self.seed + self._batch_index, cnt0=self.model.mask_cnt0())
+        self.model.advance(self.mc_passes)
+        return {k: v.cpu().numpy() for k, v in r.items()}
+
+    def _get_output(self, b_x):
+        r = self._predict(b_x)
+        self.last_var = r["var"]
+        logit_mean, prob_mean = r["logit_mean"], r["mean"]
+        output = [torch.from_numpy(a) for a in logit_mean]
+        output_sm = [torch.from_numpy(a) for a in prob_mean]
+        ens_out = [torch.from_numpy(a) for a in exit_ensembles(logit_mean)]
+        ens_sm = [torch.from_numpy(a) for a in exit_ensembles(prob_mean)]
+        return output, output_sm, prob_mean, ens_out, ens_sm
+
+    # -- host collation ------------------------------------------------------------------------
+    @staticmethod
+    def _track(logits_like, probs, labels, offset, correct, wrong, predictions, confidence):
+        pred = np.argmax(logits_like, axis=1)
+        conf = np.max(probs, axis=1)
+        ok = pred == labels
+        ids = np.arange(len(labels)) + offset
+        correct.update(ids[ok].tolist())
+        wrong.update(ids[~ok].tolist())
+        predictions.update(zip(ids.tolist(), pred.tolist()))
+        confidence.update(zip(ids.tolist(), conf.tolist()))
+
+    def _collect(self, loader):
+        n_exits, C = self.model.n_exits if self.model.n_exits > 1 else len(self._probe_exits()), self.model.out_dim
+        n = len(loader.dataset) if hasattr(loader, "dataset") else sum(len(b[1]) for b in loader)
+        preds = np.empty((n_exits, n, C))
+        var = np.empty((n_exits, n, C))
+        labels = np.zeros((n, C))
+        trackers = [[(set(), set(), {}, {}) for _ in range(n_exits)] for _ in range(2)]
+        off = 0
+        for self._batch_index, batch in enumerate(loader):
+            b_x = batch[0].to(self.device)
+            b_y = batch[1].cpu().numpy().astype(np.int64)
+            output, output_sm, output_sm_np, ens_out, ens_sm = self._get_output(b_x)
+            B = len(b_y)
+            for e in range(n_exits):
+                self._track(output[e].numpy(), output_sm[e].numpy(), b_y, off, *trackers[0][e])
+                self._track(ens_out[e].numpy(), ens_sm[e].numpy(), b_y, off, *trackers[1][e])
+            labels[np.arange(B) + off, b_y] = 1
+            preds[:, off:off + B] = output_sm_np
+            var[:, off:off + B] = self.last_var
+            off += B
+        return preds, exit_ensembles(preds), labels, var, trackers
+
+    def _probe_exits(self):
+        from ..engine import model_exits
+        return range(model_exits(self.model))
+
+    def sdn_get_detailed_results(self):
+        self.model.eval()
+        self.outputs = list(self._probe_exits())
+        self.preds, self.ensemble_preds, self.labels, self.var, tr = self._collect(self.loader)
+        names = ("layer_correct", "layer_wrong", "layer_predictions", "layer_confidence")
+        for k, nm in enumerate(names):
+            setattr(self, nm, {e: tr[0][e][k] for e in self.outputs})
+            setattr(self, "ensemble_" + nm, {e: tr[1][e][k] for e in self.outputs})
+        return None
+
+    def get_validation_predictions(self, val_loader):
+        preds, ens, labels, _, _ = self._collect(val_loader)
+        return preds, ens, labels
+
+    def ece_eval_binary(self, p, label):
+        """(ECE, NLL, MSE, accuracy) — :497-505 with the histogram ECE in place of the KDE ECE."""
+        nll, mse, acc = nll_mse_acc(p, label)
+        return ece_hist_binary(p, label), nll, mse, acc
+
+    def all_experiments(self, experiment_id, write=True):
+        rows = []
+        for prefix, correct, wrong, preds in (("", self.layer_correct, self.layer_wrong, self.preds),
+                                              ("Ensemble", self.ensemble_layer_correct, self.ensemble_layer_wrong,
+                                               self.ensemble_preds)):
+            layers = sorted(correct.keys())
+            end_wrong = wrong[layers[-1]]
+            cum = set()
+            for layer in layers:
+                cur = correct[layer]
+                unique = cur - cum
+                cum = cum | cur
+                ece, nll, mse, acc = self.ece_eval_binary(preds[layer], self.labels)
+                rows.append((f"{prefix}{layer}", acc, len(cum), len(cur & end_wrong), len(unique), ece, nll, mse))
+        self.rows = rows
+        if write:
+            self.saver(experiment_id)
+        return rows
+
+    def saver(self, experiment_id):
+        """Layer,Accuracy,Cumulative Correct,Destructive Overthinking,Unique Correct,ECE,NLL,MSE (:515-526) and the
+        three consecutive np.save arrays preds / ensemble_preds / labels (:538-541)."""
+        name = f"test_evaluation_log_{type(self.model).__name__}{experiment_id}{self.filename_suffix}.txt"
+        with open(name, "w") as f:
+            for r in self.rows:
+                f.write(",".join(str(v) for v in r) + "\n")
+        with open(f"test_predictions_{experiment_id}.npy", "wb") as f:
+            np.save(f, self.preds)
+            np.save(f, self.ensemble_preds)
+            np.save(f, self.labels)
+        return name

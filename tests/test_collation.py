@@ -1,0 +1,90 @@
+"""Host collation (FullAnalysis mirror, metrics) on CPU: the device step is replaced by the oracle's
+per-pass outputs, so what is checked is the collation against the reference's own 5-tuple / metrics."""
+import numpy as np
+import pytest
+import torch
+
+from bayesnn_fpga_amd.train import FullAnalysis, MultiExitAccuracy
+from bayesnn_fpga_amd.train.metrics import ece_hist_binary, nll_mse_acc
+from bayesnn_fpga_amd.train.results_analyzer import exit_ensembles
+from tests.helpers import load_golden
+
+
+class _Injected(FullAnalysis):
+    def __init__(self, logits, probs, model):
+        self._l, self._p = logits, probs
+        super().__init__(model, None, gpu=-1, mc_dropout=True, mc_passes=logits.shape[0])
+
+    def _predict(self, b_x):
+        return dict(mean=self._p.mean(0), var=self._p.var(0), logit_mean=self._l.mean(0))
+
+
+class _M:
+    n_exits, out_dim = 4, 10
+
+
+def test_get_output_tuple_matches_reference():
+    g = load_golden("resnet18_block_exit.npz")
+    logits = g["logits"].astype(np.float64)
+    probs = torch.softmax(torch.from_numpy(g["logits"]), -1).numpy().astype(np.float64)
+    fa = _Injected(logits, probs, _M())
+    out, out_sm, out_sm_np, ens_out, ens_sm = fa._get_output(torch.zeros(4, 3, 32, 32))
+    np.testing.assert_allclose(np.stack([o.numpy() for o in out]), g["go_output"], atol=1e-6)
+    np.testing.assert_allclose(np.stack([o.numpy() for o in out_sm]), g["go_output_sm"], atol=1e-7)
+    np.testing.assert_allclose(out_sm_np, g["go_output_sm_np"], atol=1e-7)
+    np.testing.assert_allclose(np.stack([o.numpy() for o in ens_out]), g["go_ensemble_output"], atol=1e-6)
+    np.testing.assert_allclose(np.stack([o.numpy() for o in ens_sm]), g["go_ensemble_output_sm"], atol=1e-7)
+    assert out_sm[0].dtype == torch.float64
+
+
+def test_exit_ensembles_is_prefix_mean():
+    a = np.random.RandomState(0).rand(4, 5, 3)
+    e = exit_ensembles(a)
+    for i in range(4):
+        np.testing.assert_allclose(e[i], a[:i + 1].mean(0), rtol=1e-12)
+
+
+def test_metrics_match_reference():
+    g = load_golden("metrics.npz")
+    assert ece_hist_binary(g["p"], g["onehot"]) == pytest.approx(float(g["ece_hist"]), abs=1e-6)
+    nll, mse, acc = nll_mse_acc(g["p"], g["onehot"])
+    assert (nll, mse, acc) == (pytest.approx(float(g["nll"]), rel=1e-12), pytest.approx(float(g["mse"]), rel=1e-12),
+                               float(g["acc"]))
+    logits = [torch.from_numpy(l) for l in g["logits"]]
+    y = torch.from_numpy(g["y"])
+    np.testing.assert_allclose(MultiExitAccuracy(4)._metrics(logits, y), g["acc_vec4"], atol=1e-7)
+    np.testing.assert_allclose(MultiExitAccuracy(1)._metrics(logits, y), g["acc_vec1"], atol=1e-7)
+    assert MultiExitAccuracy(4).metric_names[0] == "acc1_avg" and len(MultiExitAccuracy(4).metric_names) == 2 + 2 * 7 + 1
+
+
+def test_full_collation_on_a_loader(tmp_path, monkeypatch):
+    rng = np.random.RandomState(1)
+    T, E, B, C = 3, 4, 6, 10
+    logits = rng.randn(T, E, B, C) * 2
+    probs = torch.softmax(torch.from_numpy(logits), -1).numpy()
+    labels = rng.randint(0, C, size=2 * B)
+    loader = [(torch.zeros(B, 3, 32, 32), torch.from_numpy(labels[:B])), (torch.zeros(B, 3, 32, 32), torch.from_numpy(labels[B:]))]
+
+    class FA(_Injected):
+        def __init__(self):
+            self._l, self._p = logits, probs
+            FullAnalysis.__init__(self, _M(), loader, gpu=-1, mc_dropout=True, mc_passes=T)
+    m = _M()
+    m.eval = lambda: None
+    _M.eval = lambda self: None
+    fa = FA()
+    assert fa.preds.shape == (E, 2 * B, C) and fa.labels.sum() == 2 * B
+    np.testing.assert_allclose(fa.ensemble_preds[2], fa.preds[:3].mean(0))
+    pred0 = probs.mean(0)[0].argmax(1)            # argmax of mean logits == tracked prediction source
+    want = set(np.nonzero(logits.mean(0)[0].argmax(1) == labels[:B])[0].tolist())
+    assert {i for i in fa.layer_correct[0] if i < B} == want
+    assert fa.layer_correct[0] | fa.layer_wrong[0] == set(range(2 * B))
+    monkeypatch.chdir(tmp_path)
+    rows = fa.all_experiments("x1")
+    assert [r[0] for r in rows] == ["0", "1", "2", "3", "Ensemble0", "Ensemble1", "Ensemble2", "Ensemble3"]
+    assert rows[3][2] >= rows[0][2]                # cumulative correct is monotone
+    with open(tmp_path / "test_predictions_x1.npy", "rb") as f:
+        a, b, c = np.load(f), np.load(f), np.load(f)
+    assert a.shape == b.shape == (E, 2 * B, C) and c.shape == (2 * B, C)
+    txt = open(next(tmp_path.glob("test_evaluation_log_*x1.txt"))).read().strip().split("\n")
+    assert len(txt) == 8 and len(txt[0].split(",")) == 8

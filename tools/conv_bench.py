@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernels per GEMM shape class, through the
+C ABI, timed with HIP events on the launch stream.  Used for kernel tuning and as the target of
+rocprofv3 --pmc runs (few other kernels in the trace).
+
+    python tools/conv_bench.py --images 1000 --iters 20 [--only S2,D3] [--check]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayesnn_fpga_amd import _lib  # noqa: E402
+
+SHAPES = {  # Cin, Cout, H, k, stride, pad
+    "S1": (64, 64, 32, 3, 1, 1), "D2": (64, 128, 32, 3, 2, 1), "P2": (64, 128, 32, 1, 2, 0),
+    "S2": (128, 128, 16, 3, 1, 1), "D3": (128, 256, 16, 3, 2, 1), "P3": (128, 256, 16, 1, 2, 0),
+    "S3": (256, 256, 8, 3, 1, 1), "D4": (256, 512, 8, 3, 2, 1), "P4": (256, 512, 8, 1, 2, 0),
+    "S4": (512, 512, 4, 3, 1, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=1000)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--site", action="store_true", help="fuse an elementwise MC-dropout site into the epilogue")
+    a = ap.parse_args()
+    lib = _lib.lib()
+    dev = "cuda:0"
+    names = [s for s in a.only.split(",") if s] or list(SHAPES)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    total_t = total_f = 0.0
+    for name in names:
+        cin, cout, H, k, s, p = SHAPES[name]
+        n = a.images
+        ho = (H + 2 * p - k) // s + 1
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(n, H, H, cin, generator=g).to(torch.float16).to(dev)
+        w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(torch.float16).to(dev)
+        scale = (0.5 + torch.rand(cout, generator=g)).to(dev)
+        bias = (0.1 * torch.randn(cout, generator=g)).to(dev)
+        res = torch.randn(n, ho, ho, cout, generator=g).to(torch.float16).to(dev)
+        out = torch.empty(n, ho, ho, cout, dtype=torch.float16, device=dev)
+        site = _lib.make_site(_lib.SITE_ELEMENTWISE, 2, 0.25) if a.site else None
+
+        def run():
+            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), w.data_ptr(), scale.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                                        out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1,
+                                        C.byref(site) if site is not None else None, 250, 0, 42, 0, st)
+            _lib.check(rc, "bmi_conv_igemm_fwd")
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        flops = 2.0 * n * ho * ho * cout * k * k * cin
+        total_t += ms
+        total_f += flops
+        print(f"{name}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s   (M={n * ho * ho}, N={cout}, K={k * k * cin})", flush=True)
+    print(f"all: {total_f / total_t / 1e9:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
