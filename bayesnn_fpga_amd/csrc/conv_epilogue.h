@@ -1,0 +1,178 @@
+// Fused conv epilogue shared by the implicit-GEMM and the patch kernels: folded-BN scale/bias,
+// residual add, ReLU, stochastic site, fp16 NHWC store — for ONE accumulator quad (4 consecutive
+// output channels of one pixel, the (reg & 3) registers of v_mfma_f32_32x32x16 with channels on
+// the row axis).  Reference semantics: BasicBlock.forward SA/models/resnet18/resnet18.py:32-48,
+// MCDropout :207-210, Masksembles2D SA/utils.py:165-169.
+#pragma once
+#include "kernels.h"
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+struct PixelCtx {
+    size_t out_off;        // element offset of this pixel's channel 0 in the output tensor
+    const _Float16* resp;  // residual row or nullptr
+    const float* mrow;     // Masksembles row or nullptr
+    int e_pix;             // pixel index inside one Monte-Carlo sample: (b*Ho + y)*Wo + x
+    int b;                 // image index inside the sample
+    int t;                 // global sample index
+};
+
+__device__ __forceinline__ PixelCtx make_pixel_ctx(const ConvArgs& a, int n, int rem /* y*Wo + x */) {
+    const int HoWo = a.Ho * a.Wo;
+    PixelCtx p;
+    p.out_off = ((size_t)n * HoWo + rem) * a.Cout;
+    p.resp = a.res ? a.res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout : nullptr;
+    const int tl = n / a.B;
+    p.b = n - tl * a.B;
+    p.t = a.t0 + tl;
+    p.e_pix = p.b * HoWo + rem;
+    p.mrow = a.site.kind == BMI_SITE_MASKSEMBLE
+                 ? a.site.masks + (size_t)((a.site.cnt0 + p.t) % a.site.num_masks) * a.Cout
+                 : nullptr;
+    return p;
+}
+
+__device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx& p, float v[4], int c4) {
+    if (a.scale) {
+        const float4 s4 = *(const float4*)(a.scale + c4);
+        v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
+    }
+    if (a.bias) {
+        const float4 b4 = *(const float4*)(a.bias + c4);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (p.resp) {
+        const half4 r4 = *(const half4*)(p.resp + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
+        const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)p.e_pix * a.Cout + c4
+                                                                  : (uint64_t)p.b * a.Cout + c4;
+        const uint64_t g = elem >> 2;
+        const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p.t, (uint32_t)a.site.site_id,
+                                         a.site.seed_lo, a.site.seed_hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[e] * a.site.scale : 0.f;
+    } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
+        const float4 k4 = *(const float4*)(p.mrow + c4);
+        v[0] *= k4.x; v[1] *= k4.y; v[2] *= k4.z; v[3] *= k4.w;
+    }
+    half4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+    *(half4*)(a.out + p.out_off + c4) = o;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Coalesced epilogue for 128-channel tiles: accumulators -> LDS (fp32, after BN scale/bias) ->
+// full 256-byte NHWC row segments.  The per-quad path above issues, per lane, dozens of
+// dependent 8-byte loads/stores that touch 32 different rows per instruction; here every global
+// access is 16 B per lane with 16 consecutive lanes covering one pixel's 128 channels, the
+// residual loads of a round are all issued before the first use, and the BN vectors are loaded
+// once per channel quad instead of once per (quad, pixel tile).
+//   LDS tile  [128 pixels][128 ch] fp32, 512-byte rows; 16-byte chunk q of pixel row p is stored
+//   at chunk q ^ (p & 31): conflict-free for the ds_write_b128 of phase 1 (8-lane groups = 8
+//   different pixels, same q) and for the ds_read_b128 of phase 2.
+//   A round handles 2 of the wave's TJ pixel tiles (64 KB); TJ = 4 takes two rounds.
+typedef float f32x16_e __attribute__((ext_vector_type(16)));
+typedef float f32x4_e __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
+
+#define BMI_EPILOGUE_LDS_BYTES 65536
+
+template <int TJ, class PixMap>
+__device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (&acc)[2][TJ], char* lds, int tid, int ch0,
+                                                   PixMap pixmap) {
+    static_assert(TJ == 2 || TJ == 4, "two pixel tiles per round");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wc = wave >> 1, wp = wave & 1;
+#pragma unroll
+    for (int rr = 0; rr < TJ / 2; ++rr) {
+        // BN scale / bias of this lane's 8 channel quads (re-loaded per round: L1 hits, and not
+        // live across phase 2, which keeps the kernel under 256 VGPRs)
+        f32x4_e sc[8], bi[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c4 = ch0 + wc * 64 + 32 * (q >> 2) + 8 * (q & 3) + 4 * hh;
+            sc[q] = a.scale ? *(const f32x4_e*)(a.scale + c4) : f32x4_e{1.f, 1.f, 1.f, 1.f};
+            bi[q] = a.bias ? *(const f32x4_e*)(a.bias + c4) : f32x4_e{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();   // main loop (or previous round's phase 2) is done with the LDS
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int pl = wp * 64 + jj * 32 + r;   // pixel inside the round
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = q >> 2, g4 = q & 3;
+                f32x4_e v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][2 * rr + jj][4 * g4 + e] * sc[q][e] + bi[q][e];
+                const int cq = wc * 16 + 8 * i + 2 * g4 + hh;
+                *(f32x4_e*)(lds + pl * 512 + ((cq ^ (pl & 31)) << 4)) = v;
+            }
+        }
+        __syncthreads();
+        // phase 2: 128 pixels x 16 groups of 8 channels = 2048 items, 8 per thread
+        half8_e resv[8];
+        int pn[8], prem[8];   // image index (-1: tile pixel beyond the tensor) and y*Wo+x
+        const int k = tid & 15;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int pl = (tid >> 4) + 16 * it;
+            const int p = (pl >> 6) * (32 * TJ) + rr * 64 + (pl & 63);   // pixel inside the workgroup tile
+            int n, rem;
+            const bool okp = pixmap(p, n, rem);
+            pn[it] = okp ? n : -1;
+            prem[it] = rem;
+            if (okp && a.res)
+                resv[it] = *(const half8_e*)(a.res + ((size_t)(n % a.res_mod) * (a.Ho * a.Wo) + rem) * a.Cout + ch0 + 8 * k);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (pn[it] < 0) continue;
+            const int pl = (tid >> 4) + 16 * it;
+            const int s = pl & 31;
+            const PixelCtx px = make_pixel_ctx(a, pn[it], prem[it]);
+            const f32x4_e lo = *(const f32x4_e*)(lds + pl * 512 + (((2 * k) ^ s) << 4));
+            const f32x4_e hi = *(const f32x4_e*)(lds + pl * 512 + (((2 * k + 1) ^ s) << 4));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const int c8 = ch0 + 8 * k;
+            if (px.resp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)resv[it][e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
+                const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)px.e_pix * a.Cout + c8
+                                                                          : (uint64_t)px.b * a.Cout + c8;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const uint64_t g = (elem >> 2) + h2;
+                    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)px.t,
+                                                     (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[4 * h2 + e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[4 * h2 + e] * a.site.scale : 0.f;
+                }
+            } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
+                const f32x4_e k0 = *(const f32x4_e*)(px.mrow + c8), k1 = *(const f32x4_e*)(px.mrow + c8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] *= k0[e]; v[4 + e] *= k1[e]; }
+            }
+            half8_e o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+            *(half8_e*)(a.out + px.out_off + c8) = o;
+        }
+    }
+}

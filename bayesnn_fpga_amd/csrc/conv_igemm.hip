@@ -17,10 +17,10 @@
 // Philox, channel dropout, or Masksembles channel mask), fp16 store.
 // Reference semantics: BasicBlock.forward SA/models/resnet18/resnet18.py:32-48, exit-head convs
 // :306-308/:318-319/:329, MCDropout :207-210, Masksembles2D SA/utils.py:165-169.
+#include "conv_epilogue.h"
 #include "kernels.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 16-byte vector (HIP's uint4 is a struct)
 
@@ -153,69 +153,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #undef GLOAD
 #undef LSTORE
     // ---- epilogue ---------------------------------------------------------------------------
-    const int BHW = a.B * HoWo;
+    if constexpr (BC == 128 && BP == 128 && WC == 2 && WP == 2) {
+        // coalesced through LDS (conv_epilogue.h); the double buffer is exactly the 64 KB it needs
+        auto pixmap = [&](int p, int& n, int& rem) -> bool {
+            const int m = pix0 + p;
+            n = m / HoWo;
+            rem = m - n * HoWo;
+            return m < a.M;
+        };
+        epilogue_coalesced<TJ>(a, acc, smem, tid, ch0, pixmap);
+    } else {
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const int m = pix0 + wp * (BP / WP) + 32 * j + r;
-        if (m >= a.M) continue;
-        const int n = m / HoWo;
-        const int rem = m - n * HoWo;
-        const int tl = m / BHW;
-        const int e_pix = m - tl * BHW;
-        const int t = a.t0 + tl;
-        const _Float16* resp = a.res ? a.res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout : nullptr;
-        _Float16* outp = a.out + (size_t)m * a.Cout;
-        const float* mrow = nullptr;
-        if (a.site.kind == BMI_SITE_MASKSEMBLE)
-            mrow = a.site.masks + (size_t)((a.site.cnt0 + t) % a.site.num_masks) * a.Cout;
+        for (int j = 0; j < TJ; ++j) {
+            const int m = pix0 + wp * (BP / WP) + 32 * j + r;
+            if (m >= a.M) continue;
+            const int n = m / HoWo;
+            const PixelCtx px = make_pixel_ctx(a, n, m - n * HoWo);
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
+            for (int i = 0; i < TI; ++i) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c4 = ch0 + wc * (BC / WC) + 32 * i + 8 * g4 + 4 * hh;
-                float v[4];
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c4 = ch0 + wc * (BC / WC) + 32 * i + 8 * g4 + 4 * hh;
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
-                if (a.scale) {
-                    const float4 s4 = *(const float4*)(a.scale + c4);
-                    v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
+                    epilogue_quad(a, px, v, c4);
                 }
-                if (a.bias) {
-                    const float4 b4 = *(const float4*)(a.bias + c4);
-                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                }
-                if (resp) {
-                    const half4 r4 = *(const half4*)(resp + c4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (a.site.kind == BMI_SITE_ELEMENTWISE) {
-                    const uint64_t g = ((uint64_t)e_pix * a.Cout + c4) >> 2;
-                    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t,
-                                                     (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[e] * a.site.scale : 0.f;
-                } else if (a.site.kind == BMI_SITE_CHANNEL) {
-                    const int b = e_pix / HoWo;
-                    const uint64_t g = ((uint64_t)b * a.Cout + c4) >> 2;
-                    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t,
-                                                     (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[e] * a.site.scale : 0.f;
-                } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
-                    const float4 k4 = *(const float4*)(mrow + c4);
-                    v[0] *= k4.x; v[1] *= k4.y; v[2] *= k4.z; v[3] *= k4.w;
-                }
-                half4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                *(half4*)(outp + c4) = o;
             }
         }
     }

@@ -12,6 +12,7 @@
 // Activation buffers live in ONE caller-owned workspace; the suffix tensors are packed by
 // live range (first-fit) so a chunk's working set stays small enough for the Infinity Cache.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -75,6 +76,20 @@ SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
         s.cnt0 = mask_cnt0;
     }
     return s;
+}
+
+// Kernel selection for one conv launch.  BMI_CONV_IMPL=igemm forces the per-tap implicit GEMM
+// (used by the parity tests to cover both kernels).
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    static const int force_igemm = [] {
+        const char* v = std::getenv("BMI_CONV_IMPL");
+        return (v && std::strcmp(v, "igemm") == 0) ? 1 : 0;
+    }();
+    if (!force_igemm) {
+        const int rc = launch_conv3x3_patch(a, s);
+        if (rc != BMI_ERR_UNSUPPORTED) return rc;
+    }
+    return launch_conv_igemm(a, s);
 }
 
 static bool site_ok(const bmi_site& s) {
@@ -369,7 +384,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.M = N * op.ho * op.wo;
             a.B = B; a.t0 = t0;
             a.site = resolve_site(&d.site, seed, cnt0);
-            return launch_conv_igemm(a, s);
+            return launch_conv(a, s);
         }
         case BMI_OP_MASK: {
             EltArgs a;
@@ -494,7 +509,7 @@ int bmi_conv_igemm_fwd(const void* in, const void* weight, const float* scale, c
     a.M = n * a.Ho * a.Wo;
     a.B = batch; a.t0 = t0;
     a.site = resolve_site(site, seed, mask_cnt0);
-    return launch_conv_igemm(a, (hipStream_t)stream);
+    return launch_conv(a, (hipStream_t)stream);
 }
 
 static int elt_args(EltArgs& a, const void* in, void* out, int n, int in_mod, int hw, int c, const bmi_site* site, int batch,

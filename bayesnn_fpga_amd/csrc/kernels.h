@@ -35,6 +35,8 @@ struct EltArgs {  // MASK / POOL ops
 };
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
+int launch_conv(const ConvArgs& a, hipStream_t s);           // picks the kernel
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s);
 int launch_mask_apply(const EltArgs& a, hipStream_t s);

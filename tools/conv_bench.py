@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--site", action="store_true", help="fuse an elementwise MC-dropout site into the epilogue")
+    ap.add_argument("--nores", action="store_true")
+    ap.add_argument("--noscale", action="store_true")
     a = ap.parse_args()
     lib = _lib.lib()
     dev = "cuda:0"
@@ -50,7 +52,8 @@ def main():
         site = _lib.make_site(_lib.SITE_ELEMENTWISE, 2, 0.25) if a.site else None
 
         def run():
-            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), w.data_ptr(), scale.data_ptr(), bias.data_ptr(), res.data_ptr(),
+            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), w.data_ptr(), None if a.noscale else scale.data_ptr(),
+                                        None if a.noscale else bias.data_ptr(), None if a.nores else res.data_ptr(),
                                         out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1,
                                         C.byref(site) if site is not None else None, 250, 0, 42, 0, st)
             _lib.check(rc, "bmi_conv_igemm_fwd")
