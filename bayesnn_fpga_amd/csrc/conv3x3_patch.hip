@@ -56,6 +56,9 @@ struct PatchGeom {
 #ifndef BMI_PATCH_WDMA
 #define BMI_PATCH_WDMA 1
 #endif
+#ifndef BMI_PATCH_SWPIPE
+#define BMI_PATCH_SWPIPE 1
+#endif
 
 template <int S, int TH, int TW, int IMGS, int TJ>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
@@ -183,6 +186,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 boff[j] = (bcell[j] + coff) * 128;
                 bsw[j] = ((bkey[j] + koff) >> 1) & 7;
             }
+#if BMI_PATCH_SWPIPE
+            // Fragment reads are software-pipelined by hand: the reads for k-substep kk+1 are issued
+            // between the MFMAs of kk, each into the registers whose last MFMA use has just been issued,
+            // so the LDS latency hides under the remaining MFMAs instead of stalling every substep.
+            half8 af[TI], bf[TJ];
+#define RD_A(I, KK) af[I] = *(const half8*)(wt + a_off + (I) * 32 * 128 + (((2 * (KK) + hh) ^ a_sw) << 4))
+#define RD_B(J, KK) bf[J] = *(const half8*)(patch + boff[J] + (((2 * (KK) + hh) ^ bsw[J]) << 4))
+#pragma unroll
+            for (int i = 0; i < TI; ++i) RD_A(i, 0);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) RD_B(j, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[j], acc[0][j], 0, 0, 0);
+                if (kk < 3) RD_A(0, kk + 1);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[j], acc[1][j], 0, 0, 0);
+                    if (kk < 3) RD_B(j, kk + 1);
+                }
+                if (kk < 3) RD_A(1, kk + 1);
+            }
+#undef RD_A
+#undef RD_B
+            // pin the interleave (LLVM sched groups: 0x008 = MFMA, 0x100 = DS read)
+            __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TJ, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TJ, 0);
+#else
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int ch = 2 * kk + hh;
@@ -197,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                     for (int j = 0; j < TJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
+#endif
             if (more) STORE_W(buf ^ 1);
             if (tap == 8 && chunk + 1 < nchunks) {
                 __syncthreads();                 // every wave is done reading this chunk's patch

@@ -86,67 +86,83 @@ typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
 
 #define BMI_EPILOGUE_LDS_BYTES 65536
 
+// LDS-only barrier: the epilogue's global stores / outstanding residual loads must NOT be drained
+// at the round boundaries (a __syncthreads() would add s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int TJ, class PixMap>
 __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (&acc)[2][TJ], char* lds, int tid, int ch0,
                                                    PixMap pixmap) {
     static_assert(TJ == 2 || TJ == 4, "two pixel tiles per round");
+    constexpr int NR = TJ / 2;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int wc = wave >> 1, wp = wave & 1;
+    const int k = tid & 15;
+    // Residual rows are requested one round ahead (round 0 here, round r+1 right after the LDS
+    // writes of round r): their HBM latency overlaps the BN pass / LDS transposition instead of
+    // being exposed in every round, and at most two rounds' rows (64 VGPRs) are live at once.
+    half8_e resv[NR][8];
+    int pn[NR][8], prem[NR][8];   // image index (-1: tile pixel beyond the tensor) and y*Wo+x
+#define BMI_EPI_FETCH(RR)                                                                              \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                 \
+        const int pl_ = (tid >> 4) + 16 * it;                                                          \
+        const int p_ = (pl_ >> 6) * (32 * TJ) + (RR) * 64 + (pl_ & 63); /* pixel inside the WG tile */ \
+        int n_, rem_;                                                                                  \
+        const bool okp_ = pixmap(p_, n_, rem_);                                                        \
+        pn[RR][it] = okp_ ? n_ : -1;                                                                   \
+        prem[RR][it] = rem_;                                                                           \
+        if (okp_ && a.res)                                                                             \
+            resv[RR][it] = *(const half8_e*)(a.res + ((size_t)(n_ % a.res_mod) * (a.Ho * a.Wo) + rem_) * a.Cout + ch0 + 8 * k); \
+    }
+    BMI_EPI_FETCH(0);
 #pragma unroll
-    for (int rr = 0; rr < TJ / 2; ++rr) {
-        // BN scale / bias of this lane's 8 channel quads (re-loaded per round: L1 hits, and not
-        // live across phase 2, which keeps the kernel under 256 VGPRs)
-        f32x4_e sc[8], bi[8];
+    for (int rr = 0; rr < NR; ++rr) {
+        lds_barrier();   // main loop (or previous round's phase 2) is done with the LDS
+        // phase 1: BN scale / bias, then fp32 rows into the swizzled LDS tile.  The BN vectors are
+        // fetched per half (4 channel quads = 32 VGPRs) so the kernel stays under 256 VGPRs.
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c4 = ch0 + wc * 64 + 32 * (q >> 2) + 8 * (q & 3) + 4 * hh;
-            sc[q] = a.scale ? *(const f32x4_e*)(a.scale + c4) : f32x4_e{1.f, 1.f, 1.f, 1.f};
-            bi[q] = a.bias ? *(const f32x4_e*)(a.bias + c4) : f32x4_e{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();   // main loop (or previous round's phase 2) is done with the LDS
+        for (int i = 0; i < 2; ++i) {
+            f32x4_e sc[4], bi[4];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int pl = wp * 64 + jj * 32 + r;   // pixel inside the round
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c4 = ch0 + wc * 64 + 32 * i + 8 * g4 + 4 * hh;
+                sc[g4] = a.scale ? *(const f32x4_e*)(a.scale + c4) : f32x4_e{1.f, 1.f, 1.f, 1.f};
+                bi[g4] = a.bias ? *(const f32x4_e*)(a.bias + c4) : f32x4_e{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = q >> 2, g4 = q & 3;
-                f32x4_e v;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int pl = wp * 64 + jj * 32 + r;   // pixel inside the round
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][2 * rr + jj][4 * g4 + e] * sc[q][e] + bi[q][e];
-                const int cq = wc * 16 + 8 * i + 2 * g4 + hh;
-                *(f32x4_e*)(lds + pl * 512 + ((cq ^ (pl & 31)) << 4)) = v;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4_e v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][2 * rr + jj][4 * g4 + e] * sc[g4][e] + bi[g4][e];
+                    const int cq = wc * 16 + 8 * i + 2 * g4 + hh;
+                    *(f32x4_e*)(lds + pl * 512 + ((cq ^ (pl & 31)) << 4)) = v;
+                }
             }
         }
-        __syncthreads();
+        if (rr + 1 < NR) { BMI_EPI_FETCH(rr + 1); }
+        lds_barrier();
         // phase 2: 128 pixels x 16 groups of 8 channels = 2048 items, 8 per thread
-        half8_e resv[8];
-        int pn[8], prem[8];   // image index (-1: tile pixel beyond the tensor) and y*Wo+x
-        const int k = tid & 15;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int pl = (tid >> 4) + 16 * it;
-            const int p = (pl >> 6) * (32 * TJ) + rr * 64 + (pl & 63);   // pixel inside the workgroup tile
-            int n, rem;
-            const bool okp = pixmap(p, n, rem);
-            pn[it] = okp ? n : -1;
-            prem[it] = rem;
-            if (okp && a.res)
-                resv[it] = *(const half8_e*)(a.res + ((size_t)(n % a.res_mod) * (a.Ho * a.Wo) + rem) * a.Cout + ch0 + 8 * k);
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            if (pn[it] < 0) continue;
+            if (pn[rr][it] < 0) continue;
             const int pl = (tid >> 4) + 16 * it;
             const int s = pl & 31;
-            const PixelCtx px = make_pixel_ctx(a, pn[it], prem[it]);
+            const PixelCtx px = make_pixel_ctx(a, pn[rr][it], prem[rr][it]);
             const f32x4_e lo = *(const f32x4_e*)(lds + pl * 512 + (((2 * k) ^ s) << 4));
             const f32x4_e hi = *(const f32x4_e*)(lds + pl * 512 + (((2 * k + 1) ^ s) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const int c8 = ch0 + 8 * k;
             if (px.resp) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)resv[it][e];
+                for (int e = 0; e < 8; ++e) v[e] += (float)resv[rr][it][e];
             }
             if (a.relu) {
 #pragma unroll
@@ -176,3 +192,4 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
         }
     }
 }
+#undef BMI_EPI_FETCH

@@ -17,6 +17,8 @@
 // Philox, channel dropout, or Masksembles channel mask), fp16 store.
 // Reference semantics: BasicBlock.forward SA/models/resnet18/resnet18.py:32-48, exit-head convs
 // :306-308/:318-319/:329, MCDropout :207-210, Masksembles2D SA/utils.py:165-169.
+#include <cstdlib>
+
 #include "conv_epilogue.h"
 #include "kernels.h"
 
@@ -28,14 +30,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BC, int BP, int WC, int WP>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+template <int BC, int BP, int WC, int WP, bool DBUF>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TI = BC / WC / 32;   // 32x32 MFMA tiles per wave along channels
     constexpr int TJ = BP / WP / 32;   // ... along pixels
     constexpr int WROWS = BC / 32;     // weight rows staged per thread
     constexpr int XROWS = BP / 32;     // pixel rows staged per thread
     constexpr int TILE = (BC + BP) * 128;
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+    constexpr int MAIN_BYTES = (DBUF ? 2 : 1) * TILE;
+    constexpr int LDS_BYTES = (BC == 128 && MAIN_BYTES < BMI_EPILOGUE_LDS_BYTES) ? BMI_EPILOGUE_LDS_BYTES : MAIN_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -112,16 +116,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int nK = a.ksize * a.ksize * (a.Cin / BK);
     int ky = 0, kx = 0, c0 = 0;
     GLOAD(ky, kx, c0);
-    LSTORE(0);
-    __syncthreads();
+    if constexpr (DBUF) {
+        LSTORE(0);
+        __syncthreads();
+    }
 
     const int sw_r = (r >> 1) & 7;
     const int a_row0 = wc * (BC / WC) + r;
     const int b_row0 = wp * (BP / WP) + r;
 
     for (int ks = 0; ks < nK; ++ks) {
-        const int buf = ks & 1;
+        const int buf = DBUF ? (ks & 1) : 0;
         const bool more = ks + 1 < nK;
+        if constexpr (!DBUF) {
+            LSTORE(0);          // single buffer: registers -> LDS, then prefetch the next step into registers
+            __syncthreads();
+        }
         if (more) {
             c0 += BK;
             if (c0 == a.Cin) {
@@ -146,14 +156,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (more) LSTORE(buf ^ 1);
+        if constexpr (DBUF) {
+            if (more) LSTORE(buf ^ 1);
+        }
         __syncthreads();
     }
 
 #undef GLOAD
 #undef LSTORE
     // ---- epilogue ---------------------------------------------------------------------------
-    if constexpr (BC == 128 && BP == 128 && WC == 2 && WP == 2) {
+    if constexpr (BC == 128 && WC == 2 && WP == 2) {
         // coalesced through LDS (conv_epilogue.h); the double buffer is exactly the 64 KB it needs
         auto pixmap = [&](int p, int& n, int& rem) -> bool {
             const int m = pix0 + p;
@@ -184,13 +196,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
-template <int BC, int BP, int WC, int WP>
+template <int BC, int BP, int WC, int WP, bool DBUF>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int n_ctiles = a.Cout / BC;
     const long n_ptiles = ((long)a.M + BP - 1) / BP;
     const long blocks = n_ptiles * n_ctiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -199,6 +211,11 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.Cin % BK != 0 || a.Cout % 64 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
     if (a.res && a.res_mod <= 0) return BMI_ERR_INVALID;
-    if (a.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2>(a, s);
-    return launch_cfg<64, 128, 1, 4>(a, s);
+    static const int big = [] { const char* v = std::getenv("BMI_IGEMM_BP256"); return v ? std::atoi(v) : 1; }();
+    if (a.Cout % 128 == 0) {
+        // 256-pixel tiles (single LDS buffer, 2 barriers per K-step) halve the weight-tile traffic per FLOP
+        if (big && (long)(a.M / 256) * (a.Cout / 128) >= 400 && a.ksize == 3) return launch_cfg<128, 256, 2, 2, false>(a, s);
+        return launch_cfg<128, 128, 2, 2, true>(a, s);
+    }
+    return launch_cfg<64, 128, 1, 4, true>(a, s);
 }
