@@ -29,13 +29,33 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef BMI_PATCH_STAMPS
+// Diagnostic build only (tools/ab_build.py stamps:-DBMI_PATCH_STAMPS): per-workgroup phase timestamps of
+// wave 0, read back with bmi_debug_stamps().  No stamp executes in the product build.
+__device__ unsigned long long g_stamps[8192 * 8];
+#define STAMP(SLOT)                                                                                  \
+    if (tid == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (SLOT)] = __builtin_readcyclecounter();
+#define STAMP_ADD(SLOT, T0)                                                                          \
+    if (tid == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (SLOT)] += __builtin_readcyclecounter() - (T0);
+extern "C" int bmi_debug_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}
+extern "C" int bmi_debug_stamps_clear() {
+    static unsigned long long z[8192 * 8];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) == hipSuccess ? 0 : -5;
+}
+#else
+#define STAMP(SLOT)
+#define STAMP_ADD(SLOT, T0)
+#endif
+
 __device__ unsigned int g_zero_page[64];  // 256 B of zeros: DMA source for padding / halo / tail cells
 
 #define GLDS16(SRC, LDSPTR)                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),       \
                                      (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
 
-template <int S, int TH, int TW, int IMGS, int TJ>
+template <int S, int TH, int TW, int IMGS, int TJ, int NB = 2>
 struct PatchGeom {
     static constexpr int BC = 128, TI = 2;
     static constexpr int BP = IMGS * TH * TW;
@@ -49,27 +69,32 @@ struct PatchGeom {
     static constexpr int ITER_P = (PIECES + 255) / 256;
     static constexpr int PATCH_BYTES = ITER_P * 256 * 16;
     static constexpr int WTILE = BC * 128;
-    static constexpr int MAIN_BYTES = PATCH_BYTES + 2 * WTILE;
+    static constexpr int MAIN_BYTES = PATCH_BYTES + NB * WTILE;
     static constexpr int LDS_BYTES = MAIN_BYTES > BMI_EPILOGUE_LDS_BYTES ? MAIN_BYTES : BMI_EPILOGUE_LDS_BYTES;
 };
 
 #ifndef BMI_PATCH_WDMA
 #define BMI_PATCH_WDMA 1
 #endif
+#ifndef BMI_PATCH_NB_S3
+#define BMI_PATCH_NB_S3 2
+#endif
 #ifndef BMI_PATCH_SWPIPE
-#define BMI_PATCH_SWPIPE 1
+#define BMI_PATCH_SWPIPE 0
 #endif
 
-template <int S, int TH, int TW, int IMGS, int TJ>
+template <int S, int TH, int TW, int IMGS, int TJ, int NB>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     constexpr bool WDMA = BMI_PATCH_WDMA != 0;
-    using G = PatchGeom<S, TH, TW, IMGS, TJ>;
+    static_assert(NB == 2 || WDMA, "deeper weight prefetch is implemented for the LDS-DMA path");
+    using G = PatchGeom<S, TH, TW, IMGS, TJ, NB>;
     constexpr int BC = G::BC, TI = G::TI, PH = G::PH, PW = G::PW, PWP = G::PWP, HALF = G::HALF, KA = G::KA;
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     char* const patch = smem;
     char* const wbuf = smem + G::PATCH_BYTES;
 
     const int tid = threadIdx.x;
+    STAMP(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -106,8 +131,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         const bool ok = cell < G::CELLS && px < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         psrc[i] = ok ? (int)((((size_t)(n % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + c * 8) : -1;
     }
-    // weight tile, two build-time variants (BMI_PATCH_WDMA): LDS-DMA one K-step ahead (default:
-    // measured 3-10 % faster on S2/S3/S4) or register-staged (global_load -> ds_write_b128).
+    // weight tile, build-time variants (same-box A/B on S2/S3/S4, tools/ab_run.sh): LDS-DMA one K-step
+    // ahead with plain per-substep fragment reads is the default (910 TF/s); register staging
+    // (BMI_PATCH_WDMA=0) -10 %, hand-pipelined fragment reads (BMI_PATCH_SWPIPE=1) -3 %, a third
+    // weight buffer with counted vmcnt (NB=3) -4 % on S3: per-phase stamps (tools/stamps.py) show the
+    // weight-DMA wait is only ~70 cycles per K-step; the losses are the ~680-cycle barrier skew per
+    // K-step and the prologue / epilogue phases.
     const int w_row = tid >> 3;
     const int w_sw = (w_row >> 1) & 7;
     const _Float16* wsrc = a.wgt + (size_t)(ch0 + w_row) * Ktot + (WDMA ? ((tid & 7) ^ w_sw) : (tid & 7)) * 8;
@@ -160,20 +189,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nchunks = a.Cin / 64;
+    const int nK = 9 * nchunks;
+    // K-step s = chunk * 9 + tap uses weight buffer s % NB.  The weight tiles of steps s+1 .. s+NB-1
+    // are in flight while step s computes (L2 latency under load is about one whole K-step, so
+    // NB = 3 keeps two tiles in flight and waits with a COUNTED vmcnt).
+    auto w_koff = [&](int st) { const int c = st / 9, t = st - 9 * c; return t * a.Cin + c * 64; };
     ISSUE_PATCH(0);
     LOAD_W(0, 0);
     STORE_W(0);
+    if constexpr (NB == 3) {
+        if (nK > 1) LOAD_W(w_koff(1), 1);
+    }
     int step = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < 9; ++tap, ++step) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();   // patch landed, W[step&1] written; every wave is done with W[(step+1)&1]
-            const int buf = step & 1;
-            const bool more = tap < 8 || chunk + 1 < nchunks;
-            if (more) {
-                const int koff = tap < 8 ? (tap + 1) * a.Cin + chunk * 64 : (chunk + 1) * 64;
-                LOAD_W(koff, buf ^ 1);
+            const int buf = step % NB;
+            if constexpr (NB == 3) {
+                // all but the youngest weight tile (4 DMA instructions per wave) must have landed;
+                // at a chunk start the patch DMA (issued last) must have landed too
+                if (tap == 0 || step + 1 >= nK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                lds_barrier();
+                if (step + 2 < nK) LOAD_W(w_koff(step + 2), (step + 2) % NB);
+            } else {
+#ifdef BMI_PATCH_STAMPS
+                const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP_ADD(4, tw0);
+                __syncthreads();   // patch landed, W[step&1] written; every wave is done with W[(step+1)&1]
+                STAMP_ADD(5, tw0);
+                if (step == 0) { STAMP(1); }
+                if (step + 1 < nK) LOAD_W(w_koff(step + 1), buf ^ 1);
             }
+            const bool more = step + 1 < nK;
             const int ky = tap / 3, kx = tap - 3 * ky;
             // per-tap cell shift and swizzle key shift
             int coff, koff;
@@ -244,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #endif
             if (more) STORE_W(buf ^ 1);
             if (tap == 8 && chunk + 1 < nchunks) {
-                __syncthreads();                 // every wave is done reading this chunk's patch
+                lds_barrier();                 // every wave is done reading this chunk's patch
                 ISSUE_PATCH((chunk + 1) * 64);
             }
         }
@@ -253,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #undef LOAD_W
 #undef STORE_W
 
+    STAMP(2);
     // ---- epilogue (coalesced through LDS) ----------------------------------------------------------
     auto pixmap = [&](int p, int& n, int& rem) -> bool {
         const int img = p / (TH * TW), q = p - img * (TH * TW);
@@ -262,13 +312,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         return n < a.N;
     };
     epilogue_coalesced<TJ>(a, acc, smem, tid, ch0, pixmap);
+    STAMP(3);
 }
 
-template <int S, int TH, int TW, int IMGS, int TJ>
+template <int S, int TH, int TW, int IMGS, int TJ, int NB = 2>
 static int launch_patch(const ConvArgs& a, hipStream_t s) {
     const long tiles = (long)((a.N + IMGS - 1) / IMGS) * (a.Ho / TH) * (a.Wo / TW) * (a.Cout / 128);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<S, TH, TW, IMGS, TJ>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<S, TH, TW, IMGS, TJ, NB>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -280,7 +331,7 @@ int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s) {
     if ((size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets
     if (a.stride == 1) {
         if (a.Ho == 16 && a.Wo == 16) return launch_patch<1, 16, 16, 1, 4>(a, s);
-        if (a.Ho == 8 && a.Wo == 8) return launch_patch<1, 8, 8, 2, 2>(a, s);
+        if (a.Ho == 8 && a.Wo == 8) return launch_patch<1, 8, 8, 2, 2, BMI_PATCH_NB_S3>(a, s);
         if (a.Ho == 4 && a.Wo == 4) return launch_patch<1, 4, 4, 8, 2>(a, s);
         if (a.Ho % 8 == 0 && a.Wo == 32) return launch_patch<1, 8, 32, 1, 4>(a, s);
     }

@@ -4,7 +4,7 @@ usage: python tools/ab_build.py name1:-DFOO=1,-DBAR=0 name2: ..."""
 import os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesnn_fpga_amd import _build
-out = os.path.join(os.path.dirname(_build.HERE), "gpurun_out", "variants")
+out = os.path.join(_build.CSRC, "build", "variants")   # in-tree: gpurun ships it (gpurun_out/ is NOT shipped)
 os.makedirs(out, exist_ok=True)
 base = list(_build.FLAGS)
 for spec in sys.argv[1:]:
