@@ -29,7 +29,7 @@ class TensorDesc(C.Structure):
 class OpDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_", C.c_int32), ("out", C.c_int32), ("residual", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32),
-                ("weight", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site)]
+                ("weight", C.c_void_p), ("weight_packed", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site)]
 
 
 class ModelDesc(C.Structure):
@@ -61,7 +61,8 @@ _PROTOS = {
     "bmi_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bmi_philox_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "bmi_stem_conv_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 9 + [C.c_void_p]),
-    "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
+    "bmi_pack_conv3x3_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
                                                                          C.c_uint64, C.c_int32, C.c_void_p]),
     "bmi_mask_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
                                  C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),

@@ -120,31 +120,26 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
             resv[RR][it] = *(const half8_e*)(a.res + ((size_t)(n_ % a.res_mod) * (a.Ho * a.Wo) + rem_) * a.Cout + ch0 + 8 * k); \
     }
     BMI_EPI_FETCH(0);
+    // folded-BN scale / bias of the 8 channels this thread finishes in phase 2
+    f32x4_e sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, bi0 = {0.f, 0.f, 0.f, 0.f}, bi1 = bi0;
+    if (a.scale) { sc0 = *(const f32x4_e*)(a.scale + ch0 + 8 * k); sc1 = *(const f32x4_e*)(a.scale + ch0 + 8 * k + 4); }
+    if (a.bias) { bi0 = *(const f32x4_e*)(a.bias + ch0 + 8 * k); bi1 = *(const f32x4_e*)(a.bias + ch0 + 8 * k + 4); }
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         lds_barrier();   // main loop (or previous round's phase 2) is done with the LDS
-        // phase 1: BN scale / bias, then fp32 rows into the swizzled LDS tile.  The BN vectors are
-        // fetched per half (4 channel quads = 32 VGPRs) so the kernel stays under 256 VGPRs.
+        // phase 1: raw fp32 accumulators into the swizzled LDS tile (BN is applied in phase 2, where
+        // a thread owns the same 8 channels for all its rows, so the BN vectors are loaded once)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4_e sc[4], bi[4];
+        for (int jj = 0; jj < 2; ++jj) {
+            const int pl = wp * 64 + jj * 32 + r;   // pixel inside the round
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c4 = ch0 + wc * 64 + 32 * i + 8 * g4 + 4 * hh;
-                sc[g4] = a.scale ? *(const f32x4_e*)(a.scale + c4) : f32x4_e{1.f, 1.f, 1.f, 1.f};
-                bi[g4] = a.bias ? *(const f32x4_e*)(a.bias + c4) : f32x4_e{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int q = 0; q < 8; ++q) {
+                const int i = q >> 2, g4 = q & 3;
+                f32x4_e v;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int pl = wp * 64 + jj * 32 + r;   // pixel inside the round
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f32x4_e v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][2 * rr + jj][4 * g4 + e] * sc[g4][e] + bi[g4][e];
-                    const int cq = wc * 16 + 8 * i + 2 * g4 + hh;
-                    *(f32x4_e*)(lds + pl * 512 + ((cq ^ (pl & 31)) << 4)) = v;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][2 * rr + jj][4 * g4 + e];
+                const int cq = wc * 16 + 8 * i + 2 * g4 + hh;
+                *(f32x4_e*)(lds + pl * 512 + ((cq ^ (pl & 31)) << 4)) = v;
             }
         }
         if (rr + 1 < NR) { BMI_EPI_FETCH(rr + 1); }
@@ -158,7 +153,9 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
             const PixelCtx px = make_pixel_ctx(a, pn[rr][it], prem[rr][it]);
             const f32x4_e lo = *(const f32x4_e*)(lds + pl * 512 + (((2 * k) ^ s) << 4));
             const f32x4_e hi = *(const f32x4_e*)(lds + pl * 512 + (((2 * k + 1) ^ s) << 4));
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e] * sc0[e] + bi0[e]; v[4 + e] = hi[e] * sc1[e] + bi1[e]; }
             const int c8 = ch0 + 8 * k;
             if (px.resp) {
 #pragma unroll

@@ -78,14 +78,22 @@ SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
     return s;
 }
 
-// Kernel selection for one conv launch.  BMI_CONV_IMPL=igemm forces the per-tap implicit GEMM
-// (used by the parity tests to cover both kernels).
+// Kernel selection for one conv launch: LDS-tile 3x3 patch kernel -> per-tap implicit GEMM.
+// BMI_CONV_IMPL=igemm skips the patch kernel, BMI_CONV_IMPL=wreg tries the experimental
+// register-weight kernel first (it needs packed weights; same-box A/B: 12-20 % slower than the
+// patch kernel because the two pixel-waves of a workgroup each stream the same weights from L2).
 int launch_conv(const ConvArgs& a, hipStream_t s) {
-    static const int force_igemm = [] {
+    static const int mode = [] {
         const char* v = std::getenv("BMI_CONV_IMPL");
-        return (v && std::strcmp(v, "igemm") == 0) ? 1 : 0;
+        if (v && std::strcmp(v, "igemm") == 0) return 2;
+        if (v && std::strcmp(v, "wreg") == 0) return 0;
+        return 1;
     }();
-    if (!force_igemm) {
+    if (mode == 0) {
+        const int rc = launch_conv3x3_wreg(a, s);
+        if (rc != BMI_ERR_UNSUPPORTED) return rc;
+    }
+    if (mode <= 1) {
         const int rc = launch_conv3x3_patch(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
@@ -370,6 +378,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             std::memset(&a, 0, sizeof(a));
             a.in = (const _Float16*)(ws + tin.offset);
             a.wgt = (const _Float16*)d.weight;
+            a.wpk = (const _Float16*)d.weight_packed;
             a.scale = d.scale; a.bias = d.bias;
             a.out = (_Float16*)(ws + e->tensors[d.out].offset);
             a.N = N;
@@ -491,7 +500,12 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
                             (hipStream_t)stream);
 }
 
-int bmi_conv_igemm_fwd(const void* in, const void* weight, const float* scale, const float* bias, const void* res,
+int bmi_pack_conv3x3_weights(const void* weight, void* packed, int32_t cout, int32_t cin, bmi_stream stream) {
+    if (!weight || !packed) return BMI_ERR_INVALID;
+    return launch_pack_conv3x3_weights((const _Float16*)weight, (_Float16*)packed, cout, cin, (hipStream_t)stream);
+}
+
+int bmi_conv_igemm_fwd(const void* in, const void* weight, const void* weight_packed, const float* scale, const float* bias, const void* res,
                        void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
                        int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
@@ -499,7 +513,7 @@ int bmi_conv_igemm_fwd(const void* in, const void* weight, const float* scale, c
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.scale = scale; a.bias = bias;
+    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.wpk = (const _Float16*)weight_packed; a.scale = scale; a.bias = bias;
     a.res = (const _Float16*)res; a.out = (_Float16*)out;
     a.N = n; a.in_mod = in_mod; a.res_mod = res_mod;
     a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;

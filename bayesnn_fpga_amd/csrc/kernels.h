@@ -9,6 +9,7 @@
 struct ConvArgs {
     const _Float16* in;
     const _Float16* wgt;  // [Cout][k*k*Cin]
+    const _Float16* wpk;  // same weights in MFMA A-fragment order (conv3x3_wreg.hip), or null
     const float* scale;   // may be null
     const float* bias;    // may be null
     const _Float16* res;  // may be null
@@ -36,6 +37,8 @@ struct EltArgs {  // MASK / POOL ops
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
+int launch_conv3x3_wreg(const ConvArgs& a, hipStream_t s);    // needs a.wpk; BMI_ERR_UNSUPPORTED -> next kernel
+int launch_pack_conv3x3_weights(const _Float16* w, _Float16* out, int cout, int cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, hipStream_t s);           // picks the kernel
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s);

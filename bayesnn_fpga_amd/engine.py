@@ -13,6 +13,7 @@ path runs in ``libbayesnn_fpga_amd.so``.  What this replaces in the reference:
                            per-exit softmax, float64 mean over T (+ build-defined variance).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -79,9 +80,19 @@ class GraphBuilder:
             scale = torch.ones(conv.out_channels)
             bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels)
         wk = conv.weight.detach().permute(0, 2, 3, 1)          # [Cout][ky][kx][Cin]
+        wdev = self.dev(wk, torch.float32 if stem else torch.float16)
+        packed = None
+        if (not stem and k == 3 and p == 1 and cin % 64 == 0 and conv.out_channels % 128 == 0
+                and torch.device(self.device).type == "cuda" and os.environ.get("BMI_CONV_IMPL") == "wreg"):
+            # one-off re-layout into MFMA fragment order for the register-weight kernel
+            packed = torch.empty_like(wdev)
+            self.keep.append(packed)
+            with torch.cuda.device(self.device):
+                st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                _lib.check(_lib.lib().bmi_pack_conv3x3_weights(wdev.data_ptr(), packed.data_ptr(), conv.out_channels, cin, st),
+                           "bmi_pack_conv3x3_weights")
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
-                             stride=s, pad=p, relu=int(relu),
-                             weight=self.dev(wk, torch.float32 if stem else torch.float16),
+                             stride=s, pad=p, relu=int(relu), weight=wdev, weight_packed=packed,
                              scale=self.dev(scale, torch.float32), bias=self.dev(bias, torch.float32), site=site))
         return out
 
@@ -202,7 +213,7 @@ class CompiledGraph:
             d = oarr[i]
             d.kind, d.in_, d.out, d.residual = op["kind"], op["in_"], op["out"], op.get("residual", -1)
             d.ksize, d.stride, d.pad, d.relu = op.get("ksize", 0), op.get("stride", 0), op.get("pad", 0), op.get("relu", 0)
-            for f in ("weight", "scale", "bias"):
+            for f in ("weight", "weight_packed", "scale", "bias"):
                 t = op.get(f)
                 setattr(d, f, t.data_ptr() if t is not None else None)
             s = op.get("site")

@@ -22,6 +22,7 @@
  *                              the counter-based Philox convention of csrc/philox.h
  *   bmi_stem_conv_fwd, bmi_conv_igemm_fwd   conv+BN(+residual)(+ReLU) of BasicBlock.forward
  *                              (resnet18.py:32-48) and of the exit heads (:306-308,:318-319,:329)
+ *   bmi_pack_conv3x3_weights   (no reference counterpart: one-off re-layout of conv weights at load time)
  *   bmi_mask_apply             MCDropout / Masksembles2D on a stage output (:278-280)
  *   bmi_pool_mask              F.avg_pool2d(F.relu(.),4) + flatten + exit dropout (:309-313)
  *   bmi_linear_softmax         ex{1,2,3}linear / linear (:314,:325,:335,:344) + softmax
@@ -94,6 +95,8 @@ typedef struct bmi_op_desc {
     int32_t relu;      /* apply ReLU after scale/bias(+residual)                       */
     const void* weight;  /* device; CONV fp16 [Cout][k][k][Cin]; STEM fp32 [Cout][k][k][Cin];
                             HEAD fp32 [ceil32(out_dim)][Cin]                           */
+    const void* weight_packed; /* CONV 3x3: the same weights repacked by bmi_pack_conv3x3_weights
+                                  (MFMA fragment order), or NULL to run the LDS-tile kernels */
     const float* scale;  /* device fp32 [Cout] folded BN scale (NULL = 1)              */
     const float* bias;   /* device fp32 [Cout] folded BN bias / Linear bias            */
     bmi_site site;       /* CONV/STEM/MASK: applied to the op's output; HEAD: applied to
@@ -155,7 +158,11 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
 
 /* out[n] = conv(in[n % in_mod]) * scale + bias (+ res[n % res_mod]) (ReLU) (site); `batch` is
  * the per-sample image count B used by the site's element index (n = t_local*B + b). */
-int bmi_conv_igemm_fwd(const void* in, const void* weight, const float* scale, const float* bias, const void* res,
+/* fp16 [Cout][3][3][Cin] -> the fragment-ordered copy the register-weight 3x3 kernel streams
+ * (Cout % 128 == 0, Cin % 64 == 0; same byte size). */
+int bmi_pack_conv3x3_weights(const void* weight, void* packed, int32_t cout, int32_t cin, bmi_stream stream);
+
+int bmi_conv_igemm_fwd(const void* in, const void* weight, const void* weight_packed, const float* scale, const float* bias, const void* res,
                        void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
                        int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);

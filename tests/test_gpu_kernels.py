@@ -109,7 +109,7 @@ def test_conv_rejects_unsupported_shapes():
     x = torch.zeros(1, 8, 8, 48, dtype=torch.float16, device=DEV)
     w = torch.zeros(64, 3, 3, 48, dtype=torch.float16, device=DEV)
     o = torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=DEV)
-    rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), gh.ptr(w), None, None, None, gh.ptr(o), 1, 1, 1, 8, 8, 48, 64, 3, 1, 1, 0, None, 1,
+    rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), gh.ptr(w), None, None, None, None, gh.ptr(o), 1, 1, 1, 8, 8, 48, 64, 3, 1, 1, 0, None, 1,
                                 0, 0, 0, gh.stream())
     assert rc == -95
 

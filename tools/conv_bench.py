@@ -49,10 +49,14 @@ def main():
         bias = (0.1 * torch.randn(cout, generator=g)).to(dev)
         res = torch.randn(n, ho, ho, cout, generator=g).to(torch.float16).to(dev)
         out = torch.empty(n, ho, ho, cout, dtype=torch.float16, device=dev)
+        wp = None
+        if k == 3 and p == 1 and cin % 64 == 0 and cout % 128 == 0:
+            wp = torch.empty_like(w)
+            _lib.check(lib.bmi_pack_conv3x3_weights(w.data_ptr(), wp.data_ptr(), cout, cin, st), "pack")
         site = _lib.make_site(_lib.SITE_ELEMENTWISE, 2, 0.25) if a.site else None
 
         def run():
-            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), w.data_ptr(), None if a.noscale else scale.data_ptr(),
+            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), w.data_ptr(), wp.data_ptr() if wp is not None else None, None if a.noscale else scale.data_ptr(),
                                         None if a.noscale else bias.data_ptr(), None if a.nores else res.data_ptr(),
                                         out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1,
                                         C.byref(site) if site is not None else None, 250, 0, 42, 0, st)
