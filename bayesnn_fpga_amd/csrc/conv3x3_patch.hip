@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     // ---- tile coordinates (channel tile fastest) ------------------------------------------------
     const int n_ctiles = a.Cout / BC;
     const int tiles_x = a.Wo / TW, tiles_y = a.Ho / TH;
-    int bid = blockIdx.x;
-    const int ctile = bid % n_ctiles; bid /= n_ctiles;
+    int bid, ctile;
+    xcd_tile_map(blockIdx.x, (int)(gridDim.x / n_ctiles), n_ctiles, bid, ctile);
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int n0 = (bid / tiles_y) * IMGS;

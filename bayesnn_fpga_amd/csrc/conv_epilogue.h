@@ -8,6 +8,26 @@
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+// XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
+// each with its own L2), so the n_ct channel tiles that share ONE pixel tile must get block ids
+// that are congruent mod 8, or every XCD fetches that pixel tile's input again from beyond its L2
+// (measured: FETCH_SIZE 3.3-3.8x the algorithmic input bytes at Cout = 512).  Within a group of
+// 8 * n_ct consecutive blocks, block j takes pixel tile (j % 8) of the group and channel tile j / 8.
+// Placement only changes speed, never results; the tail group falls back to the plain order.
+__device__ __forceinline__ void xcd_tile_map(int bid, int n_pt, int n_ct, int& ptile, int& ctile) {
+    const int group = 8 * n_ct;
+    const int full = (n_pt / 8) * group;
+    if (bid < full) {
+        const int g = bid / group, j = bid - g * group;
+        ptile = g * 8 + (j & 7);
+        ctile = j >> 3;
+    } else {
+        const int t = bid - full;
+        ptile = (n_pt / 8) * 8 + t / n_ct;
+        ctile = t % n_ct;
+    }
+}
+
 struct PixelCtx {
     size_t out_off;        // element offset of this pixel's channel 0 in the output tensor
     const _Float16* resp;  // residual row or nullptr

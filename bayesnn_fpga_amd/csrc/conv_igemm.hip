@@ -46,11 +46,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int r = lane & 31, hh = lane >> 5;
     const int wc = wave / WP, wp = wave % WP;
 
-    // blockIdx.x walks channel tiles fastest so that the blocks sharing one pixel tile are
-    // adjacent in dispatch order.
     const int n_ctiles = a.Cout / BC;
-    const int ctile = blockIdx.x % n_ctiles;
-    const int ptile = blockIdx.x / n_ctiles;
+    int ptile, ctile;
+    xcd_tile_map(blockIdx.x, (a.M + BP - 1) / BP, n_ctiles, ptile, ctile);
     const int ch0 = ctile * BC;
     const int pix0 = ptile * BP;
 
