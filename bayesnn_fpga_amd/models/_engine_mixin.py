@@ -1,0 +1,62 @@
+"""Engine plumbing shared by the model mirrors: the compiled-engine cache, the Monte-Carlo stream
+state, and ``forward`` = ONE stochastic pass on the GPU (there is no CPU forward)."""
+import torch
+from torch import nn
+
+from ..utils import Masksembles1D, Masksembles2D
+
+
+class EngineModelMixin:
+    def _init_engine_state(self):
+        self.mc_seed = 0      # Philox key of the Monte-Carlo stream (csrc/philox.h)
+        self.mc_pass = 0      # global sample index t of the next forward
+        self._engines = {}
+
+    def _apply(self, fn, *a, **k):
+        self._engines = {}          # parameters moved / cast: compiled weights are stale
+        return nn.Module._apply(self, fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engines = {}
+        return nn.Module.load_state_dict(self, *a, **k)
+
+    def invalidate_engine(self):
+        self._engines = {}
+
+    def engine(self, device, max_batch=None, chunk_samples=None):
+        """The compiled HIP engine for ``device`` (built on first use, rebuilt when it must grow)."""
+        from ..engine import MCDEngine
+        key = str(device)
+        eng = self._engines.get(key)
+        need_b = max_batch or 1
+        if eng is None or eng.max_batch < need_b or (chunk_samples and eng.chunk_samples != chunk_samples):
+            eng = MCDEngine(self, device, max_batch=max(need_b, eng.max_batch if eng else 0),
+                            chunk_samples=chunk_samples or (eng.chunk_samples if eng else None))
+            self._engines[key] = eng
+        return eng
+
+    def mask_layers(self):
+        return [m for m in self.modules() if isinstance(m, (Masksembles1D, Masksembles2D))]
+
+    def advance(self, passes):
+        """Bookkeeping after ``passes`` stochastic forwards: MC pass index and every Masksembles
+        layer's ``cnt`` (they move in lock-step, SA/utils.py:168,230)."""
+        self.mc_pass += passes
+        for m in self.mask_layers():
+            m.cnt = (m.cnt + passes) % m.n
+
+    def mask_cnt0(self):
+        """Masksembles counter value that corresponds to MC sample t = 0 of the current stream: the
+        engine selects mask (cnt0 + t) mod M for global sample index t (so t-shards on different
+        GPUs agree), and sample ``mc_pass`` must see the layer's current ``cnt``."""
+        ml = self.mask_layers()
+        return (ml[0].cnt - self.mc_pass) % ml[0].n if ml else 0
+
+    def forward(self, x):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise RuntimeError("bayesnn_fpga_amd models run on an MI355X through the HIP engine; got a CPU tensor "
+                               "(there is no CPU fallback)")
+        eng = self.engine(x.device, max_batch=x.shape[0])
+        out = eng.forward_once(x, seed=self.mc_seed, t=self.mc_pass, cnt0=self.mask_cnt0())
+        self.advance(1)
+        return out

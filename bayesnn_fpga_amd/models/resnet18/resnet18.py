@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from ...utils import Masksembles1D, Masksembles2D
+from .._engine_mixin import EngineModelMixin
 
 _STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))           # (planes, first-block stride)
 _EXIT_CONVS = {1: ((64, 128), (128, 256), (256, 512)), 2: ((128, 256), (256, 512)), 3: ((256, 512),)}
@@ -48,7 +49,7 @@ class BasicBlock(nn.Module):
     forward = _no_cpu
 
 
-class ResNet(nn.Module):
+class ResNet(EngineModelMixin, nn.Module):
     family = "resnet"
     multi_exit = True
 
@@ -76,10 +77,7 @@ class ResNet(nn.Module):
             elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
-        # Monte-Carlo stream state (engine-side RNG: csrc/philox.h)
-        self.mc_seed = 0
-        self.mc_pass = 0
-        self._engines = {}
+        self._init_engine_state()
 
     def _make_layer(self, block, planes, blocks, stride):
         down = None
@@ -90,56 +88,6 @@ class ResNet(nn.Module):
         self.inplanes = planes * block.expansion
         seq += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*seq)
-
-    # ---- engine plumbing -----------------------------------------------------------------
-    def _apply(self, fn, *a, **k):
-        self._engines = {}          # parameters moved / cast: compiled weights are stale
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._engines = {}
-        return super().load_state_dict(*a, **k)
-
-    def invalidate_engine(self):
-        self._engines = {}
-
-    def engine(self, device, max_batch=None, chunk_samples=None):
-        """The compiled HIP engine for ``device`` (built on first use, rebuilt when it must grow)."""
-        from ...engine import MCDEngine
-        key = str(device)
-        eng = self._engines.get(key)
-        need_b = max_batch or 1
-        if eng is None or eng.max_batch < need_b or (chunk_samples and eng.chunk_samples != chunk_samples):
-            eng = MCDEngine(self, device, max_batch=max(need_b, eng.max_batch if eng else 0),
-                            chunk_samples=chunk_samples or (eng.chunk_samples if eng else None))
-            self._engines[key] = eng
-        return eng
-
-    def mask_layers(self):
-        return [m for m in self.modules() if isinstance(m, (Masksembles1D, Masksembles2D))]
-
-    def advance(self, passes):
-        """Bookkeeping after ``passes`` stochastic forwards: MC pass index and every Masksembles
-        layer's ``cnt`` (they move in lock-step, SA/utils.py:168,230)."""
-        self.mc_pass += passes
-        for m in self.mask_layers():
-            m.cnt = (m.cnt + passes) % m.n
-
-    def mask_cnt0(self):
-        """Masksembles counter value that corresponds to MC sample t = 0 of the current stream: the
-        engine selects mask (cnt0 + t) mod M for global sample index t (so t-shards on different
-        GPUs agree), and sample ``mc_pass`` must see the layer's current ``cnt``."""
-        ml = self.mask_layers()
-        return (ml[0].cnt - self.mc_pass) % ml[0].n if ml else 0
-
-    def forward(self, x):
-        if not (isinstance(x, torch.Tensor) and x.is_cuda):
-            raise RuntimeError("bayesnn_fpga_amd models run on an MI355X through the HIP engine; got a CPU tensor "
-                               "(there is no CPU fallback)")
-        eng = self.engine(x.device, max_batch=x.shape[0])
-        out = eng.forward_once(x, seed=self.mc_seed, t=self.mc_pass, cnt0=self.mask_cnt0())
-        self.advance(1)
-        return out
 
 
 class ResNet18EarlyExit(ResNet):

@@ -179,6 +179,47 @@ def gen_resnet():
     print("factory", type(net).__name__)
 
 
+VGG_CASES = {
+    "exit_mc": (dict(dropout_exit=True, dropout=None, dropout_p=0.25, out_dim=100, n_exits=5), 2, 4),
+    "exit_mask4": (dict(dropout_exit=True, dropout=None, mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=10,
+                        n_exits=5), 2, 6),
+}
+
+
+def gen_vgg():
+    from models.vgg19.vgg19 import VGG19MCEarlyExit, VGG19MC
+    for name, (kw, B, T) in VGG_CASES.items():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model = VGG19MCEarlyExit(**kw)
+        init_sum = state_checksum(model.state_dict())
+        synthetic_weights_(model, 0)
+        x = synthetic_images(B, seed=1234)
+        logits = ref_passes(model, x, T, 42)
+        np.savez_compressed(os.path.join(OUT, f"vgg19_{name}.npz"), kwargs=repr(kw), B=B, T=T, seed=42,
+                            init_checksum=init_sum, weights_checksum=state_checksum(model.state_dict()),
+                            logits=logits.astype(np.float32))
+        print("vgg19", name, logits.shape)
+    torch.manual_seed(0)
+    m = VGG19MC(dropout_exit=True, dropout_p=0.5, out_dim=10)
+    init_sum = state_checksum(m.state_dict())
+    synthetic_weights_(m, 0)
+    x = synthetic_images(3, seed=1234)
+    np.savez_compressed(os.path.join(OUT, "vgg19mc_exit.npz"), B=3, T=3, seed=7, init_checksum=init_sum,
+                        logits=ref_passes(m, x, 3, 7).astype(np.float32))
+    # the broken insertion modes: both raise AttributeError at construction
+    broken = []
+    for cls in (VGG19MC, VGG19MCEarlyExit):
+        for mode in ("block", "layer"):
+            try:
+                cls(dropout=mode, dropout_exit=True, out_dim=10)
+                broken.append("ok")
+            except Exception as e:      # noqa: BLE001
+                broken.append(type(e).__name__)
+    np.savez_compressed(os.path.join(OUT, "vgg19_broken_modes.npz"), errors=np.array(broken))
+    print("vgg broken modes", broken)
+
+
 def gen_masksembles():
     np.random.seed(3)
     m2 = ref_utils.Masksembles2D(16, 4, 2.0).eval()
@@ -247,3 +288,4 @@ if __name__ == "__main__":
     gen_masksembles()
     gen_metrics()
     gen_resnet()
+    gen_vgg()
