@@ -88,3 +88,25 @@ def test_full_collation_on_a_loader(tmp_path, monkeypatch):
     assert a.shape == b.shape == (E, 2 * B, C) and c.shape == (2 * B, C)
     txt = open(next(tmp_path.glob("test_evaluation_log_*x1.txt"))).read().strip().split("\n")
     assert len(txt) == 8 and len(txt[0].split(",")) == 8
+
+
+def test_confidence_exiting_matches_reference():
+    from bayesnn_fpga_amd.train import confidence_exiting as ce
+    g = load_golden("confidence_exiting.npz")
+    p, onehot = g["p"], g["onehot"]
+    assert ce.baseline_flops("resnet18") == int(g["baseline"])
+    for k, th in enumerate(g["thresholds"]):
+        for diff in (False, True):
+            acc, ece, nll, best = ce.confidence_exiting(p, onehot, float(th), diff=bool(diff))
+            np.testing.assert_array_equal(best, g[f"best_{k}_{int(diff)}"])
+            assert acc == pytest.approx(float(g[f"acc_{k}_{int(diff)}"]))
+        for eo in (True, False):
+            assert ce.flop_saver(p, float(th), "resnet18", eo, 10) == int(g[f"flops_{k}_{int(eo)}"])
+            assert ce.flop_saver_ensembled(p, float(th), "resnet18", eo, 10) == int(g[f"ensflops_{k}_{int(eo)}"])
+    want = g["std_exit"]
+    got = [[ce.flops_standard_exit("resnet18", l, 10, ens) for l in range(4)] for ens in (False, True)]
+    np.testing.assert_array_equal(np.array(got), want)
+    lay = ce.exit_layer(p, 0.5)
+    assert lay.min() >= 1                                   # exit 0 is never an exit point (reference quirk)
+    rows = ce.sweep(p, p, onehot, "resnet18", True)
+    assert len(rows) == 11 and rows[0]["flops"] <= rows[-1]["flops"]

@@ -270,6 +270,34 @@ def gen_metrics():
     print("metrics", ece, nll, mse, acc)
 
 
+def gen_confidence_exiting():
+    """Reference confidence-threshold exiting + FLOP model on a fixed random prediction set."""
+    rng = np.random.RandomState(5)
+    E, N, C = 4, 300, 10
+    logits = rng.randn(E, N, C) * np.array([1.0, 1.5, 2.0, 3.0])[:, None, None]
+    p = torch.softmax(torch.from_numpy(logits), -1).numpy()
+    y = rng.randint(0, C, size=N)
+    y = np.where(rng.rand(N) < 0.6, p[-1].argmax(1), y)
+    onehot = np.eye(C)[y]
+    fa = FullAnalysis.__new__(FullAnalysis)
+    fa.model_type = "resnet18"
+    fa.get_flops_per_module()
+    fa.ece_eval_binary = lambda bp, lab: (bp.copy(), 0.0, 0.0, float(np.mean(bp.argmax(1) == lab.argmax(1))))
+    out = dict(p=p, onehot=onehot, thresholds=np.array([0.1, 0.5, 0.8, 0.95, 0.999]), baseline=fa.baseline_flops)
+    for k, th in enumerate(out["thresholds"]):
+        for diff in (False, True):
+            acc, best, _ = fa.confidence_exiting(float(th), p, onehot, diff=diff)
+            out[f"best_{k}_{int(diff)}"] = best
+            out[f"acc_{k}_{int(diff)}"] = acc
+        for eo in (True, False):
+            fa.exit_only = eo
+            out[f"flops_{k}_{int(eo)}"] = fa.flop_saver(float(th), p, onehot, mc_passes=10)
+            out[f"ensflops_{k}_{int(eo)}"] = fa.flop_saver_ensembled(float(th), p, onehot, mc_passes=10)
+    out["std_exit"] = np.array([[fa.get_flops_standard_exit(l, 10, ens) for l in range(4)] for ens in (False, True)])
+    np.savez_compressed(os.path.join(OUT, "confidence_exiting.npz"), **out)
+    print("confidence exiting ok")
+
+
 def gen_philox():
     """Mask bits of the shared convention for a few (seed, site, t, p, shape) — pins the
     layout rule (NHWC-linear element order) independently of the model fixtures."""
@@ -287,5 +315,6 @@ if __name__ == "__main__":
     gen_philox()
     gen_masksembles()
     gen_metrics()
+    gen_confidence_exiting()
     gen_resnet()
     gen_vgg()
