@@ -18,7 +18,7 @@ Out of scope here: confidence-threshold exiting and the analytical FLOP model (:
 import numpy as np
 import torch
 
-from .metrics import ece_hist_binary, nll_mse_acc
+from .metrics import ece_hist_binary, ece_kde_binary, nll_mse_acc
 
 
 def get_device(gpu):
@@ -33,7 +33,9 @@ def exit_ensembles(per_exit):
 
 
 class FullAnalysis:
-    def __init__(self, model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="", seed=0):
+    def __init__(self, model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="", seed=0, ece="hist"):
+        self.ece_kind = ece          # "hist" (pinned to the reference's ece_hist_binary) | "kde" (reference's headline
+                                     # estimator, direct evaluation, parity unpinned)
         self.model = model
         self.loader = test_loader
         self.gpu = gpu
@@ -119,7 +121,8 @@ class FullAnalysis:
     def ece_eval_binary(self, p, label):
         """(ECE, NLL, MSE, accuracy) — :497-505 with the histogram ECE in place of the KDE ECE."""
         nll, mse, acc = nll_mse_acc(p, label)
-        return ece_hist_binary(p, label), nll, mse, acc
+        ece = ece_kde_binary(p, label) if getattr(self, "ece_kind", "hist") == "kde" else ece_hist_binary(p, label)
+        return ece, nll, mse, acc
 
     def all_experiments(self, experiment_id, write=True):
         rows = []

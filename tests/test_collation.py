@@ -110,3 +110,19 @@ def test_confidence_exiting_matches_reference():
     assert lay.min() >= 1                                   # exit 0 is never an exit point (reference quirk)
     rows = ce.sweep(p, p, onehot, "resnet18", True)
     assert len(rows) == 11 and rows[0]["flops"] <= rows[-1]["flops"]
+
+
+def test_kde_ece_properties_unpinned():
+    """KDE-ECE is NOT pinned to the reference (KDEpy absent): only estimator properties are checked."""
+    from bayesnn_fpga_amd.train.metrics import ece_kde_binary
+    rng = np.random.RandomState(0)
+    N = 3000
+    conf = rng.uniform(0.5, 1.0, N)
+    p = np.zeros((N, 3))
+    p[:, 0], p[:, 1], p[:, 2] = conf, (1 - conf) * 0.6, (1 - conf) * 0.4
+    calibrated = np.eye(3)[np.where(rng.rand(N) < conf, 0, 1)]
+    overconfident = np.eye(3)[np.where(rng.rand(N) < conf - 0.3, 0, 1)]
+    a, b = ece_kde_binary(p, calibrated, grid_points=2 ** 12), ece_kde_binary(p, overconfident, grid_points=2 ** 12)
+    assert a < 0.03 and 0.2 < b < 0.4
+    g = load_golden("metrics.npz")
+    assert abs(ece_kde_binary(g["p"], g["onehot"], grid_points=2 ** 12) - ece_hist_binary(g["p"], g["onehot"])) < 0.02
