@@ -22,6 +22,8 @@
 // Orientation, fragment layouts and the fused epilogue are those of conv_igemm.hip
 // (channels on the MFMA row axis -> one Philox call / one 8-byte store per accumulator quad).
 // Reference semantics: BasicBlock.forward SA/models/resnet18/resnet18.py:32-48.
+#include <cstdlib>
+
 #include "conv_epilogue.h"
 #include "kernels.h"
 
@@ -334,6 +336,12 @@ int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s) {
         if (a.Ho == 8 && a.Wo == 8) return launch_patch<1, 8, 8, 2, 2, BMI_PATCH_NB_S3>(a, s);
         if (a.Ho == 4 && a.Wo == 4) return launch_patch<1, 4, 4, 8, 2>(a, s);
         if (a.Ho % 8 == 0 && a.Wo == 32) return launch_patch<1, 8, 32, 1, 4>(a, s);
+    }
+    static const int s2 = [] { const char* v = std::getenv("BMI_PATCH_S2"); return v ? std::atoi(v) : 0; }();
+    if (a.stride == 2 && s2) {   // experimental: stride-2 through the patch kernel (1 workgroup per CU)
+        if (a.Ho == 8 && a.Wo == 8) return launch_patch<2, 8, 8, 2, 2>(a, s);
+        if (a.Ho == 4 && a.Wo == 4) return launch_patch<2, 4, 4, 8, 2>(a, s);
+        if (a.Ho == 16 && a.Wo == 16) return launch_patch<2, 8, 16, 1, 2>(a, s);
     }
     return BMI_ERR_UNSUPPORTED;
 }

@@ -73,11 +73,13 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
     if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
         const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)p.e_pix * a.Cout + c4
                                                                   : (uint64_t)p.b * a.Cout + c4;
-        const uint64_t g = elem >> 2;
+        const uint64_t g = elem >> 3;          // this quad is the low or the high half of an 8-element group
+        const int e0 = (int)(elem & 4);
         const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p.t, (uint32_t)a.site.site_id,
                                          a.site.seed_lo, a.site.seed_hi);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[e] * a.site.scale : 0.f;
+        for (int e = 0; e < 4; ++e)
+            v[e] = (!a.site.drop_all && philox_keep(rn, e0 + e, a.site.thresh)) ? v[e] * a.site.scale : 0.f;
     } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
         const float4 k4 = *(const float4*)(p.mrow + c4);
         v[0] *= k4.x; v[1] *= k4.y; v[2] *= k4.z; v[3] *= k4.w;
@@ -188,15 +190,12 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
             if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
                 const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)px.e_pix * a.Cout + c8
                                                                           : (uint64_t)px.b * a.Cout + c8;
+                const uint64_t g = elem >> 3;      // one Philox call masks the thread's 8 channels
+                const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)px.t,
+                                                 (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const uint64_t g = (elem >> 2) + h2;
-                    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)px.t,
-                                                     (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[4 * h2 + e] = (!a.site.drop_all && rn.w[e] >= a.site.thresh) ? v[4 * h2 + e] * a.site.scale : 0.f;
-                }
+                for (int e = 0; e < 8; ++e)
+                    v[e] = (!a.site.drop_all && philox_keep(rn, e, a.site.thresh)) ? v[e] * a.site.scale : 0.f;
             } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
                 const f32x4_e k0 = *(const f32x4_e*)(px.mrow + c8), k1 = *(const f32x4_e*)(px.mrow + c8 + 4);
 #pragma unroll

@@ -17,15 +17,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void site_mask8(const SiteArgs& s, float v[8], uint64_t elem0, int t, const float* mrow) {
     // elem0: element index of v[0] (multiple of 8 within the site's index space)
     if (s.kind == BMI_SITE_ELEMENTWISE || s.kind == BMI_SITE_CHANNEL) {
+        const uint64_t g = elem0 >> 3;
+        const philox4 rn =
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t, (uint32_t)s.site_id, s.seed_lo, s.seed_hi);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint64_t g = (elem0 >> 2) + q;
-            const philox4 rn =
-                philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t, (uint32_t)s.site_id, s.seed_lo, s.seed_hi);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[4 * q + e] = (!s.drop_all && rn.w[e] >= s.thresh) ? v[4 * q + e] * s.scale : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = (!s.drop_all && philox_keep(rn, e, s.thresh)) ? v[e] * s.scale : 0.f;
     } else if (s.kind == BMI_SITE_MASKSEMBLE) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= mrow[e];
@@ -259,18 +255,18 @@ int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, 
 __global__ void philox_mask_kernel(uint8_t* keep, long n, uint32_t k0, uint32_t k1, int site, int t, uint32_t thresh,
                                    int drop_all) {
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g * 4 >= n) return;
+    if (g * 8 >= n) return;
     const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)t, (uint32_t)site, k0, k1);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (g * 4 + e < n) keep[g * 4 + e] = (!drop_all && rn.w[e] >= thresh) ? 1 : 0;
+    for (int e = 0; e < 8; ++e)
+        if (g * 8 + e < n) keep[g * 8 + e] = (!drop_all && philox_keep(rn, e, thresh)) ? 1 : 0;
 }
 
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s) {
     if (n <= 0) return BMI_ERR_INVALID;
     int drop_all = 0;
     const uint32_t thresh = bmi_drop_threshold(p, &drop_all);
-    const long groups = (n + 3) / 4;
+    const long groups = (n + 7) / 8;
     hipLaunchKernelGGL(philox_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, keep, (long)n,
                        (uint32_t)seed, (uint32_t)(seed >> 32), site, t, thresh, drop_all);
     BMI_CHECK_LAUNCH();

@@ -1,11 +1,13 @@
 // Philox4x32-10 (Salmon et al., SC'11; Random123 philox4x32_R(10,...)) and the dropout-mask
 // convention shared with the CPU oracle (oracle/philox.py):
-//   key = (seed_lo, seed_hi); counter = (g_lo, g_hi, t, site), g = element_index / 4;
-//   element e uses word r[e & 3]; keep iff r >= thresh (thresh = round(p * 2^32); p >= 1 drops all).
-// element_index is the NHWC-linear index inside ONE Monte-Carlo sample's activation, so the
-// four words of one call cover four consecutive channels of one pixel — exactly the four
-// accumulator registers (reg & 3) a lane of v_mfma_f32_32x32x16 holds when channels are on the
-// MFMA row axis (see conv_igemm.hip).
+//   key = (seed_lo, seed_hi); counter = (g_lo, g_hi, t, site), g = element_index / 8;
+//   element e uses the 16-bit half (e & 1) of word r[(e & 7) >> 1]  (even e: low half);
+//   keep iff half >= thresh16, thresh16 = floor(fl32(p) * 65536 + 0.5)  (65536: drop everything).
+// element_index is the NHWC-linear index inside ONE Monte-Carlo sample's activation, so ONE call
+// covers eight consecutive channels of one pixel — the 16 bytes a lane moves in the coalesced conv
+// epilogue, in mask_apply and in pool_mask.  (Round 1 started with 32 bits per element; the
+// stand-alone mask kernel was Philox-bound, so the convention went to 16 bits: P(drop) is then
+// quantised to 1/65536, a relative error below 8e-6 for every p the reference sweeps.)
 #pragma once
 #include <stdint.h>
 
@@ -41,7 +43,7 @@ BMI_HD philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 struct SiteArgs {
     int kind;            // BMI_SITE_*
     int site_id;
-    uint32_t thresh;     // keep iff word >= thresh
+    uint32_t thresh;     // keep iff 16-bit half-word >= thresh
     int drop_all;        // p >= 1
     float scale;         // fl32(1 / fl32(1 - p)); 1 for MASKSEMBLE
     const float* masks;  // MASKSEMBLE [M][C]
@@ -51,10 +53,15 @@ struct SiteArgs {
 };
 
 static inline uint32_t bmi_drop_threshold(float p, int* drop_all) {
-    double v = (double)p * 4294967296.0 + 0.5;
+    double v = (double)p * 65536.0 + 0.5;
     uint64_t t = v <= 0 ? 0 : (uint64_t)v;  // floor
-    *drop_all = t >= (1ull << 32);
-    return *drop_all ? 0xFFFFFFFFu : (uint32_t)t;
+    *drop_all = t >= 65536;
+    return *drop_all ? 0xFFFFu : (uint32_t)t;
+}
+
+// keep flag of element e (0..7) of the call's group
+BMI_HD bool philox_keep(const philox4& r, int e, uint32_t thresh16) {
+    return ((r.w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu) >= thresh16;
 }
 
 static inline float bmi_drop_scale(float p) {

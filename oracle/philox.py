@@ -7,15 +7,15 @@ the Random123 known-answer vectors in ``tests/test_philox.py``.
 Mask convention shared by oracle and HIP kernels (bayesnn_fpga_amd/csrc/philox.h):
 
   key      = (seed & 0xffffffff, seed >> 32)
-  counter  = (g & 0xffffffff, g >> 32, t, site)          g = element_index // 4
-  element  e uses output word  r[e % 4]
-  keep(e)  = r[e % 4] >= thresh,   thresh = min(floor(fl32(p) * 2**32 + 0.5), 2**32)   (u64 compare)
+  counter  = (g & 0xffffffff, g >> 32, t, site)          g = element_index // 8
+  element  e uses the 16-bit half (e & 1) of output word r[(e % 8) // 2]   (even e: low half)
+  keep(e)  = half >= thresh,   thresh = min(floor(fl32(p) * 2**16 + 0.5), 2**16)
   out      = x * keep * fl32(1 / fl32(1 - p))            (MCDropout: F.dropout, always on,
                                                           SA/models/resnet18/resnet18.py:209-210)
 
 ``element_index`` is the NHWC-linear index inside ONE Monte-Carlo sample's activation of
 logical shape [B, C, H, W]:  ((b*H + h)*W + w)*C + c  ([B, C] tensors have H = W = 1), so
-a group of 4 consecutive channels of a pixel shares one Philox call.  ``t`` is the global
+a group of 8 consecutive channels of a pixel shares one Philox call.  ``t`` is the global
 Monte-Carlo sample index and ``site`` the call-order index of the stochastic layer inside
 one forward.  Channel-wise sites (``F.dropout2d`` semantics of
 ``Hardware_Artifact/converter/pytorch/Dropouts.py:25-56``) use element_index = b*C + c.
@@ -50,8 +50,8 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def drop_threshold(p):
-    """u64 threshold: keep iff r >= thresh.  P(drop) = thresh / 2**32."""
-    return min(int(np.floor(float(np.float32(p)) * 4294967296.0 + 0.5)), 1 << 32)
+    """16-bit threshold: keep iff half-word >= thresh.  P(drop) = thresh / 2**16."""
+    return min(int(np.floor(float(np.float32(p)) * 65536.0 + 0.5)), 1 << 16)
 
 
 def drop_scale(p):
@@ -64,13 +64,14 @@ def drop_scale(p):
 
 def keep_bits(n_elems, seed, site, t, p):
     """Boolean keep-mask for elements 0..n_elems-1 of one (seed, site, t) stream."""
-    n_groups = (n_elems + 3) // 4
+    n_groups = (n_elems + 7) // 8
     g = np.arange(n_groups, dtype=np.uint64)
     r = philox4x32_10(g & _MASK32, g >> np.uint64(32), np.uint64(t), np.uint64(site),
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    words = np.stack(r, axis=1).reshape(-1)[:n_elems].astype(np.uint64)
-    return words >= np.uint64(drop_threshold(p)) if drop_threshold(p) < (1 << 32) \
-        else np.zeros(n_elems, dtype=bool)
+    words = np.stack(r, axis=1).astype(np.uint32)                        # [groups, 4]
+    halves = np.stack([words & np.uint32(0xFFFF), words >> np.uint32(16)], axis=2).reshape(-1)[:n_elems]
+    thr = drop_threshold(p)
+    return halves >= thr if thr < (1 << 16) else np.zeros(n_elems, dtype=bool)
 
 
 def elementwise_mask(shape, seed, site, t, p):

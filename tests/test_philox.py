@@ -31,23 +31,26 @@ def test_philox_vectorised_matches_scalar():
 
 def test_threshold_and_scale():
     assert philox.drop_threshold(0.0) == 0
-    assert philox.drop_threshold(0.25) == 1 << 30
-    assert philox.drop_threshold(0.5) == 1 << 31
-    assert philox.drop_threshold(1.0) == 1 << 32
+    assert philox.drop_threshold(0.25) == 1 << 14
+    assert philox.drop_threshold(0.5) == 1 << 15
+    assert philox.drop_threshold(1.0) == 1 << 16
+    assert philox.drop_threshold(0.2) == 13107                      # quantised to 1/65536
     assert philox.drop_scale(0.25) == np.float32(1.0) / np.float32(0.75)
     assert philox.drop_scale(1.0) == 0.0
 
 
 def test_mask_layout_rule():
-    """element index is NHWC-linear: ((b*H+h)*W+w)*C+c, four consecutive channels per call."""
+    """element index is NHWC-linear: ((b*H+h)*W+w)*C+c, eight consecutive channels per call,
+    16 bits per element (low half of the word first)."""
     seed, site, t, p = 42, 3, 5, 0.25
     B, C, H, W = 2, 8, 3, 2
     m = philox.elementwise_mask((B, C, H, W), seed, site, t, p)
     thr = philox.drop_threshold(p)
     for (b, c, h, w) in [(0, 0, 0, 0), (1, 5, 2, 1), (0, 7, 1, 0), (1, 3, 0, 1)]:
         e = ((b * H + h) * W + w) * C + c
-        r = philox.philox4x32_10(e // 4, 0, t, site, seed, 0)
-        assert m[b, c, h, w] == float(int(r[e % 4]) >= thr)
+        r = philox.philox4x32_10(e // 8, 0, t, site, seed, 0)
+        half = (int(r[(e % 8) // 2]) >> (16 * (e & 1))) & 0xFFFF
+        assert m[b, c, h, w] == float(half >= thr)
 
 
 def test_mask_statistics():
