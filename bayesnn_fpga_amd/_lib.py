@@ -62,7 +62,9 @@ _PROTOS = {
     "bmi_philox_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "bmi_stem_conv_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 9 + [C.c_void_p]),
     "bmi_pack_conv3x3_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
-    "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
+    "bmi_mask_bits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site), C.c_int32, C.c_int32, C.c_uint64,
+                                C.c_void_p]),
+    "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
                                                                          C.c_uint64, C.c_int32, C.c_void_p]),
     "bmi_mask_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
                                  C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),

@@ -326,8 +326,16 @@ static int launch_patch(const ConvArgs& a, hipStream_t s) {
     return BMI_OK;
 }
 
+// Shapes the patch kernel takes (kept in sync with launch_conv3x3_patch; the engine uses it to decide
+// which consumers of a site can read keep bits instead of a materialised masked tensor).
+bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo) {
+    if (ksize != 3 || pad != 1 || stride != 1 || cin % 64 != 0 || cout % 128 != 0) return false;
+    return (ho == 16 && wo == 16) || (ho == 8 && wo == 8) || (ho == 4 && wo == 4) || (ho % 8 == 0 && wo == 32);
+}
+
 // Returns BMI_ERR_UNSUPPORTED when no patch configuration fits (the caller falls back to conv_igemm).
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s) {
+    if (a.in_bits) return BMI_ERR_UNSUPPORTED;   // the patch is filled by DMA: no place to apply keep bits
     if (a.ksize != 3 || a.pad != 1 || a.Cin % 64 != 0 || a.Cout % 128 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
     if ((size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets

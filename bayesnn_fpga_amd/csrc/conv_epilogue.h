@@ -55,7 +55,10 @@ __device__ __forceinline__ PixelCtx make_pixel_ctx(const ConvArgs& a, int n, int
 __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx& p, float v[4], int c4) {
     if (a.scale) {
         const float4 s4 = *(const float4*)(a.scale + c4);
-        v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
+        v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
+    } else if (a.out_mul != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
     }
     if (a.bias) {
         const float4 b4 = *(const float4*)(a.bias + c4);
@@ -146,6 +149,8 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
     f32x4_e sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, bi0 = {0.f, 0.f, 0.f, 0.f}, bi1 = bi0;
     if (a.scale) { sc0 = *(const f32x4_e*)(a.scale + ch0 + 8 * k); sc1 = *(const f32x4_e*)(a.scale + ch0 + 8 * k + 4); }
     if (a.bias) { bi0 = *(const f32x4_e*)(a.bias + ch0 + 8 * k); bi1 = *(const f32x4_e*)(a.bias + ch0 + 8 * k + 4); }
+    sc0 *= a.out_mul;
+    sc1 *= a.out_mul;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         lds_barrier();   // main loop (or previous round's phase 2) is done with the LDS

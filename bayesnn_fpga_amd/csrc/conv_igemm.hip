@@ -30,7 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BC, int BP, int WC, int WP, bool DBUF>
+template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TI = BC / WC / 32;   // 32x32 MFMA tiles per wave along channels
     constexpr int TJ = BP / WP / 32;   // ... along pixels
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const _Float16* wptr = a.wgt + (size_t)(ch0 + r0) * Ktot + chunk * 8;
 
     int iy0[XROWS], ix0[XROWS];
+    int bbase[XMASK ? XROWS : 1];
     const _Float16* xbase[XROWS];
     bool vm[XROWS];
 #pragma unroll
@@ -76,12 +77,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         iy0[j] = oy * a.stride - a.pad;
         ix0[j] = ox * a.stride - a.pad;
         xbase[j] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + chunk * 8;
+        if constexpr (XMASK) bbase[j] = n * a.H * a.W;   // pixel index base of the FOLDED image (keep bits are per sample)
     }
 
     // NOTE: staging registers are filled/drained by macros, not lambdas: with by-reference lambda
     // captures hipcc fails to scalarise the arrays and "promotes" them to LDS (an extra 16 KB and a
     // round trip through LDS per K-step).
     u32x4 wreg[WROWS], xreg[XROWS];
+    uint32_t kreg[XMASK ? XROWS : 1];
 #define GLOAD(KY, KX, C0)                                                                                  \
     {                                                                                                      \
         const int koff_ = ((KY) * a.ksize + (KX)) * a.Cin + (C0);                                          \
@@ -92,6 +95,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             const bool ok_ = vm[j] && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;      \
             u32x4 v_ = {0u, 0u, 0u, 0u};                                                                   \
             if (ok_) v_ = *(const u32x4*)(xbase[j] + (size_t)(iy_ * a.W + ix_) * a.Cin + (C0));           \
+            if constexpr (XMASK) {                                                                         \
+                /* input-side MC-dropout: fetch the keep byte now, apply it at LSTORE time so the */       \
+                /* loads stay in flight under the MFMAs of the current step */                             \
+                uint32_t kb_ = 0;                                                                          \
+                if (ok_) kb_ = a.in_bits[(size_t)(bbase[j] + iy_ * a.W + ix_) * (a.Cin >> 3) + ((C0) >> 3) + chunk]; \
+                kreg[j] = kb_;                                                                             \
+            }                                                                                              \
             xreg[j] = v_;                                                                                  \
         }                                                                                                  \
     }
@@ -99,8 +109,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     {                                                                                                      \
         char* base_ = smem + (BUF) * TILE;                                                                 \
         _Pragma("unroll") for (int j = 0; j < WROWS; ++j) *(u32x4*)(base_ + st_off + j * 32 * 128) = wreg[j];   \
-        _Pragma("unroll") for (int j = 0; j < XROWS; ++j)                                                  \
-            *(u32x4*)(base_ + BC * 128 + st_off + j * 32 * 128) = xreg[j];                                 \
+        _Pragma("unroll") for (int j = 0; j < XROWS; ++j) {                                                \
+            u32x4 xv_ = xreg[j];                                                                           \
+            if constexpr (XMASK) {   /* zero the dropped halves (1/(1-p) is folded into out_mul) */        \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d)                                              \
+                    xv_[d] &= ((kreg[j] >> (2 * d)) & 1u ? 0xFFFFu : 0u) | ((kreg[j] >> (2 * d + 1)) & 1u ? 0xFFFF0000u : 0u); \
+            }                                                                                              \
+            *(u32x4*)(base_ + BC * 128 + st_off + j * 32 * 128) = xv_;                                     \
+        }                                                                                                  \
     }
 
     f32x16 acc[TI][TJ];
@@ -194,13 +210,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
-template <int BC, int BP, int WC, int WP, bool DBUF>
+template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int n_ctiles = a.Cout / BC;
     const long n_ptiles = ((long)a.M + BP - 1) / BP;
     const long blocks = n_ptiles * n_ctiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -210,6 +226,10 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
     if (a.res && a.res_mod <= 0) return BMI_ERR_INVALID;
     static const int big = [] { const char* v = std::getenv("BMI_IGEMM_BP256"); return v ? std::atoi(v) : 1; }();
+    if (a.in_bits) {   // masked-input variant (register budget: 128-pixel tiles only)
+        if (a.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2, true, true>(a, s);
+        return launch_cfg<64, 128, 1, 4, true, true>(a, s);
+    }
     if (a.Cout % 128 == 0) {
         // 256-pixel tiles (single LDS buffer, 2 barriers per K-step) halve the weight-tile traffic per FLOP
         if (big && (long)(a.M / 256) * (a.Cout / 128) >= 400 && a.ksize == 3) return launch_cfg<128, 256, 2, 2, false>(a, s);

@@ -13,6 +13,9 @@ struct ConvArgs {
     const float* scale;   // may be null
     const float* bias;    // may be null
     const _Float16* res;  // may be null
+    const uint8_t* in_bits;  // keep bits of an elementwise MC-dropout site on the INPUT (1 bit per element,
+                             // byte g = elements 8g..8g+7 of the folded tensor), or null; conv_igemm only
+    float out_mul;           // multiplies the folded-BN scale (the site's 1/(1-p) when in_bits is used), else 1
     _Float16* out;
     int N;        // output images in this launch (= samples_in_chunk * B in the suffix)
     int in_mod;   // input image = n % in_mod  (B when the input is deterministic)
@@ -52,6 +55,8 @@ int launch_moments(const float* probs, const float* logits, double* S1, double* 
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
+int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s);
+bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);
 
 SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0);
 

@@ -68,6 +68,46 @@ int launch_mask_apply(const EltArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Keep bits of an elementwise site for a folded batch: byte g of sample t_local holds the keep flags
+// of elements 8g..8g+7 (bit e = element 8g+e).  16x smaller than the masked activation: consumers that
+// stage their input through registers (conv_igemm) read the un-expanded deterministic tensor from
+// L2 plus these bits instead of a materialised x * mask copy from HBM.
+__global__ __launch_bounds__(256) void mask_bits_kernel(uint8_t* __restrict__ bits, long groups_per_sample, int tc, int t0,
+                                                        SiteArgs s) {
+    const long total4 = (groups_per_sample * tc + 3) / 4;   // 4 groups (one dword of bits) per thread
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long gi = i * 4 + q;
+            if (gi >= groups_per_sample * tc) break;
+            const long tl = gi / groups_per_sample;
+            const uint64_t g = (uint64_t)(gi - tl * groups_per_sample);
+            const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(t0 + tl), (uint32_t)s.site_id,
+                                             s.seed_lo, s.seed_hi);
+            uint32_t b = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b |= (!s.drop_all && philox_keep(rn, e, s.thresh)) ? (1u << e) : 0u;
+            word |= b << (8 * q);
+        }
+        if (i * 4 + 3 < groups_per_sample * tc) *(uint32_t*)(bits + i * 4) = word;
+        else for (int q = 0; q < 4 && i * 4 + q < groups_per_sample * tc; ++q) bits[i * 4 + q] = (uint8_t)(word >> (8 * q));
+    }
+}
+
+int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s) {
+    if (c % 8 != 0 || site.kind != BMI_SITE_ELEMENTWISE) return BMI_ERR_UNSUPPORTED;
+    if (n <= 0 || batch <= 0 || n % batch != 0) return BMI_ERR_INVALID;
+    const long gps = (long)batch * hw * (c / 8);
+    const int tc = n / batch;
+    long blocks = ((gps * tc + 3) / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(mask_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bits, gps, tc, t0, site);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_mask_kernel(EltArgs a) {
     const int cg = a.C >> 3;
     const long total = (long)a.N * cg;

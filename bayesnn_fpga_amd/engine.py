@@ -22,7 +22,7 @@ from torch import nn
 from . import _lib
 from .utils import Masksembles1D, Masksembles2D
 
-DEFAULT_CHUNK_IMAGES = 5120      # image-samples folded into one suffix launch (tuned on MI355X)
+DEFAULT_CHUNK_IMAGES = 25600      # image-samples folded into one suffix launch (tuned on MI355X)
 
 
 def _is_site(m):

@@ -23,7 +23,7 @@
  *   bmi_stem_conv_fwd, bmi_conv_igemm_fwd   conv+BN(+residual)(+ReLU) of BasicBlock.forward
  *                              (resnet18.py:32-48) and of the exit heads (:306-308,:318-319,:329)
  *   bmi_pack_conv3x3_weights   (no reference counterpart: one-off re-layout of conv weights at load time)
- *   bmi_mask_apply             MCDropout / Masksembles2D on a stage output (:278-280)
+ *   bmi_mask_apply, bmi_mask_bits   MCDropout / Masksembles2D on a stage output (:278-280)
  *   bmi_pool_mask              F.avg_pool2d(F.relu(.),4) + flatten + exit dropout (:309-313)
  *   bmi_linear_softmax         ex{1,2,3}linear / linear (:314,:325,:335,:344) + softmax
  *                              (results_analyzer.py:242)
@@ -162,7 +162,14 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
  * (Cout % 128 == 0, Cin % 64 == 0; same byte size). */
 int bmi_pack_conv3x3_weights(const void* weight, void* packed, int32_t cout, int32_t cin, bmi_stream stream);
 
-int bmi_conv_igemm_fwd(const void* in, const void* weight, const void* weight_packed, const float* scale, const float* bias, const void* res,
+/* keep bits (1 bit per element, byte g = elements 8g..8g+7) of an elementwise site for the folded batch
+ * n = samples*batch images of hw pixels x c channels */
+int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* site, int32_t batch, int32_t t0,
+                  uint64_t seed, bmi_stream stream);
+
+/* in_keep_bits (or NULL): input-side MC-dropout — image n reads in[n % in_mod] with the dropped elements of
+ * folded image n zeroed while staging; out_mul multiplies the BN scale (pass 1/(1-p) then, else 1). */
+int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, const void* weight, const void* weight_packed, const float* scale, const float* bias, const void* res,
                        void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
                        int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);

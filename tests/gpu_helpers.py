@@ -65,7 +65,8 @@ def conv_ref(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod):
     return y        # NCHW fp32
 
 
-def run_conv(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod, site=None, batch=None, t0=0, seed=0, cnt0=0):
+def run_conv(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod, site=None, batch=None, t0=0, seed=0, cnt0=0,
+             in_bits=None, out_mul=1.0):
     lib = _lib.lib()
     n_in, H, W, cin = x.shape
     cout, k = w.shape[0], w.shape[1]
@@ -77,7 +78,7 @@ def run_conv(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod, site
     if k == 3 and pad == 1 and cin % 64 == 0 and cout % 128 == 0:      # only used under BMI_CONV_IMPL=wreg
         wp = torch.empty_like(w)
         _lib.check(lib.bmi_pack_conv3x3_weights(ptr(w), ptr(wp), cout, cin, stream()), "bmi_pack_conv3x3_weights")
-    rc = lib.bmi_conv_igemm_fwd(ptr(x), ptr(w), ptr(wp), ptr(scale), ptr(bias), ptr(res), ptr(out), n, in_mod, res_mod, H, W, cin,
+    rc = lib.bmi_conv_igemm_fwd(ptr(x), ptr(in_bits), float(out_mul), ptr(w), ptr(wp), ptr(scale), ptr(bias), ptr(res), ptr(out), n, in_mod, res_mod, H, W, cin,
                                 cout, k, stride, pad, int(relu), C.byref(s) if s is not None else None,
                                 batch if batch is not None else n, t0, seed, cnt0, stream())
     _lib.check(rc, "bmi_conv_igemm_fwd")

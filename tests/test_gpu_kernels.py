@@ -109,7 +109,7 @@ def test_conv_rejects_unsupported_shapes():
     x = torch.zeros(1, 8, 8, 48, dtype=torch.float16, device=DEV)
     w = torch.zeros(64, 3, 3, 48, dtype=torch.float16, device=DEV)
     o = torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=DEV)
-    rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), gh.ptr(w), None, None, None, None, gh.ptr(o), 1, 1, 1, 8, 8, 48, 64, 3, 1, 1, 0, None, 1,
+    rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), None, 1.0, gh.ptr(w), None, None, None, None, gh.ptr(o), 1, 1, 1, 8, 8, 48, 64, 3, 1, 1, 0, None, 1,
                                 0, 0, 0, gh.stream())
     assert rc == -95
 
@@ -213,3 +213,36 @@ def test_maxpool2():
     torch.cuda.synchronize()
     ref = torch.nn.functional.max_pool2d(x.float().cpu().permute(0, 3, 1, 2), 2)
     assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)
+
+
+def test_mask_bits_and_masked_input_conv():
+    """Input-side MC-dropout: keep bits (bit-exact vs the oracle mask) + a stride-2 conv that reads the
+    un-expanded deterministic tensor and applies the bits while staging == conv on the materialised
+    x * keep / (1 - p)."""
+    lib = _lib.lib()
+    B, tc, H, cin, cout, t0, seed, p = 3, 3, 16, 64, 128, 4, (5 << 32) + 9, 0.25
+    N = B * tc
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=0, p=p)
+    keep = []
+    s = gh.site_struct(site, keep)
+    bits = torch.zeros(N * H * H * cin // 8, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.bmi_mask_bits(gh.ptr(bits), N, H * H, cin, C.byref(s), B, t0, seed, gh.stream()), "bmi_mask_bits")
+    torch.cuda.synchronize()
+    got_bits = np.unpackbits(bits.cpu().numpy(), bitorder="little").astype(bool)
+    want = np.concatenate([philox.keep_bits(B * H * H * cin, seed, 0, t0 + tl, p) for tl in range(tc)])
+    assert np.array_equal(got_bits, want)
+
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, 3, B, 31, False)
+    out = gh.run_conv(x, w, scale, bias, None, True, 2, 1, N, B, 1, batch=B, in_bits=bits,
+                      out_mul=float(philox.drop_scale(p)))
+    mult = gh.folded_site_mask(site, B, cin, H, H, tc, t0, seed)                 # keep * 1/(1-p), [N,C,H,W]
+    xin = (x.float().cpu().permute(0, 3, 1, 2).repeat(tc, 1, 1, 1) * mult)
+    ref = torch.nn.functional.conv2d(xin, w.float().cpu().permute(0, 3, 1, 2), stride=2, padding=1)
+    ref = torch.relu(ref * scale.cpu()[None, :, None, None] + bias.cpu()[None, :, None, None])
+    torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=2e-3)
+    # 1x1 stride-2 (the downsample conv) takes the same path
+    w1 = (torch.randn(cout, 1, 1, cin, generator=g) * 0.2).to(torch.float16).to(DEV)
+    out1 = gh.run_conv(x, w1, scale, bias, None, False, 2, 0, N, B, 1, batch=B, in_bits=bits, out_mul=float(philox.drop_scale(p)))
+    ref1 = torch.nn.functional.conv2d(xin, w1.float().cpu().permute(0, 3, 1, 2), stride=2)
+    ref1 = ref1 * scale.cpu()[None, :, None, None] + bias.cpu()[None, :, None, None]
+    torch.testing.assert_close(out1.float().cpu().permute(0, 3, 1, 2), ref1, rtol=2e-3, atol=2e-3)

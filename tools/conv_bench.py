@@ -56,7 +56,7 @@ def main():
         site = _lib.make_site(_lib.SITE_ELEMENTWISE, 2, 0.25) if a.site else None
 
         def run():
-            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), w.data_ptr(), wp.data_ptr() if wp is not None else None, None if a.noscale else scale.data_ptr(),
+            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), wp.data_ptr() if wp is not None else None, None if a.noscale else scale.data_ptr(),
                                         None if a.noscale else bias.data_ptr(), None if a.nores else res.data_ptr(),
                                         out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1,
                                         C.byref(site) if site is not None else None, 250, 0, 42, 0, st)
