@@ -27,9 +27,9 @@ class TensorDesc(C.Structure):
 
 
 class OpDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("in_", C.c_int32), ("out", C.c_int32), ("residual", C.c_int32),
+    _fields_ = [("kind", C.c_int32), ("in_", C.c_int32), ("out", C.c_int32), ("residual", C.c_int32), ("in2", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32),
-                ("weight", C.c_void_p), ("weight_packed", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site)]
+                ("weight", C.c_void_p), ("weight2", C.c_void_p), ("weight_packed", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site)]
 
 
 class ModelDesc(C.Structure):
@@ -66,6 +66,7 @@ _PROTOS = {
                                 C.c_void_p]),
     "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
                                                                          C.c_uint64, C.c_int32, C.c_void_p]),
+    "bmi_conv3x3_shortcut_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 7 + [C.c_void_p]),
     "bmi_mask_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
                                  C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
     "bmi_maxpool2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -304,6 +304,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #undef LOAD_W
 #undef STORE_W
 
+    // ---- fused 1x1 strided shortcut: extra K-steps on a halo-free "patch" of the block input -----
+    // (the downsample conv of BasicBlock: as its own launch it is a K = 64..256 GEMM that costs 10 % of
+    // the conv time for 1.2 % of the FLOPs; here it is Cin2/64 more K-steps and no residual traffic)
+    if (a.in2) {
+        const int nch2 = a.Cin2 / 64;
+        for (int c2 = 0; c2 < nch2; ++c2) {
+            lds_barrier();   // every wave is done with the patch and the weight buffers
+#pragma unroll
+            for (int i = 0; i < 2 * TJ; ++i) {   // BP cells x 8 pieces = 256 threads x 2*TJ
+                const int q = tid + 256 * i;
+                const int p = q >> 3, cp = q & 7;
+                const int img = p / (TH * TW), rem = p - img * (TH * TW);
+                const int oy = rem / TW, ox = rem - oy * TW;
+                const int c = cp ^ (((ox + KA * oy) >> 1) & 7);
+                const int n = n0 + img;
+                const int nm = n < a.in2_mod ? n : n % a.in2_mod;
+                const _Float16* src = n < a.N ? a.in2 + (((size_t)nm * a.H2 + (size_t)(y0 + oy) * a.stride2) * a.W2 +
+                                                        (size_t)(x0 + ox) * a.stride2) * a.Cin2 + c2 * 64 + c * 8
+                                              : (const _Float16*)g_zero_page;
+                GLDS16(src, patch + (i * 256 + wave * 64) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                GLDS16(a.wgt2 + (size_t)(ch0 + w_row + 32 * i) * a.Cin2 + c2 * 64 + ((tid & 7) ^ w_sw) * 8,
+                       wbuf + (i * 256 + wave * 64) * 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ch = 2 * kk + hh;
+                half8 af[TI], bf[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wbuf + a_off + i * 32 * 128 + ((ch ^ a_sw) << 4));
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int p = wp * (32 * TJ) + 32 * j + r;
+                    const int rem = p % (TH * TW);
+                    const int sw = (((rem % TW) + KA * (rem / TW)) >> 1) & 7;
+                    bf[j] = *(const half8*)(patch + p * 128 + ((ch ^ sw) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
     STAMP(2);
     // ---- epilogue (coalesced through LDS) ----------------------------------------------------------
     auto pixmap = [&](int p, int& n, int& rem) -> bool {
@@ -336,6 +385,7 @@ bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, 
 // Returns BMI_ERR_UNSUPPORTED when no patch configuration fits (the caller falls back to conv_igemm).
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s) {
     if (a.in_bits) return BMI_ERR_UNSUPPORTED;   // the patch is filled by DMA: no place to apply keep bits
+    if (a.in2 && (!a.wgt2 || a.Cin2 % 64 != 0 || a.in2_mod <= 0 || a.stride2 < 1)) return BMI_ERR_INVALID;
     if (a.ksize != 3 || a.pad != 1 || a.Cin % 64 != 0 || a.Cout % 128 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
     if ((size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets

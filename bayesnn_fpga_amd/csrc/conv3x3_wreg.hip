@@ -294,7 +294,7 @@ static int launch_wreg(const ConvArgs& a, hipStream_t s) {
 
 // Returns BMI_ERR_UNSUPPORTED when the shape has no configuration or no packed weights were given.
 int launch_conv3x3_wreg(const ConvArgs& a, hipStream_t s) {
-    if (a.in_bits) return BMI_ERR_UNSUPPORTED;
+    if (a.in_bits || a.in2) return BMI_ERR_UNSUPPORTED;
     if (!a.wpk || a.ksize != 3 || a.pad != 1 || a.Cin % 64 != 0 || a.Cout % 128 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
     if ((size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets

@@ -222,7 +222,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
-    if (a.Cin % BK != 0 || a.Cout % 64 != 0) return BMI_ERR_UNSUPPORTED;
+    if (a.Cin % BK != 0 || a.Cout % 64 != 0 || a.in2) return BMI_ERR_UNSUPPORTED;   // the fused shortcut is a patch-kernel feature
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
     if (a.res && a.res_mod <= 0) return BMI_ERR_INVALID;
     static const int big = [] { const char* v = std::getenv("BMI_IGEMM_BP256"); return v ? std::atoi(v) : 1; }();

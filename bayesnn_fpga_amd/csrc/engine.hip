@@ -178,7 +178,18 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     if (tr.h != to.h || tr.w != to.w || tr.c != to.c) { rc = BMI_ERR_INVALID; break; }
                     in_st = in_st || tr.stoch;
                 }
-                const int64_t macs = (int64_t)op.ho * op.wo * op.cout * d.ksize * d.ksize * tin.c;
+                int64_t macs = (int64_t)op.ho * op.wo * op.cout * d.ksize * d.ksize * tin.c;
+                if (d.kind == BMI_OP_CONV && d.in2 >= 0) {
+                    if (!tensor_ok(d.in2) || !written[d.in2] || d.in2 == 0 || !d.weight2 || d.scale) { rc = BMI_ERR_INVALID; break; }
+                    const TensorInfo& t2 = e->tensors[d.in2];
+                    if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || t2.c % 64 != 0 || t2.h % op.ho != 0 ||
+                        t2.h / op.ho != t2.w / op.wo || t2.w % op.wo != 0 ||
+                        !conv_takes_patch_kernel(3, 1, 1, tin.c, op.cout, op.ho, op.wo)) {
+                        rc = BMI_ERR_UNSUPPORTED; break;
+                    }
+                    in_st = in_st || t2.stoch;
+                    macs += (int64_t)op.ho * op.wo * op.cout * t2.c;
+                }
                 if (!in_st && d.site.kind != BMI_SITE_NONE) {
                     // deterministic conv feeding a site: keep the conv in the once-per-batch prefix
                     // and apply the site while expanding to the folded sample batch.
@@ -198,6 +209,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     m.d.in = tmp_id;
                     m.d.out = d.out;
                     m.d.residual = -1;
+                    m.d.in2 = -1;
                     m.d.site = d.site;
                     m.stoch = true;
                     m.ho = to.h; m.wo = to.w; m.cout = to.c;
@@ -306,6 +318,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
             t.last = k;
         };
         touch(d.in);
+        if (d.kind == BMI_OP_CONV) touch(d.in2);
         touch(e->suffix[k].bits_tensor);
         if (d.kind == BMI_OP_CONV) touch(d.residual);
         if (d.kind != BMI_OP_HEAD) touch(d.out);
@@ -437,6 +450,13 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.B = B; a.t0 = t0;
             a.site = resolve_site(&d.site, seed, cnt0);
             a.out_mul = op.out_mul;
+            if (d.in2 >= 0) {
+                const TensorInfo& t2 = e->tensors[d.in2];
+                a.in2 = (const _Float16*)(ws + t2.offset);
+                a.wgt2 = (const _Float16*)d.weight2;
+                a.in2_mod = t2.stoch ? N : B;
+                a.H2 = t2.h; a.W2 = t2.w; a.Cin2 = t2.c; a.stride2 = t2.h / op.ho;
+            }
             if (op.bits_tensor >= 0) a.in_bits = (const uint8_t*)(ws + e->tensors[op.bits_tensor].offset);
             return launch_conv(a, s);
         }
@@ -580,6 +600,21 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
     a.in_bits = (const uint8_t*)in_keep_bits;
     a.out_mul = out_mul;
     return launch_conv(a, (hipStream_t)stream);
+}
+
+int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2, const void* weight2, const float* bias,
+                             void* out, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t cin2,
+                             int32_t relu, bmi_stream stream) {
+    if (!in || !weight || !in2 || !weight2 || !out) return BMI_ERR_INVALID;
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.bias = bias; a.out = (_Float16*)out;
+    a.N = n; a.in_mod = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.Ho = h; a.Wo = w;
+    a.ksize = 3; a.stride = 1; a.pad = 1; a.relu = relu; a.M = n * h * w; a.B = n; a.out_mul = 1.f;
+    a.in2 = (const _Float16*)in2; a.wgt2 = (const _Float16*)weight2; a.in2_mod = n; a.H2 = 2 * h; a.W2 = 2 * w;
+    a.Cin2 = cin2; a.stride2 = 2;
+    a.site = resolve_site(nullptr, 0, 0);
+    return launch_conv3x3_patch(a, (hipStream_t)stream);
 }
 
 static int elt_args(EltArgs& a, const void* in, void* out, int n, int in_mod, int hw, int c, const bmi_site* site, int batch,

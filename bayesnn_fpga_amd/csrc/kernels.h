@@ -16,6 +16,11 @@ struct ConvArgs {
     const uint8_t* in_bits;  // keep bits of an elementwise MC-dropout site on the INPUT (1 bit per element,
                              // byte g = elements 8g..8g+7 of the folded tensor), or null; conv_igemm only
     float out_mul;           // multiplies the folded-BN scale (the site's 1/(1-p) when in_bits is used), else 1
+    // fused 1x1 strided shortcut (conv3x3_patch only): out += conv1x1(in2; wgt2), both BN scales folded
+    // into the fp16 weights by the host, the biases summed (BasicBlock.forward :42-45 downsample path)
+    const _Float16* in2;     // [N or in2_mod][H2][W2][Cin2], or null
+    const _Float16* wgt2;    // [Cout][Cin2]
+    int in2_mod, H2, W2, Cin2, stride2;
     _Float16* out;
     int N;        // output images in this launch (= samples_in_chunk * B in the suffix)
     int in_mod;   // input image = n % in_mod  (B when the input is deterministic)

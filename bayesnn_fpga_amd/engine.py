@@ -69,7 +69,9 @@ class GraphBuilder:
             return dict(kind=_lib.SITE_MASKSEMBLE, site_id=sid, num_masks=module.n, masks=masks)
         return dict(kind=_lib.SITE_ELEMENTWISE, site_id=sid, p=float(module.p))
 
-    def conv(self, x, conv, bn, relu, residual=-1, site=None, stem=False):
+    def conv(self, x, conv, bn, relu, residual=-1, site=None, stem=False, shortcut=None):
+        """conv (+ folded BN) op.  ``shortcut=(x2, conv1x1, bn)`` fuses the BasicBlock downsample path into this
+        conv as extra K-steps: both BN scales are folded into the fp16 weights, the biases are summed."""
         h, w, cin = self.tensors[x]
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -80,6 +82,15 @@ class GraphBuilder:
             scale = torch.ones(conv.out_channels)
             bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels)
         wk = conv.weight.detach().permute(0, 2, 3, 1)          # [Cout][ky][kx][Cin]
+        in2, w2dev = -1, None
+        if shortcut is not None:
+            x2, conv_s, bn_s = shortcut
+            s_scale, s_bias = fold_bn(bn_s, conv_s.bias)
+            wk = wk.float() * scale[:, None, None, None]
+            w2dev = self.dev(conv_s.weight.detach().float()[:, :, 0, 0] * s_scale[:, None], torch.float16)   # [Cout][Cin2]
+            bias = bias + s_bias
+            scale = None
+            in2 = x2
         wdev = self.dev(wk, torch.float32 if stem else torch.float16)
         packed = None
         if (not stem and k == 3 and p == 1 and cin % 64 == 0 and conv.out_channels % 128 == 0
@@ -92,8 +103,9 @@ class GraphBuilder:
                 _lib.check(_lib.lib().bmi_pack_conv3x3_weights(wdev.data_ptr(), packed.data_ptr(), conv.out_channels, cin, st),
                            "bmi_pack_conv3x3_weights")
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
-                             stride=s, pad=p, relu=int(relu), weight=wdev, weight_packed=packed,
-                             scale=self.dev(scale, torch.float32), bias=self.dev(bias, torch.float32), site=site))
+                             stride=s, pad=p, relu=int(relu), weight=wdev, weight_packed=packed, in2=in2, weight2=w2dev,
+                             scale=self.dev(scale, torch.float32) if scale is not None else None,
+                             bias=self.dev(bias, torch.float32), site=site))
         return out
 
     def mask(self, x, site):
@@ -126,6 +138,18 @@ def _unwrap(module):
     return module, None
 
 
+def _can_fuse_shortcut(t_in, blk):
+    """The 1x1 strided downsample conv rides along in the 3x3 patch kernel when that kernel takes conv2
+    (16x16 / 8x8 / 4x4 maps, Cout % 128 == 0) and the block input has a multiple of 64 channels.
+    BMI_FUSE_SHORTCUT=0 keeps the separate launch + residual (A/B, tests)."""
+    if os.environ.get("BMI_FUSE_SHORTCUT", "1") == "0":
+        return False
+    h, w, c = t_in
+    ds = blk.downsample[0]
+    return ((h, w) in ((16, 16), (8, 8), (4, 4)) and blk.conv2.out_channels % 128 == 0 and c % 64 == 0
+            and ds.in_channels % 64 == 0 and ds.kernel_size == (1, 1) and ds.stride == (2, 2) and ds.bias is None)
+
+
 def build_resnet_graph(model, g):
     """Op sequence of the ResNet family forwards (reference resnet18.py:302-346 / :246-258 / :195-204)."""
     x = g.tensor(32, 32, 3)                                   # tensor 0: network input (fp32 NCHW)
@@ -140,11 +164,15 @@ def build_resnet_graph(model, g):
             blk, blk_site = _unwrap(blk)
             site_mod = blk_site if blk_site is not None else (stage_site if bi == len(blocks) - 1 else None)
             a = g.conv(x, blk.conv1, blk.bn1, relu=True)
-            res = x
-            if blk.downsample is not None:
-                res = g.conv(x, blk.downsample[0], blk.downsample[1], relu=False)
             # site ids follow call order: a block's site is allocated when the block finishes
-            x = g.conv(a, blk.conv2, blk.bn2, relu=True, residual=res, site=g.site(site_mod))
+            if blk.downsample is not None and _can_fuse_shortcut(g.tensors[a], blk):
+                x = g.conv(a, blk.conv2, blk.bn2, relu=True, site=g.site(site_mod),
+                           shortcut=(x, blk.downsample[0], blk.downsample[1]))
+            else:
+                res = x
+                if blk.downsample is not None:
+                    res = g.conv(x, blk.downsample[0], blk.downsample[1], relu=False)
+                x = g.conv(a, blk.conv2, blk.bn2, relu=True, residual=res, site=g.site(site_mod))
         if multi and si < 4:
             # exit head si: relu -> conv s2 -> bn chain, relu, avg-pool, [exit dropout], linear
             # (F.relu on a stage output is idempotent: it is already >= 0 and masks keep the sign)
@@ -213,7 +241,8 @@ class CompiledGraph:
             d = oarr[i]
             d.kind, d.in_, d.out, d.residual = op["kind"], op["in_"], op["out"], op.get("residual", -1)
             d.ksize, d.stride, d.pad, d.relu = op.get("ksize", 0), op.get("stride", 0), op.get("pad", 0), op.get("relu", 0)
-            for f in ("weight", "weight_packed", "scale", "bias"):
+            d.in2 = op.get("in2", -1)
+            for f in ("weight", "weight2", "weight_packed", "scale", "bias"):
                 t = op.get(f)
                 setattr(d, f, t.data_ptr() if t is not None else None)
             s = op.get("site")

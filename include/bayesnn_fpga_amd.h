@@ -91,10 +91,15 @@ typedef struct bmi_op_desc {
     int32_t in;        /* input tensor id                                              */
     int32_t out;       /* output tensor id; HEAD: exit index                           */
     int32_t residual;  /* CONV: tensor added before the ReLU, or -1                    */
+    int32_t in2;       /* CONV 3x3 stride-1: input of a fused 1x1 strided shortcut conv (the BasicBlock
+                          downsample path, resnet18.py:42-45) whose result is added before the ReLU, or -1.
+                          With in2 both BN scales must be folded into the fp16 weights (scale = NULL)
+                          and `bias` is the sum of the two BN biases.                               */
     int32_t ksize, stride, pad;
     int32_t relu;      /* apply ReLU after scale/bias(+residual)                       */
     const void* weight;  /* device; CONV fp16 [Cout][k][k][Cin]; STEM fp32 [Cout][k][k][Cin];
                             HEAD fp32 [ceil32(out_dim)][Cin]                           */
+    const void* weight2;       /* CONV with in2: device fp16 [Cout][Cin2] (BN scale folded in)          */
     const void* weight_packed; /* CONV 3x3: the same weights repacked by bmi_pack_conv3x3_weights
                                   (MFMA fragment order), or NULL to run the LDS-tile kernels */
     const float* scale;  /* device fp32 [Cout] folded BN scale (NULL = 1)              */
@@ -173,6 +178,12 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
                        void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
                        int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
+
+/* out = relu?( conv3x3_s1_p1(in; weight) + conv1x1_stride2(in2; weight2) + bias ), the fused BasicBlock tail
+ * with downsample (both BN scales folded into the weights); in2 is [n][2h][2w][cin2]. */
+int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2, const void* weight2, const float* bias,
+                             void* out, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t cin2,
+                             int32_t relu, bmi_stream stream);
 
 int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
                    int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);

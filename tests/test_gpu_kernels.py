@@ -246,3 +246,26 @@ def test_mask_bits_and_masked_input_conv():
     ref1 = torch.nn.functional.conv2d(xin, w1.float().cpu().permute(0, 3, 1, 2), stride=2)
     ref1 = ref1 * scale.cpu()[None, :, None, None] + bias.cpu()[None, :, None, None]
     torch.testing.assert_close(out1.float().cpu().permute(0, 3, 1, 2), ref1, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("name,cin2", [("S2", 64), ("S3", 128), ("S4", 256)])
+def test_conv3x3_with_fused_shortcut(name, cin2):
+    """BasicBlock tail with downsample in ONE launch: relu(conv3x3(a) + conv1x1_s2(x) + bias)."""
+    lib = _lib.lib()
+    cin, cout, H, _, _, _ = SHAPES[name]
+    n = 5
+    g = _gen(77)
+    a_in = torch.randn(n, H, H, cin, generator=g).to(torch.float16).to(DEV)
+    x_in = torch.randn(n, 2 * H, 2 * H, cin2, generator=g).to(torch.float16).to(DEV)
+    w = (torch.randn(cout, 3, 3, cin, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(torch.float16).to(DEV)
+    w2 = (torch.randn(cout, cin2, generator=g) * (1.0 / cin2) ** 0.5).to(torch.float16).to(DEV)
+    bias = (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    out = torch.full((n, H, H, cout), float("nan"), dtype=torch.float16, device=DEV)
+    _lib.check(lib.bmi_conv3x3_shortcut_fwd(gh.ptr(a_in), gh.ptr(w), gh.ptr(x_in), gh.ptr(w2), gh.ptr(bias), gh.ptr(out), n, H, H,
+                                            cin, cout, cin2, 1, gh.stream()), "bmi_conv3x3_shortcut_fwd")
+    torch.cuda.synchronize()
+    F_ = torch.nn.functional
+    ref = F_.conv2d(a_in.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), padding=1)
+    ref = ref + F_.conv2d(x_in.float().cpu().permute(0, 3, 1, 2), w2.float().cpu()[:, :, None, None], stride=2)
+    ref = torch.relu(ref + bias.cpu()[None, :, None, None])
+    torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3)
