@@ -120,6 +120,18 @@ class GraphBuilder:
         self.ops.append(dict(kind=_lib.OP_MAXPOOL, in_=x, out=out, residual=-1))
         return out
 
+    def dense(self, x, linear, relu, site=None):
+        """Hidden fully-connected layer on a [N,1,1,C] tensor as a 1x1 convolution (same MFMA kernel)."""
+        h, w, cin = self.tensors[x]
+        if (h, w) != (1, 1) or cin != linear.in_features:
+            raise ValueError("dense layers run on flattened [N,1,1,C] tensors")
+        out = self.tensor(1, 1, linear.out_features)
+        wk = linear.weight.detach().reshape(linear.out_features, 1, 1, cin)
+        self.ops.append(dict(kind=_lib.OP_CONV, in_=x, out=out, residual=-1, ksize=1, stride=1, pad=0, relu=int(relu),
+                             weight=self.dev(wk, torch.float16), weight_packed=None, in2=-1, weight2=None, scale=None,
+                             bias=self.dev(linear.bias, torch.float32), site=site))
+        return out
+
     def head(self, x, linear, exit_index, site=None):
         c_in = self.tensors[x][2]
         if linear.in_features != c_in:
@@ -188,6 +200,8 @@ def build_resnet_graph(model, g):
 
 def model_exits(model):
     """Number of logits tensors the reference forward returns (4 multi-exit, 1 single-exit)."""
+    if hasattr(model, "build_graph"):
+        return int(model.n_exits)
     if getattr(model, "family", "") == "vgg":
         return 5 if getattr(model, "multi_exit", True) else 1
     return 4 if getattr(model, "multi_exit", True) else 1
@@ -232,6 +246,10 @@ class CompiledGraph:
         _lib.check(self.lib.bmi_query(self.handle, C.byref(pm), C.byref(sm), C.byref(npo), C.byref(nso)), "bmi_query")
         self.prefix_macs, self.suffix_macs = pm.value, sm.value
         self.n_prefix_ops, self.n_suffix_ops = npo.value, nso.value
+        # MACs that do not run in the MFMA conv kernels (bench.py's roofline accounting): the direct stem and the heads
+        t = self.graph.tensors
+        self.stem_macs = sum(t[o["out"]][0] * t[o["out"]][1] * t[o["out"]][2] * 27 for o in self.graph.ops if o["kind"] == _lib.OP_STEM)
+        self.head_macs = sum(t[o["in_"]][2] * self.out_dim for o in self.graph.ops if o["kind"] == _lib.OP_HEAD)
 
     def _make_desc(self):
         g = self.graph

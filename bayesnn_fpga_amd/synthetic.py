@@ -13,6 +13,13 @@ import torch
 from torch import nn
 
 
+def _parent(model, name):
+    mod = model
+    for part in name.split(".")[:-1]:
+        mod = getattr(mod, part)
+    return mod
+
+
 def synthetic_weights_(model, seed=0):
     g = torch.Generator().manual_seed(int(seed) + 7919)
     for name, m in model.named_modules():
@@ -20,7 +27,9 @@ def synthetic_weights_(model, seed=0):
             c = m.num_features
             leaf = name.rsplit(".", 1)[-1]
             # bn2 / downsample BN close a residual branch; keep the stream's variance bounded
-            gain = 0.6 if (leaf == "bn2" or ".downsample." in name) else 1.0
+            closes_branch = (leaf == "bn3" or ".downsample." in name or
+                             (leaf == "bn2" and not hasattr(_parent(model, name), "bn3")))
+            gain = 0.3 if leaf == "bn3" else (0.6 if closes_branch else 1.0)   # 16 bottleneck blocks: smaller gain
             with torch.no_grad():
                 m.weight.copy_((0.8 + 0.4 * torch.rand(c, generator=g)) * gain)
                 m.bias.copy_(0.1 * torch.randn(c, generator=g))
@@ -30,8 +39,12 @@ def synthetic_weights_(model, seed=0):
             # default Linear init gives near-uniform softmax outputs; widen the logits so the
             # predictive distribution is peaked like a trained classifier's (ECE is then meaningful)
             with torch.no_grad():
-                m.weight.copy_(0.4 * torch.randn(m.weight.shape, generator=g))
-                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                if m.out_features <= 128:      # classifier
+                    m.weight.copy_(0.4 * torch.randn(m.weight.shape, generator=g))
+                    m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                else:                          # hidden fully-connected layer: variance preserving
+                    m.weight.copy_((2.0 / m.in_features) ** 0.5 * torch.randn(m.weight.shape, generator=g))
+                    m.bias.copy_(0.05 * torch.randn(m.bias.shape, generator=g))
     return model
 
 

@@ -37,14 +37,41 @@ if ROOT not in sys.path:
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16, MI355X_MICROARCH.md §Chip-level parameters
 MODEL_KW = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
 
+# name -> (package class, oracle class, kwargs, batch, T, description).  The default is the configuration BASELINE.json's
+# metric is quoted on; the others are measurement aids for the remaining GPU configs (not the driver's bench line).
+WORKLOADS = {
+    "resnet18_me": ("bayesnn_fpga_amd.models.resnet18.resnet18:ResNet18MCEarlyExit", "oracle.resnet18:ResNet18MCEarlyExit",
+                    MODEL_KW, 250, 100,
+                    "ResNet18MCEarlyExit C=10 dropout=block+exit p=0.25, batch 250 x T=100 (BASELINE configs[2])"),
+    "vgg11": ("bayesnn_fpga_amd.models.extra:VGG11MC", "oracle.extra_models:VGG11MC",
+              dict(num_bayes_layer=3, dropout_p=0.25, out_dim=10), 250, 30,
+              "VGG11MC (build-defined) C=10, 3 dropout sites p=0.25, batch 250 x T=30 (BASELINE configs[1])"),
+    "resnet18_masksembles": ("bayesnn_fpga_amd.models.resnet18.resnet18:ResNet18MCEarlyExit",
+                             "oracle.resnet18:ResNet18MCEarlyExit",
+                             dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=100, mask_type="mask",
+                                  num_masks=8, mask_scale=4.0), 250, 8,
+                             "ResNet18MCEarlyExit C=100 Masksembles M=8 block+exit, batch 250 x T=8 (BASELINE configs[3])"),
+    "resnet50_me": ("bayesnn_fpga_amd.models.extra:ResNet50MCEarlyExit", "oracle.extra_models:ResNet50MCEarlyExit",
+                    MODEL_KW, 250, 64,
+                    "ResNet50MCEarlyExit (build-defined) C=10 dropout=block+exit p=0.25, batch 250 x T=64 "
+                    "(one GPU's share of BASELINE configs[4])"),
+}
+
+
+def _load(spec):
+    import importlib
+    mod, name = spec.split(":")
+    return getattr(importlib.import_module(mod), name)
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=250)
-    ap.add_argument("--T", type=int, default=100)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="resnet18_me")
+    ap.add_argument("--batch", type=int, default=0, help="images per batch (0 = the workload's)")
+    ap.add_argument("--T", type=int, default=0, help="MC samples per image (0 = the workload's)")
     ap.add_argument("--chunk", type=int, default=0, help="MC samples folded per suffix launch (0 = engine default)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,14 +79,14 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch, T, seed):
+def cpu_baseline(wl, batch, T, seed):
     """The oracle (port of FullAnalysis._get_output, T sequential full forwards per batch, fp32) on
     the host cores.  Returns (MCD-samples/s, threads, mean probs)."""
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
     from oracle import mcd
-    from oracle import resnet18 as oresnet
     torch.manual_seed(0)
-    m = synthetic_weights_(oresnet.ResNet18MCEarlyExit(**MODEL_KW), 0)
+    np.random.seed(0)
+    m = synthetic_weights_(_load(wl[1])(**wl[2]), 0)
     x = synthetic_images(batch, seed=1234)
     mcd.mcd_predict(m, x[:8], 1, seed)          # warm the allocator / oneDNN primitives
     t0 = time.perf_counter()
@@ -86,14 +113,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
     from bayesnn_fpga_amd.sharding import shard_range
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
     from bayesnn_fpga_amd.train.metrics import ece_hist_binary
 
+    wl = WORKLOADS[a.workload]
+    kw = wl[2]
     torch.manual_seed(0)
-    model = synthetic_weights_(ResNet18MCEarlyExit(**MODEL_KW), 0).to(dev).eval()
-    B, T = a.batch, a.T
+    np.random.seed(0)
+    model = synthetic_weights_(_load(wl[0])(**kw), 0).to(dev).eval()
+    B, T = a.batch or wl[3], a.T or wl[4]
     eng = model.engine(dev, max_batch=B, chunk_samples=a.chunk or None)
     x = synthetic_images(B, seed=1234).to(dev)
     t_lo, t_hi = shard_range(T, rank, world)
@@ -137,22 +166,20 @@ def main():
         value = samples / dt
         my_T = t_hi - t_lo
         # conv FLOPs of rank 0's profiled step: prefix convs once + suffix convs x its samples
-        head_macs = 4 * 512 * MODEL_KW["out_dim"]
-        conv_flops = 2.0 * B * ((eng.prefix_macs) + my_T * (eng.suffix_macs - head_macs))
+        conv_flops = 2.0 * B * ((eng.prefix_macs) + my_T * (eng.suffix_macs - eng.head_macs))
         conv_ms, conv_launches = prof.get("conv_igemm", (0.0, 0))
-        stem_ms = prof.get("stem", (0.0, 0))[0]
-        conv_flops -= 2.0 * B * 1769472              # the 3-channel stem runs in its own direct kernel
+        conv_flops -= 2.0 * B * eng.stem_macs        # the 3-channel stem runs in its own direct kernel
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         mean = out["mean"].cpu().numpy()
-        labels = synthetic_labels(B, MODEL_KW["out_dim"], seed=1235).numpy()
-        onehot = np.eye(MODEL_KW["out_dim"])[labels]
+        labels = synthetic_labels(B, kw["out_dim"], seed=1235).numpy()
+        onehot = np.eye(kw["out_dim"])[labels]
         line = {
-            "metric": "MCD-samples/sec (T x images/s) + ECE, ResNet-18 multi-exit T=100",
+            "metric": "MCD-samples/sec (T x images/s) + ECE, ResNet-18 multi-exit T=100" if a.workload == "resnet18_me"
+                      else f"MCD-samples/sec (T x images/s) + ECE, {a.workload} T={T}",
             "value": round(value, 1), "unit": "MCD-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ResNet18MCEarlyExit C=10 dropout=block+exit p=0.25, batch 250 x T=100 "
-                                   "(BASELINE configs[2])",
+            "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
                        "sharding": f"T over {world} rank(s), one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
@@ -165,7 +192,7 @@ def main():
                          "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
         }
         if not a.no_cpu_baseline:
-            cpu_val, threads, cpu_mean = cpu_baseline(B, a.cpu_T, a.seed)
+            cpu_val, threads, cpu_mean = cpu_baseline(wl, B, a.cpu_T, a.seed)
             gpu_same = eng.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()
             line["cpu_baseline"] = {
                 "value": round(cpu_val, 1), "unit": "MCD-samples/s", "cores": threads, "kind": "port",
