@@ -276,6 +276,27 @@ class CompiledGraph:
         """Executed-algorithmic FLOPs (prefix once + T x suffix), conv + linear only, 1 MAC = 2 FLOP."""
         return 2 * batch * (self.prefix_macs + T * self.suffix_macs)
 
+    def conv_traffic_model(self, batch, T):
+        """Algorithmic HBM bytes and launch count of the MFMA conv kernels for one batch x T samples: every conv reads
+        its input (+ residual / shortcut input) and weights once and writes its output once, fp16.  A conv whose inputs
+        are all deterministic runs once per batch (prefix), the others once per chunk of ``chunk_samples`` samples."""
+        t, stoch = self.graph.tensors, set()
+        chunks = -(-T // self.chunk_samples)
+        total, launches = 0, 0
+        for o in self.graph.ops:
+            ins = [o["in_"]] + [o[k] for k in ("residual", "in2") if o.get(k, -1) is not None and o.get(k, -1) >= 0]
+            det = not any(i in stoch for i in ins)
+            if o["kind"] != _lib.OP_HEAD and (o.get("site") or not det):
+                stoch.add(o["out"])
+            if o["kind"] != _lib.OP_CONV:
+                continue
+            px = lambda i: t[i][0] * t[i][1] * t[i][2] * 2
+            act = sum(px(i) for i in ins) + px(o["out"])
+            wb = sum(o[k].numel() * 2 for k in ("weight", "weight2") if o.get(k) is not None)
+            total += batch * act * (1 if det else T) + wb * (1 if det else chunks)
+            launches += 1 if det else chunks
+        return total, launches
+
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
             self.lib.bmi_destroy(self.handle)

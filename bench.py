@@ -79,6 +79,19 @@ def parse():
     return ap.parse_args()
 
 
+def hbm_traffic(workload, launches_per_step):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py
+    -> profiles/hbm_traffic_<workload>.json; FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes).  None when absent."""
+    path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
+    if not os.path.exists(path):
+        return None, None
+    ks = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm_kernel", "conv3x3_patch_kernel"))}
+    n = sum(v["launches"] for v in ks.values())
+    if n == 0 or n % launches_per_step:
+        return None, None                   # collected for another batch / T / chunking: do not quote it
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / n, os.path.relpath(path, ROOT)
+
+
 def cpu_baseline(wl, batch, T, seed):
     """The oracle (port of FullAnalysis._get_output, T sequential full forwards per batch, fp32) on
     the host cores.  Returns (MCD-samples/s, threads, mean probs)."""
@@ -88,7 +101,9 @@ def cpu_baseline(wl, batch, T, seed):
     np.random.seed(0)
     m = synthetic_weights_(_load(wl[1])(**wl[2]), 0)
     x = synthetic_images(batch, seed=1234)
-    mcd.mcd_predict(m, x[:8], 1, seed)          # warm the allocator / oneDNN primitives
+    import copy
+    mcd.mcd_predict(copy.deepcopy(m), x[:8], 1, seed)   # warm the allocator / oneDNN primitives (on a copy: Masksembles
+                                                        # layers count their calls, the timed model must start at mask 0)
     t0 = time.perf_counter()
     r = mcd.mcd_predict(m, x, T, seed)
     dt = time.perf_counter() - t0
@@ -170,6 +185,8 @@ def main():
         conv_ms, conv_launches = prof.get("conv_igemm", (0.0, 0))
         conv_flops -= 2.0 * B * eng.stem_macs        # the 3-channel stem runs in its own direct kernel
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        alg_bytes, alg_launches = eng.conv_traffic_model(B, my_T)
+        traffic, traffic_src = hbm_traffic(a.workload, alg_launches) if (world == 1 and not a.batch and not a.T and not a.chunk) else (None, None)
         mean = out["mean"].cpu().numpy()
         labels = synthetic_labels(B, kw["out_dim"], seed=1235).numpy()
         onehot = np.eye(kw["out_dim"])[labels]
@@ -187,7 +204,11 @@ def main():
             "tflops_naive_equiv": round(2.0 * (eng.prefix_macs + eng.suffix_macs) * samples / dt / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one step)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None if traffic is None else round(traffic),
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_launches, 1)),
+                         "algorithmic_flops_per_launch": round(conv_flops / max(conv_launches, 1)),
                          "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                          "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
         }

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile_bench.sh <workload> <tag>
+# Kernel-trace stats pass + the two PMC passes of `python3 bench.py --workload W` -> gpurun_out/<tag>_*; then
+# copy what is to be judged into profiles/ (see DESIGN.md §Measurement).
+set -e
+W=${1:-resnet18_me}; TAG=${2:-prof}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd /tmp
+ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_write.log 2>&1
+cd $R
+python3 tools/pmc_summary.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/hbm_traffic_$W.json --note "bench.py $ARGS"
+find gpurun_out/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
+tail -1 gpurun_out/${TAG}_stats.log
