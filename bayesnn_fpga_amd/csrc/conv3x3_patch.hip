@@ -85,7 +85,7 @@ struct PatchGeom {
 #define BMI_PATCH_SWPIPE 0
 #endif
 
-template <int S, int TH, int TW, int IMGS, int TJ, int NB>
+template <int S, int TH, int TW, int IMGS, int TJ, int NB, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     constexpr bool WDMA = BMI_PATCH_WDMA != 0;
     static_assert(NB == 2 || WDMA, "deeper weight prefetch is implemented for the LDS-DMA path");
@@ -362,7 +362,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         rem = (y0 + oy) * a.Wo + x0 + ox;
         return n < a.N;
     };
-    epilogue_coalesced<TJ>(a, acc, smem, tid, ch0, pixmap);
+    auto offmap = [&](int p, size_t& off) -> bool {
+        int n, rem;
+        const bool ok = pixmap(p, n, rem);
+        off = ((size_t)n * (a.Ho * a.Wo) + rem) * a.Cout;
+        return ok;
+    };
+    epilogue_coalesced<TJ, PLAIN>(a, acc, smem, tid, ch0, pixmap, offmap);
     STAMP(3);
 }
 
@@ -370,7 +376,8 @@ template <int S, int TH, int TW, int IMGS, int TJ, int NB = 2>
 static int launch_patch(const ConvArgs& a, hipStream_t s) {
     const long tiles = (long)((a.N + IMGS - 1) / IMGS) * (a.Ho / TH) * (a.Wo / TW) * (a.Cout / 128);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<S, TH, TW, IMGS, TJ, NB>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv3x3_patch_kernel<S, TH, TW, IMGS, TJ, NB, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<S, TH, TW, IMGS, TJ, NB, false>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

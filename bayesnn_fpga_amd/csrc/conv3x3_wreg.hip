@@ -251,7 +251,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wreg_kernel(ConvArgs a) {
         rem = (y0 + oy) * a.Wo + x0 + ox;
         return n < a.N;
     };
-    epilogue_coalesced<TJ>(a, acc, smem, tid, ch0, pixmap);
+    auto offmap = [&](int p, size_t& off) -> bool {
+        int n, rem;
+        const bool ok = pixmap(p, n, rem);
+        off = ((size_t)n * (a.Ho * a.Wo) + rem) * a.Cout;
+        return ok;
+    };
+    epilogue_coalesced<TJ, false>(a, acc, smem, tid, ch0, pixmap, offmap);
     WSTAMP(3);
 }
 

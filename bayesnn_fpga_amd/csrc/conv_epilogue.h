@@ -111,6 +111,8 @@ typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
 
 #define BMI_EPILOGUE_LDS_BYTES 65536
 
+__host__ __device__ inline bool conv_epilogue_is_plain(const ConvArgs& a) { return !a.res && a.site.kind == BMI_SITE_NONE; }
+
 // LDS-only barrier: the epilogue's global stores / outstanding residual loads must NOT be drained
 // at the round boundaries (a __syncthreads() would add s_waitcnt vmcnt(0)).
 __device__ __forceinline__ void lds_barrier() {
@@ -119,10 +121,89 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int TJ, class PixMap>
+// Plain epilogue (no residual, no stochastic site: 15 of the 18 suffix convs of ResNet-18 multi-exit): BN and
+// ReLU are applied on the accumulators, the fp16 results make ONE trip through LDS (the whole 128-channel x
+// 64*TJ-pixel tile is 16*TJ KB as fp16, a single round: one barrier instead of four, half the LDS bytes) and
+// leave as 256-byte NHWC row segments.  Same arithmetic as epilogue_coalesced (fma-free scale, bias, max), so a
+// conv gives the same bits whichever epilogue finishes it.
+//   LDS tile [64*TJ pixels][128 ch] fp16, 256-byte rows; the 16-byte chunk q (8 channels) of pixel row p lives at
+//   chunk q ^ (p & 15), and its two 8-byte quads are swapped when (p >> 4) & 1: the 32 lanes of a ds_write_b64
+//   (32 pixels, one channel quad) then hit 32 distinct 8-byte bank pairs.
+template <int TJ, class OffMap>
+__device__ __forceinline__ void epilogue_plain(const ConvArgs& a, f32x16_e (&acc)[2][TJ], char* lds, int tid, int ch0, OffMap offmap) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wc = wave >> 1, wp = wave & 1;
+    // BN vectors of the 8 channel quads this lane holds (channel = ch0 + wc*64 + 32*i + 8*g4 + 4*hh), fetched one
+    // quad ahead of their use: all eight at once would be 64 VGPRs on top of the 128 accumulators
+    const int cl = ch0 + wc * 64 + 4 * hh;
+#define BMI_EPI_BN(Q, SC, BI)                                                          \
+    {                                                                                  \
+        const int c4_ = cl + 32 * ((Q) >> 2) + 8 * ((Q) & 3);                          \
+        SC = f32x4_e{1.f, 1.f, 1.f, 1.f};                                              \
+        BI = f32x4_e{0.f, 0.f, 0.f, 0.f};                                              \
+        if (a.scale) SC = *(const f32x4_e*)(a.scale + c4_);                            \
+        if (a.bias) BI = *(const f32x4_e*)(a.bias + c4_);                              \
+        SC *= a.out_mul;                                                               \
+    }
+    f32x4_e scn, bin;
+    BMI_EPI_BN(0, scn, bin);
+    const int hsw = hh ^ ((r >> 4) & 1);
+    lds_barrier();   // the main loop is done with the LDS
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4_e sc = scn, bi = bin;
+        if (q < 7) { BMI_EPI_BN(q + 1, scn, bin); }
+        const int i = q >> 2, g4 = q & 3;
+        const int cq = wc * 8 + 4 * i + g4;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int p = wp * (32 * TJ) + 32 * j + r;
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[i][j][4 * g4 + e] * sc[e] + bi[e];
+                if (a.relu) v = fmaxf(v, 0.f);
+                o[e] = (_Float16)v;
+            }
+            *(half4*)(lds + p * 256 + ((cq ^ (r & 15)) << 4) + hsw * 8) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef BMI_EPI_BN
+    lds_barrier();
+    // phase 2: 64*TJ pixels x 16 chunks of 8 channels, 4*TJ per thread.  All LDS reads are issued before the first
+    // store (the accumulators are dead: registers are free), rows beyond the tensor are only skipped at the store.
+    const int k = tid & 15;
+    half8_e o[4 * TJ];
+#pragma unroll
+    for (int it = 0; it < 4 * TJ; ++it) {
+        const int pl = (tid >> 4) + 16 * it;
+        o[it] = *(const half8_e*)(lds + pl * 256 + ((k ^ (pl & 15)) << 4));
+    }
+#pragma unroll
+    for (int it = 0; it < 4 * TJ; ++it) {
+        const int pl = (tid >> 4) + 16 * it;
+        size_t off;
+        if (!offmap(pl, off)) continue;
+        half8_e v = o[it];
+        if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);   // (pl >> 4) & 1 == it & 1: quads swapped
+        *(half8_e*)(a.out + off + ch0 + 8 * k) = v;
+    }
+}
+
+// pixmap(p, n, rem) -> bool: tile pixel p -> image n and y*Wo+x (false beyond the tensor);
+// offmap(p, off) -> bool: the same pixel's element offset in the output tensor (no division for linear tiles).
+// PLAIN (chosen per launch: no residual, no site) selects epilogue_plain at compile time: with both paths in one
+// kernel the register allocator spills 56-80 VGPRs in the other one.
+template <int TJ, bool PLAIN, class PixMap, class OffMap>
 __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (&acc)[2][TJ], char* lds, int tid, int ch0,
-                                                   PixMap pixmap) {
+                                                   PixMap pixmap, OffMap offmap) {
     static_assert(TJ == 2 || TJ == 4, "two pixel tiles per round");
+    if constexpr (PLAIN) {
+        epilogue_plain<TJ>(a, acc, lds, tid, ch0, offmap);
+        return;
+    }
     constexpr int NR = TJ / 2;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;

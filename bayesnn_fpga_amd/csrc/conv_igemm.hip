@@ -30,7 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK>
+template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TI = BC / WC / 32;   // 32x32 MFMA tiles per wave along channels
     constexpr int TJ = BP / WP / 32;   // ... along pixels
@@ -187,7 +187,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             rem = m - n * HoWo;
             return m < a.M;
         };
-        epilogue_coalesced<TJ>(a, acc, smem, tid, ch0, pixmap);
+        auto offmap = [&](int p, size_t& off) -> bool {
+            off = (size_t)(pix0 + p) * a.Cout;
+            return pix0 + p < a.M;
+        };
+        epilogue_coalesced<TJ, PLAIN>(a, acc, smem, tid, ch0, pixmap, offmap);
     } else {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -216,7 +220,10 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     const long n_ptiles = ((long)a.M + BP - 1) / BP;
     const long blocks = n_ptiles * n_ctiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (BC == 128 && conv_epilogue_is_plain(a))   // the 64-channel tiles use the per-quad epilogue: one instantiation
+        hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, BC == 128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

@@ -1,0 +1,276 @@
+// Wide-tile implicit-GEMM convolution for gfx950: 256 output channels x 256 pixels x 64 deep per K-step,
+// 512 threads (8 waves), both operand tiles filled by LDS-DMA into a double-buffered 2 x 64 KB LDS ring.
+//
+// Why a second per-tap kernel: the stride-2 3x3 convs (BasicBlock conv1 of layers 2-4 and every exit-head
+// conv, SA/models/resnet18/resnet18.py:280-299, :306-329) and the 1x1 convs of Bottleneck nets cannot keep
+// an input patch in LDS (a stride-2 patch is 4x the bytes per output pixel), so every K-step streams an
+// activation tile AND a weight tile from L2.  With conv_igemm's 128 x 256 tile that is 48 KB per 4.2 MFLOP,
+// register-staged and single-buffered: measured 540-740 TFLOP/s on these shapes against 930-1030 for the
+// patch kernel.  Here the tile is 256 x 256 (64 KB per 8.4 MFLOP: 1.5x fewer L2->LDS bytes per FLOP, half
+// the barriers per FLOP), nothing is staged through VGPRs, and the next K-step's tiles are in flight
+// while the current one computes (one barrier per K-step).
+//
+//   waves      = 2 channel halves (g) x [2 (channels) x 2 (pixels)]: each wave owns 64 ch x 128 px
+//                (2 x 4 tiles of v_mfma_f32_32x32x16_f16), exactly the wave tile of conv_igemm<128,256>
+//   LDS rows   = 128 B (64 fp16 of one weight row / one pixel); 16-byte chunk c of row r is stored at
+//                chunk c ^ ((r >> 1) & 7) (conflict-free ds_read_b128); the DMA writes lane-linearly, so
+//                the permutation is applied to the per-lane SOURCE address
+//   padding    = out-of-image taps and tile rows beyond M are DMA'd from a zero page
+//   epilogue   = each channel half runs conv_epilogue.h's coalesced epilogue in its own 64 KB of the ring
+//   pair mode  = two convs that read the SAME input with the same geometry (layerN.0.conv1 and the first
+//                conv of the exit head before it) run as one launch: channel tiles below `split` use the
+//                first conv's weights / BN / output tensor, the others the second's.  The input tile is
+//                then fetched once for both, and a 128-channel conv still fills the 256-channel tile.
+#include <cstdlib>
+
+#include "conv_epilogue.h"
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static __device__ unsigned int g_zero_page_w[64];   // 256 B of zeros (DMA source for padding / tail rows)
+
+#define GLDS16(SRC, LDSPTR)                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),       \
+                                     (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
+
+#ifdef BMI_WIDE_STAMPS
+// Diagnostic build only (tools/ab_build.py stamps:-DBMI_WIDE_STAMPS): phase timestamps of wave 0 of each workgroup.
+__device__ unsigned long long g_wide_stamps[8192 * 8];
+#define STAMP(SLOT) if (tid == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 8 + (SLOT)] = __builtin_readcyclecounter();
+#if BMI_WIDE_STAMPS >= 2   // per-K-step accumulators (each costs wave 0 a global round trip: inflates the main loop)
+#define STAMP_ADD(SLOT, T0) if (tid == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 8 + (SLOT)] += __builtin_readcyclecounter() - (T0);
+#define STAMP_T0(V) const unsigned long long V = __builtin_readcyclecounter();
+#else
+#define STAMP_ADD(SLOT, T0)
+#define STAMP_T0(V)
+#endif
+extern "C" int bmi_debug_wide_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}
+extern "C" int bmi_debug_wide_stamps_clear() {
+    static unsigned long long z[8192 * 8];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stamps), z, sizeof(z)) == hipSuccess ? 0 : -5;
+}
+#else
+#define STAMP(SLOT)
+#define STAMP_ADD(SLOT, T0)
+#define STAMP_T0(V)
+#endif
+
+#ifndef BMI_WIDE_PIPE
+#define BMI_WIDE_PIPE 0
+#endif
+#define WBC 256
+#define WBP 256
+#define WSTAGE ((WBC + WBP) * 128)
+
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
+    constexpr int TI = 2, TJ = 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE];
+    static_assert(2 * WSTAGE == 2 * BMI_EPILOGUE_LDS_BYTES, "one epilogue staging area per channel half");
+
+    const int tid = threadIdx.x;
+    STAMP(0);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
+
+    const int n_ctiles = a.Cout / WBC;
+    int ptile, ctile;
+    xcd_tile_map(blockIdx.x, (a.M + WBP - 1) / WBP, n_ctiles, ptile, ctile);
+    const int ch0 = ctile * WBC;
+    const int pix0 = ptile * WBP;
+    const int HoWo = a.Ho * a.Wo;
+    const int Ktot = a.ksize * a.ksize * a.Cin;
+    const int split = a.wgt_b ? a.split : a.Cout;
+
+    // ---- per-thread DMA sources: piece q = tid + 512*i -> tile row (q >> 3) = 64*i + (tid >> 3), slot tid & 7 ----
+    const int rowt = tid >> 3;
+    const int srcchunk = ((tid & 7) ^ ((rowt >> 1) & 7)) * 8;   // (64*i >> 1) & 7 == 0: the same for all i
+    const _Float16* wsrc[4];
+    const _Float16* xsrc[4];
+    int iy0[4], ix0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = ch0 + 64 * i + rowt;
+        wsrc[i] = (ch < split ? a.wgt + (size_t)ch * Ktot : a.wgt_b + (size_t)(ch - split) * Ktot) + srcchunk;
+        const int m = pix0 + 64 * i + rowt;
+        const bool vm = m < a.M;
+        const int mm = vm ? m : 0;
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;       // a row beyond M never passes the bounds test
+        ix0[i] = ox * a.stride - a.pad;
+        xsrc[i] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + srcchunk;
+    }
+    // One row block (64 rows = 8 KB) of the weight / activation tile per call: the fills of the NEXT K-step are
+    // spread over the MFMAs of the current one (2 DMA instructions per 8 MFMAs per wave).  Issued as one burst
+    // after the barrier they cost ~960 cycles per K-step during which no wave of the workgroup issues an MFMA
+    // (phase stamps, tools/wide_stamps.py): 64 KB per K-step at the CU's 64 B/clk vector-memory path.
+#define ISSUE_W(I, KOFF, ST)  GLDS16(wsrc[I] + (KOFF), (ST) + ((I) * 512 + wave * 64) * 16)
+#define ISSUE_X(I, KY, KX, C0, ST)                                                                     \
+    {                                                                                                  \
+        const int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                            \
+        const bool ok_ = (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;               \
+        const _Float16* s_ = ok_ ? xsrc[I] + (size_t)(iy_ * a.W + ix_) * a.Cin + (C0)                  \
+                                 : (const _Float16*)g_zero_page_w;                                     \
+        GLDS16(s_, (ST) + WBC * 128 + ((I) * 512 + wave * 64) * 16);                                   \
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int a_off = (g * 128 + wc * 64 + r) * 128;
+    const int b_off = WBC * 128 + (wp * 128 + r) * 128;
+    const int sw_r = (r >> 1) & 7;
+
+#if BMI_WIDE_PIPE
+    half8 fa[2][TI], fb[2][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) fa[1][i] = half8{0, 0, 0, 0, 0, 0, 0, 0};   // the first "previous substep" adds zero
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) fb[1][j] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const int nK = a.ksize * a.ksize * (a.Cin / 64);
+    int ky = 0, kx = 0, c0 = 0;
+    {
+        char* st0 = smem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ISSUE_W(i, 0, st0);
+            ISSUE_X(i, 0, 0, 0, st0);
+        }
+    }
+    for (int ks = 0; ks < nK; ++ks) {
+        const int buf = ks & 1;
+        STAMP_T0(tw0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP_ADD(4, tw0);
+        __syncthreads();   // this step's tiles have landed; every wave is done reading the other buffer
+        STAMP_ADD(5, tw0);
+        if (ks == 0) { STAMP(1); }
+        STAMP_T0(tw1);
+        // next K-step's (tap, chunk); after the last step the same tiles are fetched once more into the idle
+        // buffer (no branch in the MFMA stream; drained before the epilogue reuses the LDS)
+        if (ks + 1 < nK) {
+            c0 += 64;
+            if (c0 == a.Cin) {
+                c0 = 0;
+                if (++kx == a.ksize) { kx = 0; ++ky; }
+            }
+        }
+        const int koff = (ky * a.ksize + kx) * a.Cin + c0;
+        char* nst = smem + (buf ^ 1) * WSTAGE;
+        const char* st = smem + buf * WSTAGE;
+#if BMI_WIDE_PIPE
+        // Fragment reads run one k-substep ahead in a second register set, and the MFMAs of a K-step's LAST substep
+        // are issued after the NEXT step's barrier: they cover the LDS latency of the first reads behind the barrier
+        // and keep the matrix pipe fed while the wave waits at it (one workgroup per CU: nobody else would).
+#define RD(KK, SET)                                                                                     \
+    {                                                                                                   \
+        const int coff_ = ((2 * (KK) + hh) ^ sw_r) << 4;                                                \
+        _Pragma("unroll") for (int i = 0; i < TI; ++i) fa[SET][i] = *(const half8*)(st + a_off + i * 32 * 128 + coff_); \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) fb[SET][j] = *(const half8*)(st + b_off + j * 32 * 128 + coff_); \
+    }
+#define MM(SET, I) _Pragma("unroll") for (int j = 0; j < TJ; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I], fb[SET][j], acc[I][j], 0, 0, 0);
+        RD(0, 0);
+        MM(1, 0); ISSUE_W(0, koff, nst); __builtin_amdgcn_sched_barrier(0);
+        MM(1, 1); ISSUE_X(0, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
+        RD(1, 1);
+        MM(0, 0); ISSUE_W(1, koff, nst); __builtin_amdgcn_sched_barrier(0);
+        MM(0, 1); ISSUE_X(1, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
+        RD(2, 0);
+        MM(1, 0); ISSUE_W(2, koff, nst); __builtin_amdgcn_sched_barrier(0);
+        MM(1, 1); ISSUE_X(2, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
+        RD(3, 1);
+        MM(0, 0); ISSUE_W(3, koff, nst); __builtin_amdgcn_sched_barrier(0);
+        MM(0, 1); ISSUE_X(3, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int coff = ((2 * kk + hh) ^ sw_r) << 4;
+            half8 af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(st + a_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(st + b_off + j * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[j], acc[0][j], 0, 0, 0);
+            ISSUE_W(kk, koff, nst);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[j], acc[1][j], 0, 0, 0);
+            ISSUE_X(kk, ky, kx, c0, nst);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        STAMP_ADD(6, tw1);
+    }
+#if BMI_WIDE_PIPE
+    MM(1, 0);
+    MM(1, 1);
+#undef RD
+#undef MM
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef ISSUE_W
+#undef ISSUE_X
+    STAMP(2);
+
+    // ---- epilogue: each channel half (4 waves) in its own 64 KB ------------------------------------
+    ConvArgs b = a;
+    int chg = ch0 + 128 * g;
+    if (a.wgt_b) {
+        if (chg >= split) {
+            b.out = a.out_b; b.scale = a.scale_b; b.bias = a.bias_b;
+            b.Cout = a.Cout - split;
+            chg -= split;
+        } else {
+            b.Cout = split;
+        }
+    }
+    auto pixmap = [&](int p, int& n, int& rem) -> bool {
+        const int m = pix0 + p;
+        n = m / HoWo;
+        rem = m - n * HoWo;
+        return m < a.M;
+    };
+    auto offmap = [&](int p, size_t& off) -> bool {
+        off = (size_t)(pix0 + p) * b.Cout;
+        return pix0 + p < a.M;
+    };
+    epilogue_coalesced<TJ, PLAIN>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+    STAMP(3);
+}
+
+// Shapes the wide kernel takes.  `cout` is the launch's total channel count (both convs of a pair).
+bool conv_takes_wide_kernel(int cin, int cout) {
+    static const int on = [] { const char* v = std::getenv("BMI_IGEMM_WIDE"); return v ? std::atoi(v) : 1; }();
+    return on && cin % 64 == 0 && cout % WBC == 0;
+}
+
+int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s) {
+    if (!conv_takes_wide_kernel(a.Cin, a.Cout) || a.in2 || a.in_bits) return BMI_ERR_UNSUPPORTED;
+    if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
+    if (a.wgt_b) {
+        if (!a.out_b || a.split <= 0 || a.split >= a.Cout || a.split % 128 != 0 || a.res || a.site.kind != BMI_SITE_NONE)
+            return BMI_ERR_INVALID;
+    }
+    const long blocks = (((long)a.M + WBP - 1) / WBP) * (a.Cout / WBC);
+    if (blocks > 0x7fffffffL) return BMI_ERR_INVALID;
+    if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL(conv_igemm_wide_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv_igemm_wide_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, s, a);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}

@@ -37,6 +37,9 @@ struct OpInfo {
     int ho = 0, wo = 0, cout = 0;
     int bits_tensor = -1;   // CONV: keep bits applied to the input while staging, or -1
     float out_mul = 1.f;    // CONV: multiplies the folded-BN scale (1/(1-p) of the input-side site)
+    bool has_pair = false;  // CONV: a second conv on the same input rides in this launch (conv_igemm_wide pair mode)
+    bmi_op_desc pair_d;
+    int pair_cout = 0;
 };
 
 struct ProfRec {
@@ -83,7 +86,8 @@ SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
     return s;
 }
 
-// Kernel selection for one conv launch: LDS-tile 3x3 patch kernel -> per-tap implicit GEMM.
+// Kernel selection for one conv launch: LDS-tile 3x3 patch kernel -> wide-tile per-tap implicit GEMM (Cout % 256 == 0)
+// -> per-tap implicit GEMM.
 // BMI_CONV_IMPL=igemm skips the patch kernel, BMI_CONV_IMPL=wreg tries the experimental
 // register-weight kernel first (it needs packed weights; same-box A/B: 12-20 % slower than the
 // patch kernel because the two pixel-waves of a workgroup each stream the same weights from L2).
@@ -100,6 +104,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     }
     if (mode <= 1) {
         const int rc = launch_conv3x3_patch(a, s);
+        if (rc != BMI_ERR_UNSUPPORTED) return rc;
+    }
+    {
+        const int rc = launch_conv_igemm_wide(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
     return launch_conv_igemm(a, s);
@@ -307,6 +315,37 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 }
         }
     }
+    // Pair fusion: two suffix convs that read the same tensor with the same geometry and a plain BN(+ReLU) epilogue
+    // (layerN.0.conv1 and the first conv of the exit head in front of it, resnet18.py:306/:318/:329 vs :280-299)
+    // run as ONE conv_igemm_wide launch: the input tile is fetched once for both and a 128-channel conv still fills
+    // the kernel's 256-channel tile.  The later conv moves up to the earlier one's position (it depends on nothing
+    // in between).  BMI_CONV_PAIR=0 keeps them separate (A/B, tests).
+    {
+        const char* env = std::getenv("BMI_CONV_PAIR");
+        const bool enable = !env || std::atoi(env) != 0;
+        auto plain = [&](const OpInfo& c) {
+            return c.d.kind == BMI_OP_CONV && !c.has_pair && c.d.residual < 0 && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE &&
+                   c.bits_tensor < 0 && c.out_mul == 1.f && c.d.scale && c.d.bias;
+        };
+        for (size_t i = 0; enable && i < e->suffix.size(); ++i) {
+            if (!plain(e->suffix[i])) continue;
+            const OpInfo A = e->suffix[i];
+            const TensorInfo& ti = e->tensors[A.d.in];
+            if (conv_takes_patch_kernel(A.d.ksize, A.d.stride, A.d.pad, ti.c, A.cout, A.ho, A.wo)) continue;
+            for (size_t j = i + 1; j < e->suffix.size(); ++j) {
+                const OpInfo& Bo = e->suffix[j];
+                if (!plain(Bo) || Bo.d.in != A.d.in || Bo.d.ksize != A.d.ksize || Bo.d.stride != A.d.stride ||
+                    Bo.d.pad != A.d.pad || Bo.d.relu != A.d.relu)
+                    continue;
+                if (A.cout % 128 != 0 || !conv_takes_wide_kernel(ti.c, A.cout + Bo.cout)) continue;
+                e->suffix[i].has_pair = true;
+                e->suffix[i].pair_d = Bo.d;
+                e->suffix[i].pair_cout = Bo.cout;
+                e->suffix.erase(e->suffix.begin() + (long)j);
+                break;
+            }
+        }
+    }
     // live ranges of the stochastic tensors over the suffix
     for (int k = 0; k < (int)e->suffix.size(); ++k) {
         const bmi_op_desc& d = e->suffix[k].d;
@@ -322,6 +361,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         touch(e->suffix[k].bits_tensor);
         if (d.kind == BMI_OP_CONV) touch(d.residual);
         if (d.kind != BMI_OP_HEAD) touch(d.out);
+        if (e->suffix[k].has_pair) touch(e->suffix[k].pair_d.out);
     }
     *out = e;
     return BMI_OK;
@@ -458,6 +498,20 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 a.H2 = t2.h; a.W2 = t2.w; a.Cin2 = t2.c; a.stride2 = t2.h / op.ho;
             }
             if (op.bits_tensor >= 0) a.in_bits = (const uint8_t*)(ws + e->tensors[op.bits_tensor].offset);
+            if (op.has_pair) {
+                ConvArgs p = a;
+                p.wgt_b = (const _Float16*)op.pair_d.weight;
+                p.scale_b = op.pair_d.scale; p.bias_b = op.pair_d.bias;
+                p.out_b = (_Float16*)(ws + e->tensors[op.pair_d.out].offset);
+                p.split = op.cout;
+                p.Cout = op.cout + op.pair_cout;
+                const int rc = launch_conv_igemm_wide(p, s);
+                if (rc != BMI_ERR_UNSUPPORTED) return rc;
+                ConvArgs q = a;          // not taken after all: two plain launches
+                q.wgt = p.wgt_b; q.scale = p.scale_b; q.bias = p.bias_b; q.out = p.out_b; q.Cout = op.pair_cout;
+                const int rc2 = launch_conv(a, s);
+                return rc2 != BMI_OK ? rc2 : launch_conv(q, s);
+            }
             return launch_conv(a, s);
         }
         case OP_MASKBITS:
@@ -600,6 +654,26 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
     a.in_bits = (const uint8_t*)in_keep_bits;
     a.out_mul = out_mul;
     return launch_conv(a, (hipStream_t)stream);
+}
+
+int bmi_conv_pair_fwd(const void* in, const void* weight_a, const float* scale_a, const float* bias_a, void* out_a,
+                      const void* weight_b, const float* scale_b, const float* bias_b, void* out_b, int32_t n,
+                      int32_t in_mod, int32_t h, int32_t w, int32_t cin, int32_t cout_a, int32_t cout_b, int32_t ksize,
+                      int32_t stride, int32_t pad, int32_t relu, bmi_stream stream) {
+    if (!in || !weight_a || !weight_b || !out_a || !out_b || ksize < 1 || stride < 1 || pad < 0) return BMI_ERR_INVALID;
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight_a; a.scale = scale_a; a.bias = bias_a; a.out = (_Float16*)out_a;
+    a.wgt_b = (const _Float16*)weight_b; a.scale_b = scale_b; a.bias_b = bias_b; a.out_b = (_Float16*)out_b;
+    a.split = cout_a;
+    a.N = n; a.in_mod = in_mod; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout_a + cout_b;
+    a.Ho = (h + 2 * pad - ksize) / stride + 1;
+    a.Wo = (w + 2 * pad - ksize) / stride + 1;
+    a.ksize = ksize; a.stride = stride; a.pad = pad; a.relu = relu;
+    a.M = n * a.Ho * a.Wo;
+    a.B = n; a.out_mul = 1.f;
+    a.site = resolve_site(nullptr, 0, 0);
+    return launch_conv_igemm_wide(a, (hipStream_t)stream);
 }
 
 int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2, const void* weight2, const float* bias,

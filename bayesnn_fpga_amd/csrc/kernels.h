@@ -21,6 +21,13 @@ struct ConvArgs {
     const _Float16* in2;     // [N or in2_mod][H2][W2][Cin2], or null
     const _Float16* wgt2;    // [Cout][Cin2]
     int in2_mod, H2, W2, Cin2, stride2;
+    // pair mode (conv_igemm_wide only): a second conv on the same input with the same geometry; channel tiles
+    // >= split of the launch's Cout (= both convs' channels) use these and write out_b [.][Cout - split]
+    const _Float16* wgt_b;   // or null
+    const float* scale_b;
+    const float* bias_b;
+    _Float16* out_b;
+    int split;
     _Float16* out;
     int N;        // output images in this launch (= samples_in_chunk * B in the suffix)
     int in_mod;   // input image = n % in_mod  (B when the input is deterministic)
@@ -44,6 +51,8 @@ struct EltArgs {  // MASK / POOL ops
 };
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s);  // 256x256 tiles; BMI_ERR_UNSUPPORTED -> conv_igemm
+bool conv_takes_wide_kernel(int cin, int cout);
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
 int launch_conv3x3_wreg(const ConvArgs& a, hipStream_t s);    // needs a.wpk; BMI_ERR_UNSUPPORTED -> next kernel
 int launch_pack_conv3x3_weights(const _Float16* w, _Float16* out, int cout, int cin, hipStream_t s);

@@ -185,6 +185,15 @@ int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2
                              void* out, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t cin2,
                              int32_t relu, bmi_stream stream);
 
+/* Two convolutions that read the SAME input with the same geometry, as one launch of the 256 x 256-tile kernel:
+ * out_a = relu?(bn_a(conv(in; weight_a))) [..][cout_a], out_b likewise [..][cout_b].  cout_a % 128 == 0,
+ * (cout_a + cout_b) % 256 == 0, cin % 64 == 0.  Replaces the pair layerN[0].conv1 / ex{N-1}conv1 of
+ * ResNet18MCEarlyExit.forward (SA/models/resnet18/resnet18.py:306, :318, :329 next to :280-299). */
+int bmi_conv_pair_fwd(const void* in, const void* weight_a, const float* scale_a, const float* bias_a, void* out_a,
+                      const void* weight_b, const float* scale_b, const float* bias_b, void* out_b, int32_t n,
+                      int32_t in_mod, int32_t h, int32_t w, int32_t cin, int32_t cout_a, int32_t cout_b, int32_t ksize,
+                      int32_t stride, int32_t pad, int32_t relu, bmi_stream stream);
+
 int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
                    int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
 

@@ -269,3 +269,63 @@ def test_conv3x3_with_fused_shortcut(name, cin2):
     ref = ref + F_.conv2d(x_in.float().cpu().permute(0, 3, 1, 2), w2.float().cpu()[:, :, None, None], stride=2)
     ref = torch.relu(ref + bias.cpu()[None, :, None, None])
     torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("name,n", [("D3", 5), ("D4", 21), ("P4", 7)])
+def test_conv_wide_tile_kernel_tails_residual_and_site(name, n):
+    """Cout % 256 == 0 shapes run in the 256 x 256-tile LDS-DMA kernel (conv_igemm_wide.hip): ragged pixel tiles
+    (M = n*Ho*Wo is not a multiple of 256), residual, ReLU and a fused elementwise site, bit-exact mask."""
+    cin, cout, H, k, s, p = SHAPES[name]
+    B, tc, t0, seed = n, 1, 3, 99
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, n, 31, True)
+    ho = (H + 2 * p - k) // s + 1
+    assert (n * ho * ho) % 256 != 0
+    res = torch.randn(n, ho, ho, cout, generator=g).to(torch.float16).to(DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=5, p=0.25)
+    out = gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=B, t0=t0, seed=seed)
+    ref = gh.conv_ref(x, w, scale, bias, res, True, s, p, n, n, n)
+    mult = gh.folded_site_mask(site, B, cout, ho, ho, tc, t0, seed)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref * mult, rtol=2e-3, atol=3e-3)
+    assert torch.equal(got[mult == 0], torch.zeros_like(got[mult == 0]))
+
+
+@pytest.mark.parametrize("cin,ca,cb,H,k,s,p,n,in_mod", [
+    (64, 128, 128, 32, 3, 2, 1, 3, 3),        # layer2[0].conv1 + ex1conv1
+    (128, 256, 256, 16, 3, 2, 1, 6, 2),       # layer3[0].conv1 + ex2conv1, input broadcast over 3 samples
+    (256, 512, 512, 8, 3, 2, 1, 5, 5),        # layer4[0].conv1 + ex3conv1
+    (64, 128, 384, 8, 1, 1, 0, 9, 9),         # unequal halves, 1x1
+])
+def test_conv_pair_one_launch_two_outputs(cin, ca, cb, H, k, s, p, n, in_mod):
+    lib = _lib.lib()
+    g = _gen(5)
+    x = torch.randn(in_mod, H, H, cin, generator=g).to(torch.float16).to(DEV)
+    ho = (H + 2 * p - k) // s + 1
+    ws, scs, bis, outs = [], [], [], []
+    for c in (ca, cb):
+        ws.append((torch.randn(c, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(torch.float16).to(DEV))
+        scs.append((0.5 + torch.rand(c, generator=g)).to(DEV))
+        bis.append((0.2 * torch.randn(c, generator=g)).to(DEV))
+        outs.append(torch.full((n, ho, ho, c), float("nan"), dtype=torch.float16, device=DEV))
+    rc = lib.bmi_conv_pair_fwd(gh.ptr(x), gh.ptr(ws[0]), gh.ptr(scs[0]), gh.ptr(bis[0]), gh.ptr(outs[0]), gh.ptr(ws[1]), gh.ptr(scs[1]),
+                               gh.ptr(bis[1]), gh.ptr(outs[1]), n, in_mod, H, H, cin, ca, cb, k, s, p, 1, gh.stream())
+    _lib.check(rc, "bmi_conv_pair_fwd")
+    torch.cuda.synchronize()
+    for i in range(2):
+        ref = gh.conv_ref(x, ws[i], scs[i], bis[i], None, True, s, p, n, in_mod, 1)
+        torch.testing.assert_close(outs[i].float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3)
+        # and identical to the same conv launched alone
+        alone = gh.run_conv(x, ws[i], scs[i], bis[i], None, True, s, p, n, in_mod, 1)
+        assert torch.equal(alone, outs[i])
+
+
+def test_conv_pair_rejects_bad_splits():
+    lib = _lib.lib()
+    z = torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=DEV)
+    w = torch.zeros(192, 3, 3, 64, dtype=torch.float16, device=DEV)
+    o = torch.zeros(1, 8, 8, 192, dtype=torch.float16, device=DEV)
+    f = torch.zeros(192, device=DEV)
+    args = lambda ca, cb: (gh.ptr(z), gh.ptr(w), gh.ptr(f), gh.ptr(f), gh.ptr(o), gh.ptr(w), gh.ptr(f), gh.ptr(f), gh.ptr(o), 1, 1, 8, 8, 64,
+                           ca, cb, 3, 1, 1, 1, gh.stream())
+    assert lib.bmi_conv_pair_fwd(*args(64, 192)) == -22        # first half must be a multiple of 128 channels
+    assert lib.bmi_conv_pair_fwd(*args(128, 64)) == -95        # total not a multiple of the 256-channel tile

@@ -131,3 +131,19 @@ def test_full_size_batch_properties():
     # row 0 of the big batch equals a batch-of-one run (mask index depends on (b, ...) only)
     r1 = eng.predict(x[:1].contiguous(), T, seed=42)
     torch.testing.assert_close(r1["mean"][:, 0], r["mean"][:, 0], rtol=0, atol=1e-6)
+
+
+def test_pair_fusion_is_invisible(monkeypatch):
+    """layerN[0].conv1 + ex{N-1}conv1 as one launch (engine.hip pair fusion) vs BMI_CONV_PAIR=0: identical moments."""
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    model = _product(ResNet18MCEarlyExit, kw)
+    B, T, seed = 9, 4, 11
+    x = synthetic_images(B, seed=3).to(DEV)
+    eng = model.engine(x.device, max_batch=B, chunk_samples=2)
+    S_fused = eng.accumulate(x, eng.new_moments(B), 0, T, seed).cpu()
+    n_fused = eng.n_suffix_ops
+    monkeypatch.setenv("BMI_CONV_PAIR", "0")
+    eng2 = type(eng)(model, x.device, max_batch=B, chunk_samples=2)
+    assert eng2.n_suffix_ops == n_fused + 3                     # three pairs in ResNet-18 multi-exit with block dropout
+    S_plain = eng2.accumulate(x, eng2.new_moments(B), 0, T, seed).cpu()
+    assert torch.equal(S_fused, S_plain)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--site", action="store_true", help="fuse an elementwise MC-dropout site into the epilogue")
     ap.add_argument("--nores", action="store_true")
     ap.add_argument("--noscale", action="store_true")
+    ap.add_argument("--sparse-input", action="store_true", help="post-ReLU, 25 %% dropped activations (as inside the network) instead of N(0,1)")
     a = ap.parse_args()
     lib = _lib.lib()
     dev = "cuda:0"
@@ -43,7 +44,10 @@ def main():
         n = a.images
         ho = (H + 2 * p - k) // s + 1
         g = torch.Generator().manual_seed(1)
-        x = torch.randn(n, H, H, cin, generator=g).to(torch.float16).to(dev)
+        x = torch.randn(n, H, H, cin, generator=g)
+        if a.sparse_input:
+            x = torch.relu(x) * (torch.rand(n, H, H, cin, generator=g) > 0.25)
+        x = x.to(torch.float16).to(dev)
         w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(torch.float16).to(dev)
         scale = (0.5 + torch.rand(cout, generator=g)).to(dev)
         bias = (0.1 * torch.randn(cout, generator=g)).to(dev)
