@@ -45,6 +45,8 @@ struct OpInfo {
 struct ProfRec {
     int slot;
     hipEvent_t a, b;
+    int family = -1;     // BMI_CONV_FAMILY_* of a conv launch
+    double flops = 0;    // its algorithmic FLOPs
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -62,6 +64,8 @@ struct bmi_engine_s {
     int max_head_k = 0;
     // profiling
     bool profiling = false;
+    double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0};
+    int64_t fam_launches[BMI_CONV_FAMILIES] = {0};
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
 };
@@ -91,7 +95,9 @@ SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
 // BMI_CONV_IMPL=igemm skips the patch kernel, BMI_CONV_IMPL=wreg tries the experimental
 // register-weight kernel first (it needs packed weights; same-box A/B: 12-20 % slower than the
 // patch kernel because the two pixel-waves of a workgroup each stream the same weights from L2).
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+int launch_conv(const ConvArgs& a, hipStream_t s, int* family) {
+    int fam_dummy;
+    if (!family) family = &fam_dummy;
     static const int mode = [] {
         const char* v = std::getenv("BMI_CONV_IMPL");
         if (v && std::strcmp(v, "igemm") == 0) return 2;
@@ -99,17 +105,21 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         return 1;
     }();
     if (mode == 0) {
+        *family = BMI_CONV_FAMILY_WREG;
         const int rc = launch_conv3x3_wreg(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
     if (mode <= 1) {
+        *family = BMI_CONV_FAMILY_PATCH;
         const int rc = launch_conv3x3_patch(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
     {
+        *family = BMI_CONV_FAMILY_WIDE;
         const int rc = launch_conv_igemm_wide(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
+    *family = BMI_CONV_FAMILY_IGEMM;
     return launch_conv_igemm(a, s);
 }
 
@@ -453,6 +463,7 @@ struct ProfScope {
         r.slot = slot; r.a = get(); r.b = get();
         (void)hipEventRecord(r.a, s);
     }
+    void tag(int family, double flops) { r.family = family; r.flops = flops; }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(r.b, s);
@@ -498,6 +509,8 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 a.H2 = t2.h; a.W2 = t2.w; a.Cin2 = t2.c; a.stride2 = t2.h / op.ho;
             }
             if (op.bits_tensor >= 0) a.in_bits = (const uint8_t*)(ws + e->tensors[op.bits_tensor].offset);
+            double flops = 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
+            if (d.in2 >= 0) flops += 2.0 * N * op.ho * op.wo * (double)op.cout * e->tensors[d.in2].c;
             if (op.has_pair) {
                 ConvArgs p = a;
                 p.wgt_b = (const _Float16*)op.pair_d.weight;
@@ -506,13 +519,19 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 p.split = op.cout;
                 p.Cout = op.cout + op.pair_cout;
                 const int rc = launch_conv_igemm_wide(p, s);
+                prof.tag(BMI_CONV_FAMILY_WIDE, flops);
                 if (rc != BMI_ERR_UNSUPPORTED) return rc;
                 ConvArgs q = a;          // not taken after all: two plain launches
                 q.wgt = p.wgt_b; q.scale = p.scale_b; q.bias = p.bias_b; q.out = p.out_b; q.Cout = op.pair_cout;
-                const int rc2 = launch_conv(a, s);
+                int fam = -1;
+                const int rc2 = launch_conv(a, s, &fam);
+                prof.tag(fam, flops);
                 return rc2 != BMI_OK ? rc2 : launch_conv(q, s);
             }
-            return launch_conv(a, s);
+            int fam = -1;
+            const int rcc = launch_conv(a, s, &fam);
+            prof.tag(fam, flops);
+            return rcc;
         }
         case OP_MASKBITS:
             return launch_mask_bits((uint8_t*)(ws + e->tensors[d.out].offset), N, tin.h * tin.w, tin.c,
@@ -595,16 +614,27 @@ int bmi_profile_enable(bmi_handle h, int32_t enable) {
 int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launches[BMI_PROFILE_SLOTS]) {
     if (!h || !ms || !launches) return BMI_ERR_INVALID;
     for (int i = 0; i < BMI_PROFILE_SLOTS; ++i) { ms[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { h->fam_ms[i] = 0; h->fam_flops[i] = 0; h->fam_launches[i] = 0; }
     int rc = BMI_OK;
     for (auto& r : h->recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = BMI_ERR_HIP;
         if (r.slot >= 0 && r.slot < BMI_PROFILE_SLOTS) { ms[r.slot] += t; launches[r.slot] += 1; }
+        if (r.slot == BMI_OP_CONV && r.family >= 0 && r.family < BMI_CONV_FAMILIES) {
+            h->fam_ms[r.family] += t; h->fam_flops[r.family] += r.flops; h->fam_launches[r.family] += 1;
+        }
         h->pool.push_back(r.a);
         h->pool.push_back(r.b);
     }
     h->recs.clear();
     return rc;
+}
+
+int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
+                              double flops[BMI_CONV_FAMILIES]) {
+    if (!h || !ms || !launches || !flops) return BMI_ERR_INVALID;
+    for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { ms[i] = h->fam_ms[i]; launches[i] = h->fam_launches[i]; flops[i] = h->fam_flops[i]; }
+    return BMI_OK;
 }
 
 // ---- single-kernel entry points -------------------------------------------------------------

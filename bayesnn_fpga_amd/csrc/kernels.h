@@ -56,7 +56,7 @@ bool conv_takes_wide_kernel(int cin, int cout);
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
 int launch_conv3x3_wreg(const ConvArgs& a, hipStream_t s);    // needs a.wpk; BMI_ERR_UNSUPPORTED -> next kernel
 int launch_pack_conv3x3_weights(const _Float16* w, _Float16* out, int cout, int cin, hipStream_t s);
-int launch_conv(const ConvArgs& a, hipStream_t s);           // picks the kernel
+int launch_conv(const ConvArgs& a, hipStream_t s, int* family = nullptr);   // picks the kernel; *family = BMI_CONV_FAMILY_*
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s);
 int launch_mask_apply(const EltArgs& a, hipStream_t s);

@@ -381,4 +381,9 @@ class MCDEngine(CompiledGraph):
         ms = (C.c_double * _lib.PROFILE_SLOTS)()
         n = (C.c_int64 * _lib.PROFILE_SLOTS)()
         _lib.check(self.lib.bmi_profile_read(self.handle, ms, n), "bmi_profile_read")
-        return {_lib.PROFILE_NAMES.get(i, str(i)): (ms[i], n[i]) for i in range(_lib.PROFILE_SLOTS) if n[i]}
+        out = {_lib.PROFILE_NAMES.get(i, str(i)): (ms[i], n[i]) for i in range(_lib.PROFILE_SLOTS) if n[i]}
+        fms, fn, ffl = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)()
+        _lib.check(self.lib.bmi_profile_conv_families(self.handle, fms, fn, ffl), "bmi_profile_conv_families")
+        names = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_wreg_kernel")
+        self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i]) for i in range(4) if fn[i]}
+        return out

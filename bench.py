@@ -185,8 +185,10 @@ def main():
         conv_ms, conv_launches = prof.get("conv_igemm", (0.0, 0))
         conv_flops -= 2.0 * B * eng.stem_macs        # the 3-channel stem runs in its own direct kernel
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        alg_bytes, alg_launches = eng.conv_traffic_model(B, my_T)
-        traffic, traffic_src = hbm_traffic(a.workload, alg_launches) if (world == 1 and not a.batch and not a.T and not a.chunk) else (None, None)
+        alg_bytes, _ = eng.conv_traffic_model(B, my_T)
+        alg_launches = int(conv_launches)            # launches actually made (paired convs are one launch)
+        traffic, traffic_src = (hbm_traffic(a.workload, max(alg_launches, 1))
+                                if (world == 1 and not a.batch and not a.T and not a.chunk) else (None, None))
         mean = out["mean"].cpu().numpy()
         labels = synthetic_labels(B, kw["out_dim"], seed=1235).numpy()
         onehot = np.eye(kw["out_dim"])[labels]
@@ -202,7 +204,10 @@ def main():
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
             "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),
             "tflops_naive_equiv": round(2.0 * (eng.prefix_macs + eng.suffix_macs) * samples / dt / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one step)",
+            # the three conv kernels together (94 % of the step); `by_kernel` splits it per kernel name as
+            # rocprofv3 --kernel-trace --stats lists them (profiles/): FLOPs are the algorithmic 2*MACs of each launch
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel + conv_igemm_wide_kernel + conv_igemm_kernel "
+                                                    "(all conv launches of one step)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": None if traffic is None else round(traffic),
@@ -210,6 +215,10 @@ def main():
                          "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_launches, 1)),
                          "algorithmic_flops_per_launch": round(conv_flops / max(conv_launches, 1)),
                          "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                         "by_kernel": {k: {"launches": int(v["launches"]), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                                           "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                                       for k, v in eng.conv_families.items()},
                          "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
         }
         if not a.no_cpu_baseline:
