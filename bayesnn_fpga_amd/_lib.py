@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libbayesnn_fpga_amd.so")
 
 BMI_OK = 0
 SITE_NONE, SITE_ELEMENTWISE, SITE_CHANNEL, SITE_MASKSEMBLE = 0, 1, 2, 3
+SITE_POS_OUTER, SITE_POS_INNER = 0, 1
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL = 1, 2, 3, 4, 5
 PROFILE_SLOTS = 8
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
@@ -29,7 +30,8 @@ class TensorDesc(C.Structure):
 class OpDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_", C.c_int32), ("out", C.c_int32), ("residual", C.c_int32), ("in2", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32),
-                ("weight", C.c_void_p), ("weight2", C.c_void_p), ("weight_packed", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site)]
+                ("weight", C.c_void_p), ("weight2", C.c_void_p), ("weight_packed", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site),
+                ("bias_post", C.c_void_p), ("site_pos", C.c_int32)]
 
 
 class ModelDesc(C.Structure):
@@ -75,6 +77,7 @@ _PROTOS = {
     "bmi_pool_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
                                 C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
     "bmi_linear_softmax": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
+    "bmi_linear_softmax_site": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.POINTER(Site), C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
     "bmi_moments_accumulate": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
 }
 

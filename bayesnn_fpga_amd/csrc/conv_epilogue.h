@@ -52,27 +52,8 @@ __device__ __forceinline__ PixelCtx make_pixel_ctx(const ConvArgs& a, int n, int
     return p;
 }
 
-__device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx& p, float v[4], int c4) {
-    if (a.scale) {
-        const float4 s4 = *(const float4*)(a.scale + c4);
-        v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
-    } else if (a.out_mul != 1.f) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
-    }
-    if (a.bias) {
-        const float4 b4 = *(const float4*)(a.bias + c4);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-    }
-    if (p.resp) {
-        const half4 r4 = *(const half4*)(p.resp + c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-    }
-    if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
+// the stochastic site on one accumulator quad (4 consecutive channels c4.. of pixel p)
+__device__ __forceinline__ void site_quad(const ConvArgs& a, const PixelCtx& p, float v[4], int c4) {
     if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
         const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)p.e_pix * a.Cout + c4
                                                                   : (uint64_t)p.b * a.Cout + c4;
@@ -87,6 +68,37 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
         const float4 k4 = *(const float4*)(p.mrow + c4);
         v[0] *= k4.x; v[1] *= k4.y; v[2] *= k4.z; v[3] *= k4.w;
     }
+}
+
+__device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx& p, float v[4], int c4) {
+    if (a.scale) {
+        const float4 s4 = *(const float4*)(a.scale + c4);
+        v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
+    } else if (a.out_mul != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
+    }
+    if (a.bias) {
+        const float4 b4 = *(const float4*)(a.bias + c4);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (a.site_inner) {
+        site_quad(a, p, v, c4);
+        if (a.bias_post) {
+            const float4 b4 = *(const float4*)(a.bias_post + c4);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+    }
+    if (p.resp) {
+        const half4 r4 = *(const half4*)(p.resp + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (!a.site_inner) site_quad(a, p, v, c4);
     half4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
@@ -111,7 +123,7 @@ typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
 
 #define BMI_EPILOGUE_LDS_BYTES 65536
 
-__host__ __device__ inline bool conv_epilogue_is_plain(const ConvArgs& a) { return !a.res && a.site.kind == BMI_SITE_NONE; }
+__host__ __device__ inline bool conv_epilogue_is_plain(const ConvArgs& a) { return !a.res && a.site.kind == BMI_SITE_NONE; }   // (an inner site has kind != NONE)
 
 // LDS-only barrier: the epilogue's global stores / outstanding residual loads must NOT be drained
 // at the round boundaries (a __syncthreads() would add s_waitcnt vmcnt(0)).
@@ -192,6 +204,24 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, f32x16_e (&acc
     }
 }
 
+// the stochastic site on 8 consecutive channels c8.. of one pixel (one Philox call)
+__device__ __forceinline__ void site_oct(const ConvArgs& a, const PixelCtx& px, float v[8], int c8) {
+    if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
+        const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)px.e_pix * a.Cout + c8
+                                                                  : (uint64_t)px.b * a.Cout + c8;
+        const uint64_t g = elem >> 3;      // one Philox call masks the thread's 8 channels
+        const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)px.t,
+                                         (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = (!a.site.drop_all && philox_keep(rn, e, a.site.thresh)) ? v[e] * a.site.scale : 0.f;
+    } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
+        const f32x4_e k0 = *(const f32x4_e*)(px.mrow + c8), k1 = *(const f32x4_e*)(px.mrow + c8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] *= k0[e]; v[4 + e] *= k1[e]; }
+    }
+}
+
 // pixmap(p, n, rem) -> bool: tile pixel p -> image n and y*Wo+x (false beyond the tensor);
 // offmap(p, off) -> bool: the same pixel's element offset in the output tensor (no division for linear tiles).
 // PLAIN (chosen per launch: no residual, no site) selects epilogue_plain at compile time: with both paths in one
@@ -265,6 +295,14 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] * sc0[e] + bi0[e]; v[4 + e] = hi[e] * sc1[e] + bi1[e]; }
             const int c8 = ch0 + 8 * k;
+            if (a.site_inner) {
+                site_oct(a, px, v, c8);
+                if (a.bias_post) {
+                    const f32x4_e p0 = *(const f32x4_e*)(a.bias_post + c8), p1 = *(const f32x4_e*)(a.bias_post + c8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+                }
+            }
             if (px.resp) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)resv[rr][it][e];
@@ -273,20 +311,7 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
-                const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)px.e_pix * a.Cout + c8
-                                                                          : (uint64_t)px.b * a.Cout + c8;
-                const uint64_t g = elem >> 3;      // one Philox call masks the thread's 8 channels
-                const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)px.t,
-                                                 (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    v[e] = (!a.site.drop_all && philox_keep(rn, e, a.site.thresh)) ? v[e] * a.site.scale : 0.f;
-            } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
-                const f32x4_e k0 = *(const f32x4_e*)(px.mrow + c8), k1 = *(const f32x4_e*)(px.mrow + c8 + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] *= k0[e]; v[4 + e] *= k1[e]; }
-            }
+            if (!a.site_inner) site_oct(a, px, v, c8);
             half8_e o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];

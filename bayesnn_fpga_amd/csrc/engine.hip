@@ -181,6 +181,9 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     rc = BMI_ERR_INVALID; break;
                 }
                 if ((d.kind == BMI_OP_STEM) != (d.in == 0)) { rc = BMI_ERR_INVALID; break; }
+                if (d.site_pos != BMI_SITE_POS_OUTER && d.site_pos != BMI_SITE_POS_INNER) { rc = BMI_ERR_INVALID; break; }
+                const bool inner = d.site_pos == BMI_SITE_POS_INNER && d.site.kind != BMI_SITE_NONE;
+                if (inner && (d.in2 >= 0 || d.site.kind == BMI_SITE_MASKSEMBLE)) { rc = BMI_ERR_UNSUPPORTED; break; }
                 const TensorInfo to = e->tensors[d.out];  // by value: the split below grows the vector
                 op.ho = (tin.h + 2 * d.pad - d.ksize) / d.stride + 1;
                 op.wo = (tin.w + 2 * d.pad - d.ksize) / d.stride + 1;
@@ -211,6 +214,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 if (!in_st && d.site.kind != BMI_SITE_NONE) {
                     // deterministic conv feeding a site: keep the conv in the once-per-batch prefix
                     // and apply the site while expanding to the folded sample batch.
+                    if (inner && d.residual >= 0) { rc = BMI_ERR_UNSUPPORTED; break; }
                     TensorInfo tmp = to;
                     tmp.stoch = false;
                     e->tensors.push_back(tmp);
@@ -218,6 +222,9 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     OpInfo conv = op;
                     conv.d.out = tmp_id;
                     conv.d.site.kind = BMI_SITE_NONE;
+                    conv.d.site_pos = BMI_SITE_POS_OUTER;
+                    conv.d.bias_post = nullptr;
+                    if (inner) conv.d.relu = 0;   // the prefix keeps conv*scale+bias; mask, BN shift and ReLU follow in the MASK op
                     conv.stoch = false;
                     e->prefix.push_back(conv);
                     e->prefix_macs += macs;
@@ -229,6 +236,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     m.d.residual = -1;
                     m.d.in2 = -1;
                     m.d.site = d.site;
+                    if (inner) { m.d.bias_post = d.bias_post; m.d.relu = d.relu; m.d.site_pos = BMI_SITE_POS_INNER; }
                     m.stoch = true;
                     m.ho = to.h; m.wo = to.w; m.cout = to.c;
                     e->suffix.push_back(m);
@@ -243,9 +251,12 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 break;
             }
             case BMI_OP_MASK: {
-                if (!tensor_ok(d.out) || d.out == 0 || written[d.out] || d.in == 0 || d.site.kind == BMI_SITE_NONE) {
+                if (!tensor_ok(d.out) || d.out == 0 || written[d.out] || d.in == 0 || d.site.kind == BMI_SITE_NONE ||
+                    d.site_pos != BMI_SITE_POS_OUTER) {
                     rc = BMI_ERR_INVALID; break;
                 }
+                op.d.bias_post = nullptr;
+                op.d.relu = 0;
                 const TensorInfo& to = e->tensors[d.out];
                 if (to.h != tin.h || to.w != tin.w || to.c != tin.c) { rc = BMI_ERR_INVALID; break; }
                 if (tin.c % 8 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
@@ -273,6 +284,9 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     rc = BMI_ERR_INVALID; break;
                 }
                 if (tin.c % 8 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                if (d.site_pos == BMI_SITE_POS_INNER && d.site.kind != BMI_SITE_NONE && d.site.kind != BMI_SITE_ELEMENTWISE) {
+                    rc = BMI_ERR_UNSUPPORTED; break;   // dropout on the logits is elementwise (F.dropout after nn.Linear)
+                }
                 exit_seen[d.out] = 1;
                 op.stoch = true;  // heads always run per sample (they emit per-sample softmax)
                 op.cout = desc->out_dim;
@@ -301,6 +315,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         for (size_t mi = 0; enable && mi < e->suffix.size(); ++mi) {
             OpInfo& m = e->suffix[mi];
             if (m.d.kind != BMI_OP_MASK || m.d.site.kind != BMI_SITE_ELEMENTWISE || e->tensors[m.d.in].stoch) continue;
+            if (m.d.site_pos == BMI_SITE_POS_INNER) continue;   // carries a BN shift / ReLU: must be materialised
             if (m.d.site.p >= 1.f || e->tensors[m.d.in].c % 8 != 0) continue;
             bool ok = true;
             int uses = 0;
@@ -500,6 +515,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.M = N * op.ho * op.wo;
             a.B = B; a.t0 = t0;
             a.site = resolve_site(&d.site, seed, cnt0);
+            if (d.site_pos == BMI_SITE_POS_INNER && d.site.kind != BMI_SITE_NONE) { a.site_inner = 1; a.bias_post = d.bias_post; }
             a.out_mul = op.out_mul;
             if (d.in2 >= 0) {
                 const TensorInfo& t2 = e->tensors[d.in2];
@@ -543,6 +559,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.out = ws + e->tensors[d.out].offset;
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
             a.site = resolve_site(&d.site, seed, cnt0);
+            if (d.site_pos == BMI_SITE_POS_INNER) { a.bias_post = d.bias_post; a.relu = d.relu; }
             return launch_mask_apply(a, s);
         }
         case BMI_OP_MAXPOOL:
@@ -554,11 +571,13 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.in = (const _Float16*)(ws + tin.offset);
             a.out = feat;
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
-            a.site = resolve_site(&d.site, seed, cnt0);
+            const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
+            a.site = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0);
             int rc = launch_pool_mask(a, s);
             if (rc != BMI_OK) return rc;
             const size_t eo = (size_t)d.out * N * e->out_dim;
-            return launch_linear_softmax(feat, (const float*)d.weight, d.bias, logits + eo, probs + eo, N, tin.c, e->out_dim, s);
+            return launch_linear_softmax(feat, (const float*)d.weight, d.bias, logits + eo, probs + eo, N, tin.c, e->out_dim,
+                                         resolve_site(on_logits ? &d.site : nullptr, seed, cnt0), B, t0, s);
         }
     }
     return BMI_ERR_INVALID;
@@ -753,7 +772,17 @@ int bmi_pool_mask(const void* in, float* feat, int32_t n, int32_t in_mod, int32_
 int bmi_linear_softmax(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
                        int32_t n, int32_t k, int32_t out_dim, bmi_stream stream) {
     if (!feat || !weight_pad || !bias || !logits || !probs) return BMI_ERR_INVALID;
-    return launch_linear_softmax(feat, weight_pad, bias, logits, probs, n, k, out_dim, (hipStream_t)stream);
+    return launch_linear_softmax(feat, weight_pad, bias, logits, probs, n, k, out_dim, resolve_site(nullptr, 0, 0), n, 0,
+                                 (hipStream_t)stream);
+}
+
+int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
+                            int32_t n, int32_t k, int32_t out_dim, const bmi_site* site, int32_t batch, int32_t t0,
+                            uint64_t seed, bmi_stream stream) {
+    if (!feat || !weight_pad || !bias || !logits || !probs || batch < 1) return BMI_ERR_INVALID;
+    if (site && !site_ok(*site)) return BMI_ERR_INVALID;
+    return launch_linear_softmax(feat, weight_pad, bias, logits, probs, n, k, out_dim, resolve_site(site, seed, 0), batch, t0,
+                                 (hipStream_t)stream);
 }
 
 int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,

@@ -28,6 +28,9 @@ struct ConvArgs {
     const float* bias_b;
     _Float16* out_b;
     int split;
+    // inner site (converter/pytorch semantics): out = relu?((acc*scale + bias) * mask + bias_post (+ res))
+    const float* bias_post;  // or null
+    int site_inner;          // 1: a.site multiplies before bias_post / residual / ReLU
     _Float16* out;
     int N;        // output images in this launch (= samples_in_chunk * B in the suffix)
     int in_mod;   // input image = n % in_mod  (B when the input is deterministic)
@@ -48,6 +51,8 @@ struct EltArgs {  // MASK / POOL ops
     int N, in_mod, HW, C;
     int B, t0;
     SiteArgs site;
+    const float* bias_post;  // MASK with an inner site: out = relu?(x * mask + bias_post[c]); or null
+    int relu;
 };
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
@@ -62,8 +67,9 @@ int launch_stem_conv(const float* x, const float* w, const float* scale, const f
 int launch_mask_apply(const EltArgs& a, hipStream_t s);
 int launch_pool_mask(const EltArgs& a, hipStream_t s);
 int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, hipStream_t s);
+// `site` (kind NONE to skip): dropout on the LOGITS ([B, out_dim] tensor: element = b*out_dim + c), sample n / batch
 int launch_linear_softmax(const float* feat, const float* w, const float* bias, float* logits, float* probs, int n,
-                          int k, int out_dim, hipStream_t s);
+                          int k, int out_dim, const SiteArgs& site, int batch, int t0, hipStream_t s);
 int launch_moments(const float* probs, const float* logits, double* S1, double* S2, double* SL, int tc, int batch,
                    int out_dim, int n_exits, size_t exit_stride_scratch, size_t exit_stride_S, hipStream_t s);
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,

@@ -14,7 +14,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int RT>
 __global__ __launch_bounds__(64) void linear_softmax_kernel(const float* __restrict__ feat, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ logits,
-                                                            float* __restrict__ probs, int N, int K, int C) {
+                                                            float* __restrict__ probs, int N, int K, int C, SiteArgs site,
+                                                            int B, int t0) {
     const int lane = threadIdx.x;
     const int r = lane & 31, hh = lane >> 5;
     const int n = blockIdx.x * 32 + r;
@@ -49,7 +50,17 @@ __global__ __launch_bounds__(64) void linear_softmax_kernel(const float* __restr
         for (int e = 0; e < 16; ++e) {
             const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
             if (c < C) {
-                const float v = acc[i][e] + bias[c];
+                float v = acc[i][e] + bias[c];
+                if (site.kind == BMI_SITE_ELEMENTWISE) {
+                    // dropout on the logits (converter/pytorch wraps the last Linear too, nn2bnn.py:33-45):
+                    // [B, C] tensor, element = b*C + c, eight elements per Philox call
+                    const int tl = n / B;
+                    const uint64_t elem = (uint64_t)(n - tl * B) * C + c;
+                    const uint64_t g8 = elem >> 3;
+                    const philox4 rn = philox4x32_10((uint32_t)g8, (uint32_t)(g8 >> 32), (uint32_t)(t0 + tl), (uint32_t)site.site_id,
+                                                     site.seed_lo, site.seed_hi);
+                    v = (!site.drop_all && philox_keep(rn, (int)(elem & 7), site.thresh)) ? v * site.scale : 0.f;
+                }
                 acc[i][e] = v;
                 mx = fmaxf(mx, v);
                 if (valid) logits[(size_t)n * C + c] = v;
@@ -80,16 +91,17 @@ __global__ __launch_bounds__(64) void linear_softmax_kernel(const float* __restr
 }
 
 int launch_linear_softmax(const float* feat, const float* w, const float* bias, float* logits, float* probs, int n,
-                          int k, int out_dim, hipStream_t s) {
-    if (n <= 0 || out_dim <= 0) return BMI_ERR_INVALID;
+                          int k, int out_dim, const SiteArgs& site, int batch, int t0, hipStream_t s) {
+    if (n <= 0 || out_dim <= 0 || batch <= 0) return BMI_ERR_INVALID;
+    if (site.kind != BMI_SITE_NONE && site.kind != BMI_SITE_ELEMENTWISE) return BMI_ERR_UNSUPPORTED;
     if (k % 8 != 0 || out_dim > 128) return BMI_ERR_UNSUPPORTED;
     const int rt = (out_dim + 31) / 32;
     const dim3 grid((n + 31) / 32), block(64);
     switch (rt) {
-        case 1: hipLaunchKernelGGL(linear_softmax_kernel<1>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim); break;
-        case 2: hipLaunchKernelGGL(linear_softmax_kernel<2>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim); break;
-        case 3: hipLaunchKernelGGL(linear_softmax_kernel<3>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim); break;
-        default: hipLaunchKernelGGL(linear_softmax_kernel<4>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim); break;
+        case 1: hipLaunchKernelGGL(linear_softmax_kernel<1>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim, site, batch, t0); break;
+        case 2: hipLaunchKernelGGL(linear_softmax_kernel<2>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim, site, batch, t0); break;
+        case 3: hipLaunchKernelGGL(linear_softmax_kernel<3>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim, site, batch, t0); break;
+        default: hipLaunchKernelGGL(linear_softmax_kernel<4>, grid, block, 0, s, feat, w, bias, logits, probs, n, k, out_dim, site, batch, t0); break;
     }
     BMI_CHECK_LAUNCH();
     return BMI_OK;

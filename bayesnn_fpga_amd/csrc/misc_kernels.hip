@@ -49,6 +49,15 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(EltArgs a) {
                                 ? a.site.masks + (size_t)((a.site.cnt0 + t) % a.site.num_masks) * a.C + c8
                                 : nullptr;
         site_mask8(a.site, v, elem0, t, mrow);
+        if (a.bias_post) {   // inner site of a deterministic conv: the BN shift (and the ReLU) come after the mask
+            const float4 p0 = *(const float4*)(a.bias_post + c8), p1 = *(const float4*)(a.bias_post + c8 + 4);
+            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+            v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];

@@ -58,20 +58,24 @@ class GraphBuilder:
         self.keep.append(d)
         return d
 
-    def site(self, module):
+    def site(self, module, channelwise=False):
         """Allocates the next site id (call order) for a stochastic layer, or none."""
         if module is None:
             return None
         sid = self.site_count
         self.site_count += 1
+        if channelwise:
+            return dict(kind=_lib.SITE_CHANNEL, site_id=sid, p=float(module.p))
         if isinstance(module, (Masksembles1D, Masksembles2D)):
             masks = self.dev(module.masks, torch.float32)
             return dict(kind=_lib.SITE_MASKSEMBLE, site_id=sid, num_masks=module.n, masks=masks)
         return dict(kind=_lib.SITE_ELEMENTWISE, site_id=sid, p=float(module.p))
 
-    def conv(self, x, conv, bn, relu, residual=-1, site=None, stem=False, shortcut=None):
+    def conv(self, x, conv, bn, relu, residual=-1, site=None, stem=False, shortcut=None, site_inner=False):
         """conv (+ folded BN) op.  ``shortcut=(x2, conv1x1, bn)`` fuses the BasicBlock downsample path into this
-        conv as extra K-steps: both BN scales are folded into the fp16 weights, the biases are summed."""
+        conv as extra K-steps: both BN scales are folded into the fp16 weights, the biases are summed.
+        ``site_inner``: the site sits between the conv and its BatchNorm (converter/pytorch rule):
+        out = relu((conv*scale + scale*conv.bias) * mask + bn_shift)."""
         h, w, cin = self.tensors[x]
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -81,6 +85,13 @@ class GraphBuilder:
         else:
             scale = torch.ones(conv.out_channels)
             bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels)
+        bias_post = None
+        if site_inner and site is not None:
+            if bn is None or shortcut is not None:
+                raise ValueError("an inner site needs a BatchNorm behind the conv and no fused shortcut")
+            scale, shift = fold_bn(bn, None)
+            bias_post = shift
+            bias = scale * conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(scale)
         wk = conv.weight.detach().permute(0, 2, 3, 1)          # [Cout][ky][kx][Cin]
         in2, w2dev = -1, None
         if shortcut is not None:
@@ -105,7 +116,9 @@ class GraphBuilder:
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
                              stride=s, pad=p, relu=int(relu), weight=wdev, weight_packed=packed, in2=in2, weight2=w2dev,
                              scale=self.dev(scale, torch.float32) if scale is not None else None,
-                             bias=self.dev(bias, torch.float32), site=site))
+                             bias=self.dev(bias, torch.float32), site=site,
+                             bias_post=self.dev(bias_post, torch.float32) if bias_post is not None else None,
+                             site_pos=_lib.SITE_POS_INNER if bias_post is not None else _lib.SITE_POS_OUTER))
         return out
 
     def mask(self, x, site):
@@ -132,7 +145,8 @@ class GraphBuilder:
                              bias=self.dev(linear.bias, torch.float32), site=site))
         return out
 
-    def head(self, x, linear, exit_index, site=None):
+    def head(self, x, linear, exit_index, site=None, site_on_logits=False):
+        """relu -> global average pool -> [site] -> Linear -> [site on the logits] -> softmax."""
         c_in = self.tensors[x][2]
         if linear.in_features != c_in:
             raise ValueError(f"classifier expects {linear.in_features} features, pooled tensor has {c_in}")
@@ -140,7 +154,8 @@ class GraphBuilder:
         w = torch.zeros(cpad, c_in)
         w[:linear.out_features] = linear.weight.detach().float()
         self.ops.append(dict(kind=_lib.OP_HEAD, in_=x, out=exit_index, residual=-1,
-                             weight=self.dev(w, torch.float32), bias=self.dev(linear.bias, torch.float32), site=site))
+                             weight=self.dev(w, torch.float32), bias=self.dev(linear.bias, torch.float32), site=site,
+                             site_pos=_lib.SITE_POS_INNER if (site_on_logits and site) else _lib.SITE_POS_OUTER))
 
 
 def _unwrap(module):
@@ -260,7 +275,8 @@ class CompiledGraph:
             d.kind, d.in_, d.out, d.residual = op["kind"], op["in_"], op["out"], op.get("residual", -1)
             d.ksize, d.stride, d.pad, d.relu = op.get("ksize", 0), op.get("stride", 0), op.get("pad", 0), op.get("relu", 0)
             d.in2 = op.get("in2", -1)
-            for f in ("weight", "weight2", "weight_packed", "scale", "bias"):
+            d.site_pos = op.get("site_pos", _lib.SITE_POS_OUTER)
+            for f in ("weight", "weight2", "weight_packed", "scale", "bias", "bias_post"):
                 t = op.get(f)
                 setattr(d, f, t.data_ptr() if t is not None else None)
             s = op.get("site")

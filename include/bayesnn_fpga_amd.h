@@ -67,6 +67,9 @@ typedef void* bmi_stream; /* hipStream_t */
 #define BMI_SITE_CHANNEL 2     /* dropout2d semantics: one Bernoulli per (image, channel)      */
 #define BMI_SITE_MASKSEMBLE 3  /* x * masks[(cnt0 + t) mod M][channel], no rescale             */
 
+#define BMI_SITE_POS_OUTER 0 /* after scale/bias/residual/ReLU (HEAD: on the pooled features) */
+#define BMI_SITE_POS_INNER 1 /* between the layer and what follows it (see bmi_op_desc)       */
+
 typedef struct bmi_site {
     int32_t kind;        /* BMI_SITE_*                                                  */
     int32_t site_id;     /* call-order index of the stochastic layer inside one forward */
@@ -106,6 +109,14 @@ typedef struct bmi_op_desc {
     const float* bias;   /* device fp32 [Cout] folded BN bias / Linear bias            */
     bmi_site site;       /* CONV/STEM/MASK: applied to the op's output; HEAD: applied to
                             the pooled features before the Linear                      */
+    /* "inner" sites — the converter/pytorch insertion rule (Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45,
+     * Dropouts.py:25-56) wraps the layer itself, so the mask lands BEFORE a following BatchNorm / on the logits:
+     *   CONV/STEM/MASK, site_pos = BMI_SITE_POS_INNER:
+     *       out = relu?( (conv * scale + bias) * mask + bias_post (+ residual) )
+     *       (scale/bias: the BN scale and scale * conv.bias; bias_post: the BN shift; no outer site then)
+     *   HEAD, site_pos = BMI_SITE_POS_INNER: logits = (Linear(pool(x))) * mask  (dropout after the last layer) */
+    const float* bias_post; /* device fp32 [Cout] or NULL (only read with BMI_SITE_POS_INNER)      */
+    int32_t site_pos;       /* BMI_SITE_POS_*                                                      */
 } bmi_op_desc;
 
 typedef struct bmi_model_desc {
@@ -215,6 +226,11 @@ int bmi_pool_mask(const void* in, float* feat, int32_t n, int32_t in_mod, int32_
 /* logits[n][c] = feat[n] . weight[c] + bias[c];  probs = softmax(logits)   (fp32 [n][out_dim]) */
 int bmi_linear_softmax(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
                        int32_t n, int32_t k, int32_t out_dim, bmi_stream stream);
+/* the same with dropout on the LOGITS (site on the [batch, out_dim] tensor, sample index n / batch + t0): the
+ * converter/pytorch rule wraps the last Linear too (nn2bnn.py:33-45).  site NULL = none; ELEMENTWISE only. */
+int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
+                            int32_t n, int32_t k, int32_t out_dim, const bmi_site* site, int32_t batch, int32_t t0,
+                            uint64_t seed, bmi_stream stream);
 
 /* S1/S2/SL [batch][out_dim] += sum over the tc samples of probs / probs^2 / logits ([tc][batch][out_dim]) */
 int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,

@@ -31,3 +31,14 @@ def build_seeded(cls, kwargs, torch_seed=0, np_seed=0):
     torch.manual_seed(torch_seed)
     np.random.seed(np_seed)
     return cls(**kwargs)
+
+
+def converter_cnn():
+    """Same layers, same construction order as tools/gen_golden.py:converter_cnn (the converter fixtures' model)."""
+    from torch import nn
+    return nn.Sequential(
+        nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2, 2)),
+        nn.Sequential(nn.Conv2d(64, 128, 3, padding=1, bias=False), nn.BatchNorm2d(128), nn.ReLU(), nn.MaxPool2d(2, 2)),
+        nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2, 2)),
+        nn.Sequential(nn.Conv2d(256, 256, 3, padding=1), nn.BatchNorm2d(256), nn.ReLU()),
+        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(256, 10))

@@ -1,0 +1,105 @@
+"""converter/pytorch "nn2bnn" (SURVEY.md §8.1 A11): dropout after EVERY Conv2d (per image-channel, before the
+BatchNorm), MaxPool and Linear (elementwise, including the logits).  The golden vectors come from the reference's own
+Dropouts.py classes and nn2bnn._convert_model (tools/gen_golden.py:gen_converter)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from bayesnn_fpga_amd.converter.pytorch import BayesianDropout, BayesianDropout2D, MCDropout, _convert_model
+from bayesnn_fpga_amd.engine import CompiledGraph
+from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
+from oracle import mcd
+from oracle.converter import ConvertedNet
+from tests.helpers import converter_cnn, load_golden, state_checksum
+
+
+def _seeded_cnn():
+    torch.manual_seed(0)
+    return converter_cnn()
+
+
+def test_oracle_converter_matches_reference():
+    g = load_golden("converter_cnn.npz")
+    net = _seeded_cnn()
+    assert state_checksum(net.state_dict()) == str(g["init_checksum"])
+    synthetic_weights_(net, 0)
+    assert state_checksum(net.state_dict()) == str(g["weights_checksum"])
+    o = ConvertedNet(net, float(g["p"]))
+    x = synthetic_images(int(g["B"]), seed=1234)
+    logits = mcd.mcd_passes(o, x, int(g["T"]), int(g["seed"]))[0]
+    np.testing.assert_allclose(logits, g["logits"], atol=1e-6)
+    assert np.abs(g["logits"][0] - g["logits"][1]).max() > 1e-2          # the passes do differ
+
+
+def test_mirror_convert_model_structure_and_errors():
+    g = load_golden("converter_cnn.npz")
+    model = _convert_model(_seeded_cnn(), float(g["p"]))
+    wrappers = [type(m).__name__ for m in model.modules() if isinstance(m, (BayesianDropout, BayesianDropout2D))]
+    assert wrappers == list(g["wrapper_classes"])
+    assert list(model.state_dict().keys()) == list(g["keys"])
+    assert isinstance(_convert_model(nn.Linear(4, 4), 0.5), BayesianDropout)          # a bare layer comes back wrapped
+    with pytest.raises(ValueError) as e:
+        BayesianDropout(nn.Linear(2, 2), p=1.5)
+    assert str(e.value) == str(g["bad_p_error"])
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model(torch.zeros(1, 3, 32, 32))
+
+
+def test_wrapper_compiles_and_rejects_what_the_engine_cannot_run():
+    m = MCDropout(_seeded_cnn(), nSamples=4, p=0.25)
+    assert m.out_dim == 10 and m.n_exits == 1 and m.nSamples == 4
+    cg = CompiledGraph(m, "cpu", 8, 2)
+    # stem conv stays in the once-per-batch prefix; its mask / BN shift / ReLU run in the suffix
+    assert cg.n_prefix_ops == 1 and cg.n_exits == 1
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(1, 3, 32, 32))
+
+    class Custom(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = nn.Linear(8, 8)
+
+        def forward(self, x):
+            return self.fc(x)
+
+    with pytest.raises(TypeError):
+        CompiledGraph(MCDropout(Custom(), 2, 0.5), "cpu", 4, 1)
+    bad = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.MaxPool2d(3, 3), nn.Flatten(), nn.Linear(64, 10))
+    with pytest.raises(TypeError):
+        CompiledGraph(MCDropout(bad, 2, 0.5), "cpu", 4, 1)
+
+
+@pytest.mark.gpu
+def test_gpu_converted_cnn_against_reference_golden():
+    g = load_golden("converter_cnn.npz")
+    B, T, seed, p = int(g["B"]), int(g["T"]), int(g["seed"]), float(g["p"])
+    net = _seeded_cnn()
+    synthetic_weights_(net, 0)
+    m = MCDropout(net, nSamples=T, p=p).to("cuda:0")
+    m.mc_seed = seed
+    x = synthetic_images(B, seed=1234).to("cuda:0")
+    m.train()                                                   # training mode: one stochastic pass per call
+    passes = np.stack([m(x).cpu().numpy()[None] for _ in range(T)])
+    np.testing.assert_allclose(passes, g["logits"], rtol=0, atol=2e-2)
+    zero = g["logits"] == 0                                     # dropped logits are exactly zero
+    assert zero.any() and np.array_equal(passes == 0, zero)
+    m.eval()
+    m.mc_pass = 0
+    mean_logits = m(x).cpu().numpy()                            # eval mode: sum(pred) / len(pred) over nSamples
+    np.testing.assert_allclose(mean_logits, g["logits"].mean(0)[0], rtol=0, atol=1e-2)
+    ref_probs = torch.softmax(torch.from_numpy(g["logits"]), -1).numpy().astype(np.float64)
+    r = m.engine(x.device, max_batch=B).predict(x, T, seed=seed)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref_probs.mean(0), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(r["var"].cpu().numpy(), ref_probs.var(0), rtol=0, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_converted_cnn_chunking_invariance():
+    net = _seeded_cnn()
+    synthetic_weights_(net, 0)
+    m = MCDropout(net, nSamples=3, p=0.5).to("cuda:0")
+    x = synthetic_images(9, seed=5).to("cuda:0")
+    S = [m.engine(x.device, max_batch=9, chunk_samples=c).accumulate(x, m.engine(x.device).new_moments(9), 0, 6, 77).cpu()
+         for c in (1, 4)]
+    torch.testing.assert_close(S[0], S[1], rtol=1e-12, atol=1e-12)

@@ -329,3 +329,30 @@ def test_conv_pair_rejects_bad_splits():
                            ca, cb, 3, 1, 1, 1, gh.stream())
     assert lib.bmi_conv_pair_fwd(*args(64, 192)) == -22        # first half must be a multiple of 128 channels
     assert lib.bmi_conv_pair_fwd(*args(128, 64)) == -95        # total not a multiple of the 256-channel tile
+
+
+@pytest.mark.parametrize("out_dim", [10, 100])
+def test_linear_softmax_with_dropout_on_the_logits(out_dim):
+    """converter/pytorch wraps the last Linear too: logits * mask / (1-p), then softmax; bit-exact mask."""
+    lib = _lib.lib()
+    B, tc, K, t0, seed = 7, 3, 256, 2, 99
+    N = B * tc
+    g = _gen(3)
+    feat = torch.randn(N, K, generator=g).to(DEV)
+    w = torch.zeros((out_dim + 31) // 32 * 32, K)
+    w[:out_dim] = 0.1 * torch.randn(out_dim, K, generator=g)
+    b = 0.2 * torch.randn(out_dim, generator=g)
+    wd, bd = w.to(DEV), b.to(DEV)
+    logits = torch.empty(N, out_dim, device=DEV)
+    probs = torch.empty(N, out_dim, device=DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=7, p=0.25)
+    keep = []
+    s = gh.site_struct(site, keep)
+    _lib.check(lib.bmi_linear_softmax_site(gh.ptr(feat), gh.ptr(wd), gh.ptr(bd), gh.ptr(logits), gh.ptr(probs), N, K, out_dim,
+                                           C.byref(s), B, t0, seed, gh.stream()), "bmi_linear_softmax_site")
+    torch.cuda.synchronize()
+    mult = gh.folded_site_mask(site, B, out_dim, 1, 1, tc, t0, seed).reshape(N, out_dim).double()
+    ref_l = (feat.cpu().double() @ w[:out_dim].double().T + b.double()) * mult
+    torch.testing.assert_close(logits.cpu().double(), ref_l, rtol=1e-5, atol=2e-5)
+    assert torch.equal(logits.cpu() == 0, mult == 0) and (mult == 0).any()
+    torch.testing.assert_close(probs.cpu().double(), torch.softmax(ref_l, 1), rtol=1e-4, atol=1e-6)

@@ -310,8 +310,81 @@ def gen_philox():
     np.savez_compressed(os.path.join(OUT, "philox_masks.npz"), cases=np.array(cases, dtype=object), allow_pickle=True)
 
 
+def converter_cnn():
+    """The small sequential CNN of the converter fixtures (shared with tests/helpers.py by construction order)."""
+    from torch import nn
+    return nn.Sequential(
+        nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2, 2)),
+        nn.Sequential(nn.Conv2d(64, 128, 3, padding=1, bias=False), nn.BatchNorm2d(128), nn.ReLU(), nn.MaxPool2d(2, 2)),
+        nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2, 2)),
+        nn.Sequential(nn.Conv2d(256, 256, 3, padding=1), nn.BatchNorm2d(256), nn.ReLU()),
+        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(256, 10))
+
+
+def gen_converter():
+    """Hardware_Artifact/converter/pytorch: the reference's own Dropouts.py classes and nn2bnn._convert_model applied
+    to a small CNN.  nn2bnn.py imports a file that is not in the repository (``test.ThreeLayerNet``, :5): an empty
+    module of that name is registered so that the import statement passes; nothing of it is used.  Patched: only
+    F.dropout / F.dropout2d (the Bernoulli source), as for the other fixtures."""
+    conv_dir = "/root/reference/Hardware_Artifact/converter/pytorch"
+    sys.path.insert(0, conv_dir)
+    saved_test = sys.modules.get("test"), sys.modules.get("test.ThreeLayerNet")
+    t = types.ModuleType("test")
+    tl = types.ModuleType("test.ThreeLayerNet")
+    tl.ThreeLayerNet = None
+    t.ThreeLayerNet = tl
+    sys.modules["test"], sys.modules["test.ThreeLayerNet"] = t, tl
+    import Dropouts as ref_dropouts
+    import nn2bnn as ref_nn2bnn
+    for k, v in zip(("test", "test.ThreeLayerNet"), saved_test):
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    sys.path.remove(conv_dir)
+
+    def d2(x, p=0.5, training=True, inplace=False):
+        assert training
+        return philox_dropout(CTX, x, p, channelwise=True)
+
+    B, T, seed, p = 5, 6, 1234, 0.25
+    torch.manual_seed(0)
+    net = converter_cnn()
+    init = state_checksum(net.state_dict())
+    synthetic_weights_(net, 0)
+    wsum = state_checksum(net.state_dict())
+    model = ref_nn2bnn._convert_model(net, p)
+    classes = [type(m).__name__ for m in model.modules() if isinstance(m, ref_dropouts._DropoutBase)]
+    x = synthetic_images(B, seed=1234)
+    model.eval()
+    outs = []
+    orig = ref_dropouts.F.dropout, ref_dropouts.F.dropout2d
+    ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = _patched_dropout, d2
+    try:
+        with torch.no_grad():
+            for tt in range(T):
+                CTX.begin_forward(seed, tt)
+                outs.append(model(x).numpy()[None])
+    finally:
+        ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = orig
+    logits = np.stack(outs)                      # [T, 1, B, C]
+    err = ""
+    try:
+        ref_dropouts.BayesianDropout(torch.nn.Linear(2, 2), p=1.5)
+    except ValueError as e:
+        err = str(e)
+    np.savez(os.path.join(OUT, "converter_cnn.npz"), logits=logits, B=B, T=T, seed=seed, p=p, init_checksum=init,
+             weights_checksum=wsum, wrapper_classes=np.array(classes), keys=np.array(list(model.state_dict().keys())),
+             bad_p_error=err)
+    print("converter_cnn", logits.shape, classes, float(np.abs(logits).max()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "converter":
+        gen_converter()
+        sys.exit(0)
+    gen_converter()
     gen_philox()
     gen_masksembles()
     gen_metrics()
