@@ -92,6 +92,21 @@ def hbm_traffic(workload, launches_per_step):
     return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / n, os.path.relpath(path, ROOT)
 
 
+def pmc_sq(workload, family):
+    """Launch-weighted SQ/GRBM figures of one conv kernel family from the same committed PMC summary (third pass of
+    tools/profile_bench.sh): MFMA-pipe busy share and effective shader clock.  {} when absent."""
+    path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
+    if not os.path.exists(path):
+        return {}
+    ks = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(family) and "sq" in v
+          and v["sq"]["mfma_busy_share"] > 0.05]          # (a 5-launch instantiation reads 0.04: counter glitch, skipped)
+    n = sum(v["launches"] for v in ks)
+    if not n:
+        return {}
+    return {"mfma_busy_share_pmc": round(sum(v["sq"]["mfma_busy_share"] * v["launches"] for v in ks) / n, 4),
+            "effective_clock_ghz_pmc": round(sum(v["sq"]["effective_clock_ghz"] * v["launches"] for v in ks) / n, 3)}
+
+
 def cpu_baseline(wl, batch, T, seed):
     """The oracle (port of FullAnalysis._get_output, T sequential full forwards per batch, fp32) on
     the host cores.  Returns (MCD-samples/s, threads, mean probs)."""
@@ -217,7 +232,8 @@ def main():
                          "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                          "by_kernel": {k: {"launches": int(v["launches"]), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
                                            "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                           **(pmc_sq(a.workload, k) if traffic is not None else {})}
                                        for k, v in eng.conv_families.items()},
                          "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
         }

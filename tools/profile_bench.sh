@@ -11,7 +11,8 @@ ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_sq -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_sq.log 2>&1
 cd $R
-python3 tools/pmc_summary.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/hbm_traffic_$W.json --note "bench.py $ARGS"
+python3 tools/pmc_summary.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/hbm_traffic_$W.json --note "bench.py $ARGS" --sq gpurun_out/${TAG}_sq
 find gpurun_out/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
 tail -1 gpurun_out/${TAG}_stats.log
