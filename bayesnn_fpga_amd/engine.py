@@ -23,6 +23,7 @@ from . import _lib
 from .utils import Masksembles1D, Masksembles2D
 
 DEFAULT_CHUNK_IMAGES = 25600      # image-samples folded into one suffix launch (tuned on MI355X)
+DEFAULT_CHUNK_SAMPLES_MAX = 128   # ... but never more than this many samples (the workspace is sized for a full chunk)
 
 
 def _is_site(m):
@@ -248,8 +249,9 @@ class CompiledGraph:
         self.out_dim = int(model.out_dim)
         self.graph = build_graph(model, self.device)
         self.max_batch = int(max_batch)
+        self.chunk_explicit = chunk_samples is not None
         if chunk_samples is None:
-            chunk_samples = max(1, DEFAULT_CHUNK_IMAGES // self.max_batch)
+            chunk_samples = min(DEFAULT_CHUNK_SAMPLES_MAX, max(1, DEFAULT_CHUNK_IMAGES // self.max_batch))
         self.chunk_samples = int(chunk_samples)
         self._desc_keep = self._make_desc()
         self.handle = C.c_void_p()

@@ -30,8 +30,15 @@ class EngineModelMixin:
         eng = self._engines.get(key)
         need_b = max_batch or 1
         if eng is None or eng.max_batch < need_b or (chunk_samples and eng.chunk_samples != chunk_samples):
-            eng = MCDEngine(self, device, max_batch=max(need_b, eng.max_batch if eng else 0),
-                            chunk_samples=chunk_samples or (eng.chunk_samples if eng else None))
+            # an explicit chunk size sticks; the default is re-derived from the new batch size (it is sized in
+            # image-samples per launch: carrying a small batch's chunk over to a larger batch multiplied the workspace)
+            if chunk_samples is None and eng is not None and eng.chunk_explicit:
+                chunk_samples = eng.chunk_samples
+            grown = max(need_b, eng.max_batch if eng else 0)
+            if eng is not None:
+                eng.close()
+                eng.workspace = None
+            eng = MCDEngine(self, device, max_batch=grown, chunk_samples=chunk_samples)
             self._engines[key] = eng
         return eng
 

@@ -147,3 +147,49 @@ def test_pair_fusion_is_invisible(monkeypatch):
     assert eng2.n_suffix_ops == n_fused + 3                     # three pairs in ResNet-18 multi-exit with block dropout
     S_plain = eng2.accumulate(x, eng2.new_moments(B), 0, T, seed).cpu()
     assert torch.equal(S_fused, S_plain)
+
+
+def test_hipgraph_capture_and_replay():
+    """The library neither allocates nor synchronises inside bmi_forward_mcd / bmi_finalize, so a whole predict() is
+    capturable into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replays on new inputs: the launch-bound small-batch
+    serving case.  Replay must equal the eager result bit for bit."""
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    model = _product(ResNet18MCEarlyExit, kw)
+    B, T, seed = 4, 6, 21
+    eng = model.engine(torch.device(DEV), max_batch=B)
+    x_static = synthetic_images(B, seed=1).to(DEV)
+    S = eng.new_moments(B)
+    out_static = {}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up on the capture stream (module load, first launches)
+        eng.accumulate(x_static, S.zero_(), 0, T, seed)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        S.zero_()
+        eng.accumulate(x_static, S, 0, T, seed)
+        out_static.update(eng.finalize(S, T))
+    for s in (2, 3):
+        x_new = synthetic_images(B, seed=s).to(DEV)
+        x_static.copy_(x_new)
+        graph.replay()
+        torch.cuda.synchronize()
+        eager = eng.predict(x_new, T, seed=seed)
+        for k in ("mean", "var", "logit_mean"):
+            assert torch.equal(out_static[k], eager[k]), k
+
+
+def test_engine_regrowth_rederives_the_default_chunk():
+    """model.engine() grown from a small to a larger batch must not carry the small batch's samples-per-chunk over
+    (that multiplied the workspace: 226 GiB at B=32 after a B=8 engine); an explicit chunk size sticks."""
+    model = _product(ResNet18MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    dev = torch.device(DEV)
+    e1 = model.engine(dev, max_batch=2)
+    assert e1.chunk_samples == 128 and not e1.chunk_explicit
+    e2 = model.engine(dev, max_batch=400)
+    assert e2 is not e1 and e2.max_batch == 400 and e2.chunk_samples == 25600 // 400
+    assert e2.workspace_bytes < 40 * 2**30
+    e3 = model.engine(dev, max_batch=400, chunk_samples=3)
+    e4 = model.engine(dev, max_batch=500)
+    assert e3.chunk_samples == 3 and e4.chunk_samples == 3 and e4.max_batch == 500
