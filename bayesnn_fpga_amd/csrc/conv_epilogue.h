@@ -52,8 +52,10 @@ __device__ __forceinline__ PixelCtx make_pixel_ctx(const ConvArgs& a, int n, int
     return p;
 }
 
-// the stochastic site on one accumulator quad (4 consecutive channels c4.. of pixel p)
-__device__ __forceinline__ void site_quad(const ConvArgs& a, const PixelCtx& p, float v[4], int c4) {
+// multipliers of the stochastic site for one accumulator quad (4 consecutive channels c4.. of pixel p)
+__device__ __forceinline__ void site_mult4(const ConvArgs& a, const PixelCtx& p, int c4, float m[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = 1.f;
     if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
         const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)p.e_pix * a.Cout + c4
                                                                   : (uint64_t)p.b * a.Cout + c4;
@@ -62,11 +64,10 @@ __device__ __forceinline__ void site_quad(const ConvArgs& a, const PixelCtx& p, 
         const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p.t, (uint32_t)a.site.site_id,
                                          a.site.seed_lo, a.site.seed_hi);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            v[e] = (!a.site.drop_all && philox_keep(rn, e0 + e, a.site.thresh)) ? v[e] * a.site.scale : 0.f;
+        for (int e = 0; e < 4; ++e) m[e] = (!a.site.drop_all && philox_keep(rn, e0 + e, a.site.thresh)) ? a.site.scale : 0.f;
     } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
         const float4 k4 = *(const float4*)(p.mrow + c4);
-        v[0] *= k4.x; v[1] *= k4.y; v[2] *= k4.z; v[3] *= k4.w;
+        m[0] = k4.x; m[1] = k4.y; m[2] = k4.z; m[3] = k4.w;
     }
 }
 
@@ -82,8 +83,11 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
         const float4 b4 = *(const float4*)(a.bias + c4);
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
     }
+    float m[4];
+    site_mult4(a, p, c4, m);
     if (a.site_inner) {
-        site_quad(a, p, v, c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
         if (a.bias_post) {
             const float4 b4 = *(const float4*)(a.bias_post + c4);
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
@@ -98,7 +102,10 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    if (!a.site_inner) site_quad(a, p, v, c4);
+    if (!a.site_inner) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
+    }
     half4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
@@ -204,8 +211,14 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, f32x16_e (&acc
     }
 }
 
-// the stochastic site on 8 consecutive channels c8.. of one pixel (one Philox call)
-__device__ __forceinline__ void site_oct(const ConvArgs& a, const PixelCtx& px, float v[8], int c8) {
+// Multipliers of the stochastic site for 8 consecutive channels c8.. of one pixel (one Philox call): 0 for a dropped
+// element, 1/(1-p) for a kept one, the mask value for Masksembles, 1 without a site.  The site code is expanded ONCE per
+// item and applied through `m` wherever the site sits (inner / outer): a second expansion pushed the item loop past
+// hipcc's full-unroll budget, the accumulator and residual arrays became dynamically indexed and moved to scratch
+// (1 KB per lane, the kernel ran 10x slower) — tests/test_build_resources.py now checks ScratchSize == 0.
+__device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px, int c8, float m[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = 1.f;
     if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
         const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)px.e_pix * a.Cout + c8
                                                                   : (uint64_t)px.b * a.Cout + c8;
@@ -213,12 +226,11 @@ __device__ __forceinline__ void site_oct(const ConvArgs& a, const PixelCtx& px, 
         const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)px.t,
                                          (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            v[e] = (!a.site.drop_all && philox_keep(rn, e, a.site.thresh)) ? v[e] * a.site.scale : 0.f;
+        for (int e = 0; e < 8; ++e) m[e] = (!a.site.drop_all && philox_keep(rn, e, a.site.thresh)) ? a.site.scale : 0.f;
     } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
         const f32x4_e k0 = *(const f32x4_e*)(px.mrow + c8), k1 = *(const f32x4_e*)(px.mrow + c8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] *= k0[e]; v[4 + e] *= k1[e]; }
+        for (int e = 0; e < 4; ++e) { m[e] = k0[e]; m[4 + e] = k1[e]; }
     }
 }
 
@@ -295,8 +307,11 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] * sc0[e] + bi0[e]; v[4 + e] = hi[e] * sc1[e] + bi1[e]; }
             const int c8 = ch0 + 8 * k;
-            if (a.site_inner) {
-                site_oct(a, px, v, c8);
+            float m[8];
+            site_mult8(a, px, c8, m);
+            if (a.site_inner) {   // mask between the conv and its BatchNorm shift (converter/pytorch rule)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
                 if (a.bias_post) {
                     const f32x4_e p0 = *(const f32x4_e*)(a.bias_post + c8), p1 = *(const f32x4_e*)(a.bias_post + c8 + 4);
 #pragma unroll
@@ -311,7 +326,10 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (!a.site_inner) site_oct(a, px, v, c8);
+            if (!a.site_inner) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
+            }
             half8_e o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];

@@ -1,0 +1,29 @@
+"""Build-time guard for the conv kernels (no GPU needed: hipcc cross-compiles): every product instantiation must keep
+its accumulators in registers — ScratchSize 0 and no VGPR spill.  A correct-but-10x-slower build slipped through the
+parity tests once (an extra inlined Philox expansion pushed the epilogue's item loop past the full-unroll budget and
+the accumulator arrays moved to scratch), which is what this pins."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from bayesnn_fpga_amd import _build
+
+FILES = ["conv3x3_patch.hip", "conv_igemm_wide.hip", "conv_igemm.hip"]
+EXPERIMENTAL = re.compile(r"conv3x3_patch_kernelILi2E")      # stride-2 patch configs (BMI_PATCH_S2=1 only)
+
+
+@pytest.mark.parametrize("src", FILES)
+def test_conv_kernels_have_no_scratch_and_no_spills(src):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([hipcc, *_build.FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(_build.CSRC, src),
+                        "-o", os.devnull], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels = re.findall(r"Function Name: (\S+).*?VGPRs Spill: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
+    assert kernels, "no kernel-resource-usage remarks in the hipcc output"
+    bad = [(n, sp, sc) for n, sp, sc in kernels if not EXPERIMENTAL.search(n) and (int(sp) or int(sc))]
+    assert not bad, f"kernels with VGPR spills / scratch: {bad}"
