@@ -356,3 +356,26 @@ def test_linear_softmax_with_dropout_on_the_logits(out_dim):
     torch.testing.assert_close(logits.cpu().double(), ref_l, rtol=1e-5, atol=2e-5)
     assert torch.equal(logits.cpu() == 0, mult == 0) and (mult == 0).any()
     torch.testing.assert_close(probs.cpu().double(), torch.softmax(ref_l, 1), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,kwargs", [("S2", dict(with_res=True, with_site=True)), ("S2", dict(with_res=False, with_site=False)),
+                                         ("D3", dict(with_res=False, with_site=False)), ("S4", dict(with_res=True, with_site=False))])
+def test_conv_kernels_are_not_pathologically_slow(name, kwargs):
+    """Coarse speed floor (a 10x regression guard, not a benchmark): the epilogue once fell into scratch memory and
+    the parity tests still passed.  Healthy kernels run these shapes at 500-1000 TFLOP/s; the floor is 150."""
+    cin, cout, H, k, s, p = SHAPES[name]
+    n = 4000
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, n, 3, False)
+    ho = (H + 2 * p - k) // s + 1
+    res = torch.randn(n, ho, ho, cout, generator=g).to(torch.float16).to(DEV) if kwargs["with_res"] else None
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=1, p=0.25) if kwargs["with_site"] else None
+    run = lambda: gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=250, seed=1)
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    tflops = 3 * 2.0 * n * ho * ho * cout * k * k * cin / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    assert tflops > 150, f"{name} {kwargs}: {tflops:.0f} TFLOP/s"

@@ -29,6 +29,9 @@ def _oracle_accumulate(model, x, seed):
     from oracle import mcd
 
     def fn(S, t0, n):
+        for m in model.modules():          # Masksembles layers pick mask (cnt0 + t) mod M for global sample t:
+            if hasattr(m, "cnt"):          # a shard that starts at t0 starts at that layer state (cnt0 = 0 here)
+                m.cnt = t0 % m.n
         logits, probs = mcd.mcd_passes(model, x, n, seed, t_begin=t0)
         S[0] += torch.from_numpy(probs.sum(0))
         S[1] += torch.from_numpy((probs ** 2).sum(0))
@@ -36,16 +39,26 @@ def _oracle_accumulate(model, x, seed):
     return fn
 
 
-def _worker(rank, world, port, T, out_path):
+KW_MC = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+KW_MASK = dict(dropout_exit=True, dropout="block", mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=10)
+
+
+def _build(kw):
+    from bayesnn_fpga_amd.synthetic import synthetic_weights_
+    from oracle.resnet18 import ResNet18MCEarlyExit
+    torch.manual_seed(0)
+    np.random.seed(0)
+    return synthetic_weights_(ResNet18MCEarlyExit(**kw), 0)
+
+
+def _worker(rank, world, port, T, out_path, kw=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
-    from oracle.resnet18 import ResNet18MCEarlyExit
-    torch.manual_seed(0)
-    model = synthetic_weights_(ResNet18MCEarlyExit(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10), 0)
+    from bayesnn_fpga_amd.synthetic import synthetic_images
+    model = _build(kw or KW_MC)
     x = synthetic_images(2, seed=1234)
     S = torch.zeros(3, 4, 2, 10, dtype=torch.float64)
     accumulate_sharded(_oracle_accumulate(model, x, 42), S, T)
@@ -63,13 +76,36 @@ def test_two_rank_gloo_equals_single_rank(tmp_path):
     out = str(tmp_path / "S.npy")
     mp.spawn(_worker, args=(2, port, T, out), nprocs=2, join=True)
     S2 = np.load(out)
-    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
-    from oracle.resnet18 import ResNet18MCEarlyExit
-    torch.manual_seed(0)
-    model = synthetic_weights_(ResNet18MCEarlyExit(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10), 0)
+    from bayesnn_fpga_amd.synthetic import synthetic_images
+    model = _build(KW_MC)
     x = synthetic_images(2, seed=1234)
     S1 = torch.zeros(3, 4, 2, 10, dtype=torch.float64)
     accumulate_sharded(_oracle_accumulate(model, x, 42), S1, T)         # no process group: single rank
     np.testing.assert_allclose(S2, S1.numpy(), rtol=1e-12, atol=1e-12)
     mean = S2[0] / T
     assert np.allclose(mean.sum(-1), 1.0, atol=1e-6)
+
+
+def test_two_rank_gloo_masksembles_shards_the_mask_indices(tmp_path):
+    """BASELINE config 3 style (Masksembles, T = M): rank g evaluates mask indices [lo_g, hi_g) on the whole batch,
+    one all-reduce gives the same moments as the single-rank sweep over all M masks."""
+    T = 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "S.npy")
+    mp.spawn(_worker, args=(2, port, T, out, KW_MASK), nprocs=2, join=True)
+    S2 = np.load(out)
+    from bayesnn_fpga_amd.synthetic import synthetic_images
+    model = _build(KW_MASK)
+    x = synthetic_images(2, seed=1234)
+    S1 = torch.zeros(3, 4, 2, 10, dtype=torch.float64)
+    accumulate_sharded(_oracle_accumulate(model, x, 42), S1, T)
+    np.testing.assert_allclose(S2, S1.numpy(), rtol=1e-12, atol=1e-12)
+    # the masks differ between passes: the two shards saw different masks
+    halves = []
+    for t0 in (0, 2):
+        Sh = torch.zeros(3, 4, 2, 10, dtype=torch.float64)
+        _oracle_accumulate(model, x, 42)(Sh, t0, 2)
+        halves.append(Sh.numpy())
+    assert np.abs(halves[0] - halves[1]).max() > 1e-3
