@@ -193,3 +193,52 @@ def test_engine_regrowth_rederives_the_default_chunk():
     e3 = model.engine(dev, max_batch=400, chunk_samples=3)
     e4 = model.engine(dev, max_batch=500)
     assert e3.chunk_samples == 3 and e4.chunk_samples == 3 and e4.max_batch == 500
+
+
+def test_edge_cases_and_error_behaviour():
+    """Smallest sizes, ragged batches and every argument error of the boundary (errno-style codes, nothing thrown
+    across the C ABI, nothing silently computed on the CPU)."""
+    import ctypes as C
+    from bayesnn_fpga_amd import _lib
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    model = _product(ResNet18MCEarlyExit, kw)
+    oracle_model = build_seeded(oresnet.ResNet18MCEarlyExit, kw)
+    synthetic_weights_(oracle_model, 0)
+    dev = torch.device(DEV)
+    eng = model.engine(dev, max_batch=5, chunk_samples=2)
+    # one image, one sample
+    x1 = synthetic_images(1, seed=4)
+    r = eng.predict(x1.to(DEV), 1, seed=9)
+    ref = mcd.mcd_predict(oracle_model, x1, 1, 9)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=TOL)
+    assert float(r["var"].abs().max()) < 1e-12                       # a single sample has no variance
+    # ragged: batch below max_batch, T not a multiple of the chunk, t_begin > 0
+    x3 = synthetic_images(3, seed=5)
+    r = eng.predict(x3.to(DEV), 5, seed=9, t_begin=7)
+    ref = mcd.mcd_predict(oracle_model, x3, 5, 9, t_begin=7)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(r["var"].cpu().numpy(), ref["var"], rtol=0, atol=TOL)
+    # host-side argument checks
+    with pytest.raises(ValueError):
+        eng.predict(synthetic_images(6, seed=1).to(DEV), 2)           # batch above max_batch
+    with pytest.raises(ValueError):
+        eng.predict(x3.to(DEV).double(), 2)                           # wrong dtype
+    with pytest.raises(ValueError):
+        eng.predict(torch.zeros(3, 3, 16, 16, device=DEV), 2)         # wrong image size
+    with pytest.raises(RuntimeError):
+        eng.predict(x3, 2)                                            # CPU tensor: no CPU path
+    # C-ABI error codes
+    S = eng.new_moments(3)
+    xd = x3.to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = lambda b, t0, tc, ws_bytes: (eng.handle, xd.data_ptr(), b, t0, tc, 1, 0, S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
+                                        eng.workspace.data_ptr(), ws_bytes, st)
+    assert eng.lib.bmi_forward_mcd(*args(3, 0, 0, eng.workspace_bytes)) == -22       # no samples
+    assert eng.lib.bmi_forward_mcd(*args(0, 0, 1, eng.workspace_bytes)) == -22       # empty batch
+    assert eng.lib.bmi_forward_mcd(*args(3, -1, 1, eng.workspace_bytes)) == -22
+    assert eng.lib.bmi_forward_mcd(*args(6, 0, 1, eng.workspace_bytes)) == -22       # above the planned batch
+    assert eng.lib.bmi_forward_mcd(*args(3, 0, 1, eng.workspace_bytes - 1)) == -12   # workspace too small
+    assert eng.lib.bmi_forward_mcd(None, xd.data_ptr(), 3, 0, 1, 1, 0, S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
+                                   eng.workspace.data_ptr(), eng.workspace_bytes, st) == -22
+    assert float(S.abs().max()) == 0.0                                               # rejected calls wrote nothing
+    assert _lib.error_string(-12) == "workspace too small"
