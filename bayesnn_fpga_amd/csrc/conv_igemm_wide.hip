@@ -59,8 +59,8 @@ extern "C" int bmi_debug_wide_stamps_clear() {
 #define STAMP_T0(V)
 #endif
 
-#ifndef BMI_WIDE_PIPE
-#define BMI_WIDE_PIPE 0
+#ifndef BMI_WIDE_PINGPONG
+#define BMI_WIDE_PINGPONG 1
 #endif
 #define WBC 256
 #define WBP 256
@@ -74,6 +74,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x;
     STAMP(0);
+#ifdef BMI_WIDE_STAMPS
+    // the cycle counter (slots 0-3) is not comparable between workgroups; the 100 MHz real-time counter (slots 5, 6) is
+    if (tid == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -135,13 +139,6 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
     const int b_off = WBC * 128 + (wp * 128 + r) * 128;
     const int sw_r = (r >> 1) & 7;
 
-#if BMI_WIDE_PIPE
-    half8 fa[2][TI], fb[2][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) fa[1][i] = half8{0, 0, 0, 0, 0, 0, 0, 0};   // the first "previous substep" adds zero
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) fb[1][j] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     const int nK = a.ksize * a.ksize * (a.Cin / 64);
     int ky = 0, kx = 0, c0 = 0;
     {
@@ -152,6 +149,85 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
             ISSUE_X(i, 0, 0, 0, st0);
         }
     }
+#if BMI_WIDE_PINGPONG
+    // ---- ping-pong main loop ------------------------------------------------------------------------------------
+    // A K-step is four phases (one 16-deep k-substep each); a phase is a LOAD part (6 ds_read_b128 of the substep's
+    // fragments + this wave's share of the next K-step's LDS-DMA), a barrier, an MFMA part (8 MFMAs at raised
+    // priority), a barrier.  The two channel halves (waves 0-3 / 4-7: one wave per SIMD each) run ONE BARRIER APART, so
+    // on every SIMD one wave is in its MFMA part while the other reads LDS and issues DMA: the matrix pipe never
+    // waits for a fragment read, and the barrier is the hand-over between the two waves, not an idle point.
+    // (With all eight waves in lockstep the same loop spent 570 cycles per K-step at the barrier, 370 waiting for
+    // the DMA and 2390 instead of 2048 in the MFMA phase: tools/wide_stamps.py.)
+    //
+    // Intervals between consecutive barriers, K-step T, phase k:  group 0: LOAD 8T+2k, MFMA 8T+2k+1
+    //                                                              group 1: LOAD 8T+2k+1, MFMA 8T+2k+2
+    // Raw s_barrier throughout (a __syncthreads() would drain the LDS-DMA: vmcnt(0)).  Hazards, by construction:
+    //   WAR  the other buffer was last read for K-step T-1 by group 1 in interval 8T-1 (retired by its lgkmcnt(0) at
+    //        the start of 8T): group 1 may refill it from 8T+1 (its phases 0,1), group 0 from 8T+2 (its phases 1,2).
+    //   RAW  every wave retires its own DMA (vmcnt(0)) in interval 8T+7, i.e. before the barrier that ends 8T+7;
+    //        the first reads of K-step T+1 are in 8T+8 (group 0) and 8T+9 (group 1).
+    // Both groups execute the same number of barriers: group 1 one extra at the start, group 0 one extra at the end.
+#define RAW_BARRIER()                                  \
+    {                                                  \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_sched_barrier(0);             \
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RAW_BARRIER();                      // K-step 0 has landed (every wave waited for its own pieces)
+    STAMP(1);
+    if (g == 1) RAW_BARRIER();          // stagger
+    const int dma_phase = g == 0 ? 1 : 0;
+    for (int ks = 0; ks < nK; ++ks) {
+        const int buf = ks & 1;
+        const bool more = ks + 1 < nK;
+        if (more) {
+            c0 += 64;
+            if (c0 == a.Cin) {
+                c0 = 0;
+                if (++kx == a.ksize) { kx = 0; ++ky; }
+            }
+        }
+        const int koff = (ky * a.ksize + kx) * a.Cin + c0;
+        char* nst = smem + (buf ^ 1) * WSTAGE;
+        const char* st = smem + buf * WSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            // LOAD part
+            const int coff = ((2 * kk + hh) ^ sw_r) << 4;
+            half8 af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(st + a_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(st + b_off + j * 32 * 128 + coff);
+            if (more && kk == dma_phase) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ISSUE_W(i, koff, nst);
+            }
+            if (more && kk == dma_phase + 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ISSUE_X(i, ky, kx, c0, nst);
+            }
+            if (kk == 3 && g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // interval 8T+7 (group 1: LOAD part)
+            RAW_BARRIER();
+            // MFMA part
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (kk == 3 && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // interval 8T+7 (group 0: MFMA part)
+            RAW_BARRIER();
+        }
+    }
+    if (g == 0) RAW_BARRIER();          // re-align the two groups before the epilogue reuses the LDS
+#undef RAW_BARRIER
+#else
     for (int ks = 0; ks < nK; ++ks) {
         const int buf = ks & 1;
         STAMP_T0(tw0);
@@ -173,30 +249,6 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         const int koff = (ky * a.ksize + kx) * a.Cin + c0;
         char* nst = smem + (buf ^ 1) * WSTAGE;
         const char* st = smem + buf * WSTAGE;
-#if BMI_WIDE_PIPE
-        // Fragment reads run one k-substep ahead in a second register set, and the MFMAs of a K-step's LAST substep
-        // are issued after the NEXT step's barrier: they cover the LDS latency of the first reads behind the barrier
-        // and keep the matrix pipe fed while the wave waits at it (one workgroup per CU: nobody else would).
-#define RD(KK, SET)                                                                                     \
-    {                                                                                                   \
-        const int coff_ = ((2 * (KK) + hh) ^ sw_r) << 4;                                                \
-        _Pragma("unroll") for (int i = 0; i < TI; ++i) fa[SET][i] = *(const half8*)(st + a_off + i * 32 * 128 + coff_); \
-        _Pragma("unroll") for (int j = 0; j < TJ; ++j) fb[SET][j] = *(const half8*)(st + b_off + j * 32 * 128 + coff_); \
-    }
-#define MM(SET, I) _Pragma("unroll") for (int j = 0; j < TJ; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][I], fb[SET][j], acc[I][j], 0, 0, 0);
-        RD(0, 0);
-        MM(1, 0); ISSUE_W(0, koff, nst); __builtin_amdgcn_sched_barrier(0);
-        MM(1, 1); ISSUE_X(0, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
-        RD(1, 1);
-        MM(0, 0); ISSUE_W(1, koff, nst); __builtin_amdgcn_sched_barrier(0);
-        MM(0, 1); ISSUE_X(1, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
-        RD(2, 0);
-        MM(1, 0); ISSUE_W(2, koff, nst); __builtin_amdgcn_sched_barrier(0);
-        MM(1, 1); ISSUE_X(2, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
-        RD(3, 1);
-        MM(0, 0); ISSUE_W(3, koff, nst); __builtin_amdgcn_sched_barrier(0);
-        MM(0, 1); ISSUE_X(3, ky, kx, c0, nst); __builtin_amdgcn_sched_barrier(0);
-#else
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int coff = ((2 * kk + hh) ^ sw_r) << 4;
@@ -214,14 +266,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
             ISSUE_X(kk, ky, kx, c0, nst);
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
         STAMP_ADD(6, tw1);
     }
-#if BMI_WIDE_PIPE
-    MM(1, 0);
-    MM(1, 1);
-#undef RD
-#undef MM
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ISSUE_W
@@ -252,6 +298,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
     };
     epilogue_coalesced<TJ, PLAIN>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
     STAMP(3);
+#ifdef BMI_WIDE_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Shapes the wide kernel takes.  `cout` is the launch's total channel count (both convs of a pair).

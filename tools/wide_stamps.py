@@ -26,11 +26,17 @@ e0.record(); run(); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 buf = (C.c_ulonglong * (8192 * 8))(); l.bmi_debug_wide_stamps(buf, 8192 * 8)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
-a = a[a[:, 0] > 0]
+a = a[(a[:, 0] > 0) & (a[:, 3] > 0)]
 t0 = a[:, 0].min()
 nK = k * k * cin // 64
 span = a[:, 3].max() - t0
-print(name, "WGs", len(a), "K-steps", nK, "kernel span (ticks)", span, f"elapsed {ms*1e3:.1f} us -> {span / (ms * 1e3):.0f} ticks/us")
+print(name, "WGs stamped", len(a), "K-steps", nK, "span of the stamped WGs (ticks)", span, f"kernel elapsed {ms*1e3:.1f} us")
+# slots 5/6: start / end on the 100 MHz real-time counter (comparable between workgroups)
+rt = (a[:, 6] - a[:, 5]) / 100.0          # lifetime in us
+span_us = (a[:, 6].max() - a[:, 5].min()) / 100.0
+print(f"  real-time: launch span {span_us:.1f} us, median workgroup lifetime {np.median(rt):.2f} us "
+      f"-> shader clock {np.median((a[:, 3] - a[:, 0]) / rt) / 1e3:.2f} GHz; CU occupancy by workgroups "
+      f"sum(lifetime) / (256 CUs x span) = {rt.sum() / (256.0 * span_us):.3f}")
 for nm, v in (("prologue", a[:, 1] - a[:, 0]), ("main", a[:, 2] - a[:, 1]), ("epilogue", a[:, 3] - a[:, 2]), ("lifetime", a[:, 3] - a[:, 0]),
-              ("sum vmcnt wait", a[:, 4]), ("sum wait+barrier", a[:, 5]), ("sum issue+mfma", a[:, 6]), ("sum issue", a[:, 7])):
+              ("sum vmcnt wait (BMI_WIDE_STAMPS=2)", a[:, 4])):
     print(f"  {nm:18s} median {np.median(v):10.0f}  p10 {np.percentile(v,10):10.0f}  p90 {np.percentile(v,90):10.0f}   per K-step {np.median(v)/nK:8.1f}")
