@@ -13,11 +13,16 @@ What is mirrored (same method names, argument meaning and return shapes):
 Differences, on purpose: ECE is the 15-bin equal-mass histogram ECE (``ece_hist_binary`` :446-495) because
 the reference's KDE-ECE needs KDEpy (parity unpinned); trackers are vectorised instead of the
 per-instance Python loop (:272-286); the extra output ``var`` (T-sample variance) is kept in ``self.var``.
-Out of scope here: confidence-threshold exiting and the analytical FLOP model (:543-734).
+  * ``save_validation``             :217-222 — the same 3-array ``.npy`` for a validation loader.
+  * ``get_confidence_exiting_values`` :543-566 with ``get_model_type`` :598-604, ``get_dropout_type`` :582-595,
+                                      ``get_flops_per_module`` :568-580 — the threshold sweep over the saved test
+                                      predictions, printed in the reference's line format (the arithmetic is in
+                                      ``confidence_exiting.py``, pinned to the reference).
 """
 import numpy as np
 import torch
 
+from . import confidence_exiting as cex
 from .metrics import ece_hist_binary, ece_kde_binary, nll_mse_acc
 
 
@@ -155,3 +160,58 @@ class FullAnalysis:
             np.save(f, self.ensemble_preds)
             np.save(f, self.labels)
         return name
+
+    def save_validation(self, experiment_id, loader):
+        preds, ensemble_preds, labels = self.get_validation_predictions(loader)
+        with open(f"validation_predictions_{experiment_id}.npy", "wb") as f:
+            np.save(f, preds)
+            np.save(f, ensemble_preds)
+            np.save(f, labels)
+
+    # -- confidence-threshold exiting (:543-604) -----------------------------------------------------------
+    def get_model_type(self):
+        fam = getattr(self.model, "family", None)
+        if fam == "vgg":
+            return "vgg19"
+        if fam == "resnet":
+            return "resnet18"
+        raise ValueError
+
+    def get_dropout_type(self):
+        """(exit_only, dropout_rate, mc_passes) — the reference hard-codes 10 passes here (:588) and falls back to
+        (True, 0, 1) for models without the dropout attributes (:590-594)."""
+        try:
+            if self.model.dropout_exit and self.model.dropout is None:
+                exit_only = True
+            elif self.model.dropout is not None:
+                exit_only = False
+            return exit_only, self.model.dropout_p, 10
+        except (AttributeError, UnboundLocalError):
+            return True, 0, 1
+
+    def get_flops_per_module(self):
+        f = cex.FLOPS[self.model_type]
+        self.n_exits = len(f["layer"])
+        self.flops_per_layer, self.flop_per_exit_convs, self.flops_per_exit = f["layer"], f["exit_convs"], f["exit_fc"]
+        self.baseline_flops = cex.baseline_flops(self.model_type)
+
+    def get_confidence_exiting_values(self, model_num):
+        self.model_type = self.get_model_type()
+        self.exit_only, dropout_rate, mc_passes = self.get_dropout_type()
+        self.get_flops_per_module()
+        with open(f"test_predictions_{model_num}.npy", "rb") as f:
+            p_evals = np.load(f)
+            ensembled_p_evals = np.load(f)
+            labels = np.load(f)
+        self.confidence_rows = cex.sweep(p_evals, ensembled_p_evals, labels, self.model_type, self.exit_only, mc_passes)
+        for r in self.confidence_rows:
+            th = r["threshold"]
+            if self.exit_only:
+                norm = self.baseline_flops * 10000
+                print(f"E ({dropout_rate},{th}), {r['accuracy']}, {r['ece']}, {r['flops'] / norm}, {r['nll']}")
+                print(f"Ensemble E ({dropout_rate},{th}), {r['ens_accuracy']}, {r['ens_ece']}, {r['ens_flops'] / norm}, {r['ens_nll']}")
+            elif self.model.dropout in ("block", "layer"):
+                tag = "B+E" if self.model.dropout == "block" else "L+E"
+                print(f"{tag} ({dropout_rate},{th}), {r['accuracy']}, {r['ece']}, ,{r['flops']}, {r['nll']}")
+                print(f"Ensemble {tag} ({dropout_rate},{th}), {r['ens_accuracy']}, {r['ens_ece']}, ,{r['ens_flops']}, {r['ens_nll']}")
+        return None
