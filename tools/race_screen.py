@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Race screen for the LDS-DMA kernels (the ping-pong loop of conv_igemm_wide orders its DMA writes and fragment reads
+by counted waits and raw barriers only): many launches of several shapes, every output compared bit for bit with the
+first launch of the same inputs, while a second stream keeps the memory system busy to perturb the timing.
+
+    python tools/race_screen.py [--rounds 300]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayesnn_fpga_amd import _lib  # noqa: E402
+
+SHAPES = [  # cin, cout, H, k, s, p, images
+    (128, 256, 16, 3, 2, 1, 333), (256, 512, 8, 3, 2, 1, 777), (64, 256, 32, 3, 2, 1, 130), (256, 512, 8, 1, 2, 0, 901),
+    (128, 128, 16, 3, 1, 1, 257), (256, 256, 8, 3, 1, 1, 515), (512, 512, 4, 3, 1, 1, 1031),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=300)
+    ap.add_argument("--scale", type=int, default=1, help="multiplies the image count of every shape")
+    a = ap.parse_args()
+    lib, dev = _lib.lib(), "cuda:0"
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(7)
+    cases = []
+    for cin, cout, H, k, s, p, n in SHAPES:
+        n = n * a.scale
+        x = torch.randn(n, H, H, cin, generator=g).half().to(dev)
+        w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).half().to(dev)
+        sc, bi = (0.5 + torch.rand(cout, generator=g)).to(dev), (0.1 * torch.randn(cout, generator=g)).to(dev)
+        ho = (H + 2 * p - k) // s + 1
+        out = torch.empty(n, ho, ho, cout, dtype=torch.float16, device=dev)
+        cases.append((x, w, sc, bi, out, (n, H, cin, cout, k, s, p)))
+
+    def run(c):
+        x, w, sc, bi, out, (n, H, cin, cout, k, s, p) = c
+        _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), None, sc.data_ptr(), bi.data_ptr(), None, out.data_ptr(),
+                                          n, n, n, H, H, cin, cout, k, s, p, 1, None, n, 0, 1, 0, st), "conv")
+    first = []
+    for c in cases:
+        run(c)
+        torch.cuda.synchronize()
+        first.append(c[4].clone())
+    noise_stream = torch.cuda.Stream()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    bad = 0
+    for r in range(a.rounds):
+        with torch.cuda.stream(noise_stream):
+            junk.add_(1)                                   # 0.5 GB of HBM traffic beside the convs
+        for i, c in enumerate(cases):
+            c[4].fill_(float("nan"))
+            run(c)
+        torch.cuda.synchronize()
+        for i, c in enumerate(cases):
+            if not torch.equal(c[4], first[i]):
+                bad += 1
+                d = (c[4].float() - first[i].float()).abs()
+                print(f"round {r} shape {SHAPES[i]}: {int((d > 0).sum())} elements differ, max {float(d.max()):.4g}", flush=True)
+    print(f"{a.rounds} rounds x {len(cases)} shapes: {bad} mismatching launches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
