@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="MC samples folded per suffix launch (0 = engine default)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the 1-GPU dry run)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="dry run of the N>1 code path on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-T", type=int, default=10, help="MC passes of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -135,13 +138,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from bayesnn_fpga_amd.sharding import shard_range
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
@@ -237,7 +245,7 @@ def main():
                                        for k, v in eng.conv_families.items()},
                          "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:        # the CPU baseline is reported at N=1 only
             cpu_val, threads, cpu_mean = cpu_baseline(wl, B, a.cpu_T, a.seed)
             gpu_same = eng.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()
             line["cpu_baseline"] = {
