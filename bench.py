@@ -15,11 +15,12 @@ combined with ONE all-reduce over RCCL per step.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 10 --warmup 3
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (conv_igemm, all launches of
-a step): algorithmic conv FLOPs / HIP-event time of those launches, measured on the launch stream in
-a separate profiled step right after the timed region (event records around every launch would
-perturb the timed steps).  `cpu_baseline` is the CPU oracle (a port of the reference loop) timed on
-this box's host cores on a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is for the conv kernels (94 % of a step: conv3x3_patch, conv_igemm_wide,
+conv_igemm; `by_kernel` splits it): algorithmic conv FLOPs / HIP-event time of those launches, measured by the
+library on the launch stream in a separate profiled step right after the timed region (event records around every
+launch would perturb the timed steps); `traffic` and the per-kernel MFMA-busy share are quoted from the committed
+rocprofv3 PMC passes of this same command (profiles/, tools/profile_bench.sh).  `cpu_baseline` is the CPU oracle (a
+port of the reference loop) timed on this box's host cores on a bounded sample, at N=1 only.
 """
 import argparse
 import json
