@@ -57,14 +57,11 @@ __device__ __forceinline__ void site_mult4(const ConvArgs& a, const PixelCtx& p,
 #pragma unroll
     for (int e = 0; e < 4; ++e) m[e] = 1.f;
     if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
-        const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)p.e_pix * a.Cout + c4
-                                                                  : (uint64_t)p.b * a.Cout + c4;
-        const uint64_t g = elem >> 3;          // this quad is the low or the high half of an 8-element group
-        const int e0 = (int)(elem & 4);
-        const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p.t, (uint32_t)a.site.site_id,
-                                         a.site.seed_lo, a.site.seed_hi);
+        const int row = a.site.kind == BMI_SITE_ELEMENTWISE ? p.e_pix : p.b;   // (one multiply: a select between two
+        const uint64_t elem = (uint64_t)row * a.Cout + c4;                      //  products went through scratch)
+        const uint32_t keep = site_keep8(a.site, elem & ~(uint64_t)7, (uint32_t)p.t) >> (elem & 4);   // low or high half
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = (!a.site.drop_all && philox_keep(rn, e0 + e, a.site.thresh)) ? a.site.scale : 0.f;
+        for (int e = 0; e < 4; ++e) m[e] = ((keep >> e) & 1u) ? a.site.scale : 0.f;
     } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
         const float4 k4 = *(const float4*)(p.mrow + c4);
         m[0] = k4.x; m[1] = k4.y; m[2] = k4.z; m[3] = k4.w;
@@ -220,13 +217,11 @@ __device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = 1.f;
     if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
-        const uint64_t elem = a.site.kind == BMI_SITE_ELEMENTWISE ? (uint64_t)px.e_pix * a.Cout + c8
-                                                                  : (uint64_t)px.b * a.Cout + c8;
-        const uint64_t g = elem >> 3;      // one Philox call masks the thread's 8 channels
-        const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)px.t,
-                                         (uint32_t)a.site.site_id, a.site.seed_lo, a.site.seed_hi);
+        const int row = a.site.kind == BMI_SITE_ELEMENTWISE ? px.e_pix : px.b;
+        const uint64_t elem = (uint64_t)row * a.Cout + c8;
+        const uint32_t keep = site_keep8(a.site, elem, (uint32_t)px.t);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (!a.site.drop_all && philox_keep(rn, e, a.site.thresh)) ? a.site.scale : 0.f;
+        for (int e = 0; e < 8; ++e) m[e] = ((keep >> e) & 1u) ? a.site.scale : 0.f;
     } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
         const f32x4_e k0 = *(const f32x4_e*)(px.mrow + c8), k1 = *(const f32x4_e*)(px.mrow + c8 + 4);
 #pragma unroll

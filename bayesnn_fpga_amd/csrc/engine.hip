@@ -80,7 +80,8 @@ SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
     s.seed_lo = (uint32_t)seed;
     s.seed_hi = (uint32_t)(seed >> 32);
     if (site->kind == BMI_SITE_ELEMENTWISE || site->kind == BMI_SITE_CHANNEL) {
-        s.thresh = bmi_drop_threshold(site->p, &s.drop_all);
+        s.log2_bits = bmi_site_log2_bits(site->p);
+        s.thresh = bmi_drop_threshold(site->p, s.log2_bits, &s.drop_all);
         s.scale = bmi_drop_scale(site->p);
     } else if (site->kind == BMI_SITE_MASKSEMBLE) {
         s.masks = site->masks;

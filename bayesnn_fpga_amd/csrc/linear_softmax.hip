@@ -56,10 +56,8 @@ __global__ __launch_bounds__(64) void linear_softmax_kernel(const float* __restr
                     // [B, C] tensor, element = b*C + c, eight elements per Philox call
                     const int tl = n / B;
                     const uint64_t elem = (uint64_t)(n - tl * B) * C + c;
-                    const uint64_t g8 = elem >> 3;
-                    const philox4 rn = philox4x32_10((uint32_t)g8, (uint32_t)(g8 >> 32), (uint32_t)(t0 + tl), (uint32_t)site.site_id,
-                                                     site.seed_lo, site.seed_hi);
-                    v = (!site.drop_all && philox_keep(rn, (int)(elem & 7), site.thresh)) ? v * site.scale : 0.f;
+                    const uint32_t keep = site_keep8(site, elem & ~(uint64_t)7, (uint32_t)(t0 + tl));
+                    v = ((keep >> (elem & 7)) & 1u) ? v * site.scale : 0.f;
                 }
                 acc[i][e] = v;
                 mx = fmaxf(mx, v);

@@ -17,11 +17,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void site_mask8(const SiteArgs& s, float v[8], uint64_t elem0, int t, const float* mrow) {
     // elem0: element index of v[0] (multiple of 8 within the site's index space)
     if (s.kind == BMI_SITE_ELEMENTWISE || s.kind == BMI_SITE_CHANNEL) {
-        const uint64_t g = elem0 >> 3;
-        const philox4 rn =
-            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t, (uint32_t)s.site_id, s.seed_lo, s.seed_hi);
+        const uint32_t keep = site_keep8(s, elem0, (uint32_t)t);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (!s.drop_all && philox_keep(rn, e, s.thresh)) ? v[e] * s.scale : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * s.scale : 0.f;
     } else if (s.kind == BMI_SITE_MASKSEMBLE) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= mrow[e];
@@ -92,11 +90,7 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(uint8_t* __restrict__ bi
             if (gi >= groups_per_sample * tc) break;
             const long tl = gi / groups_per_sample;
             const uint64_t g = (uint64_t)(gi - tl * groups_per_sample);
-            const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(t0 + tl), (uint32_t)s.site_id,
-                                             s.seed_lo, s.seed_hi);
-            uint32_t b = 0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) b |= (!s.drop_all && philox_keep(rn, e, s.thresh)) ? (1u << e) : 0u;
+            const uint32_t b = site_keep8(s, g << 3, (uint32_t)(t0 + tl));
             word |= b << (8 * q);
         }
         if (i * 4 + 3 < groups_per_sample * tc) *(uint32_t*)(bits + i * 4) = word;
@@ -301,23 +295,22 @@ int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, 
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void philox_mask_kernel(uint8_t* keep, long n, uint32_t k0, uint32_t k1, int site, int t, uint32_t thresh,
-                                   int drop_all) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void philox_mask_kernel(uint8_t* keep, long n, SiteArgs s, int t) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one 8-element group per thread
     if (g * 8 >= n) return;
-    const philox4 rn = philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)t, (uint32_t)site, k0, k1);
+    const uint32_t bits = site_keep8(s, (uint64_t)g << 3, (uint32_t)t);
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-        if (g * 8 + e < n) keep[g * 8 + e] = (!drop_all && philox_keep(rn, e, thresh)) ? 1 : 0;
+        if (g * 8 + e < n) keep[g * 8 + e] = (bits >> e) & 1u;
 }
 
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s) {
     if (n <= 0) return BMI_ERR_INVALID;
-    int drop_all = 0;
-    const uint32_t thresh = bmi_drop_threshold(p, &drop_all);
+    bmi_site bs;
+    bs.kind = BMI_SITE_ELEMENTWISE; bs.site_id = site; bs.p = p; bs.num_masks = 0; bs.masks = nullptr;
+    const SiteArgs sa = resolve_site(&bs, seed, 0);
     const long groups = (n + 7) / 8;
-    hipLaunchKernelGGL(philox_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, keep, (long)n,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), site, t, thresh, drop_all);
+    hipLaunchKernelGGL(philox_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, keep, (long)n, sa, t);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

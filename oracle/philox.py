@@ -6,12 +6,17 @@ the Random123 known-answer vectors in ``tests/test_philox.py``.
 
 Mask convention shared by oracle and HIP kernels (bayesnn_fpga_amd/csrc/philox.h):
 
+  bits     k = the fewest of {2, 4, 8, 16} bits per element with fl32(p) * 2**k an integer, else 16
+             (p = 0.25 or 0.5 -> 2, 0.125 / 0.375 -> 4, 0.1 -> 16: quantised to 1/65536)
   key      = (seed & 0xffffffff, seed >> 32)
-  counter  = (g & 0xffffffff, g >> 32, t, site)          g = element_index // 8
-  element  e uses the 16-bit half (e & 1) of output word r[(e % 8) // 2]   (even e: low half)
-  keep(e)  = half >= thresh,   thresh = min(floor(fl32(p) * 2**16 + 0.5), 2**16)
+  counter  = (g & 0xffffffff, g >> 32, t, site)          g = element_index // (128 // k)
+  element  e uses field f = e % (128 // k) of the call's 128 output bits: bits [f*k, (f+1)*k) of r[0] | r[1]<<32 | ...
+             (k = 16: the 16-bit half (e & 1) of word r[(e % 8) // 2], low half first)
+  keep(e)  = field >= thresh,   thresh = min(floor(fl32(p) * 2**k + 0.5), 2**k)      P(drop) = thresh / 2**k
   out      = x * keep * fl32(1 / fl32(1 - p))            (MCDropout: F.dropout, always on,
                                                           SA/models/resnet18/resnet18.py:209-210)
+The field width follows p because the Philox call is what the GPU pays for (v_mad_u64_u32 issues at a quarter rate):
+at p = 0.25 one call masks 64 elements instead of 8.
 
 ``element_index`` is the NHWC-linear index inside ONE Monte-Carlo sample's activation of
 logical shape [B, C, H, W]:  ((b*H + h)*W + w)*C + c  ([B, C] tensors have H = W = 1), so
@@ -49,9 +54,19 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return (c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32))
 
 
-def drop_threshold(p):
-    """16-bit threshold: keep iff half-word >= thresh.  P(drop) = thresh / 2**16."""
-    return min(int(np.floor(float(np.float32(p)) * 65536.0 + 0.5)), 1 << 16)
+def site_bits(p):
+    """Bits drawn per element for drop probability p: 2, 4, 8 when fl32(p) * 2**k is an integer, else 16."""
+    pf = float(np.float32(p))
+    for k in (2, 4, 8):
+        if pf * (1 << k) == np.floor(pf * (1 << k)):
+            return k
+    return 16
+
+
+def drop_threshold(p, k=None):
+    """k-bit threshold (k = site_bits(p) by default): keep iff field >= thresh.  P(drop) = thresh / 2**k."""
+    k = site_bits(p) if k is None else k
+    return min(int(np.floor(float(np.float32(p)) * float(1 << k) + 0.5)), 1 << k)
 
 
 def drop_scale(p):
@@ -64,14 +79,19 @@ def drop_scale(p):
 
 def keep_bits(n_elems, seed, site, t, p):
     """Boolean keep-mask for elements 0..n_elems-1 of one (seed, site, t) stream."""
-    n_groups = (n_elems + 7) // 8
+    k = site_bits(p)
+    per_call = 128 // k
+    n_groups = (n_elems + per_call - 1) // per_call
     g = np.arange(n_groups, dtype=np.uint64)
     r = philox4x32_10(g & _MASK32, g >> np.uint64(32), np.uint64(t), np.uint64(site),
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     words = np.stack(r, axis=1).astype(np.uint32)                        # [groups, 4]
-    halves = np.stack([words & np.uint32(0xFFFF), words >> np.uint32(16)], axis=2).reshape(-1)[:n_elems]
-    thr = drop_threshold(p)
-    return halves >= thr if thr < (1 << 16) else np.zeros(n_elems, dtype=bool)
+    f = np.arange(per_call, dtype=np.uint32) * np.uint32(k)              # bit position of field f inside the call
+    fields = (words[:, f >> np.uint32(5)] >> (f & np.uint32(31))) & np.uint32((1 << k) - 1)     # [groups, per_call]
+    thr = drop_threshold(p, k)
+    if thr >= (1 << k):
+        return np.zeros(n_elems, dtype=bool)
+    return (fields.reshape(-1)[:n_elems] >= thr)
 
 
 def elementwise_mask(shape, seed, site, t, p):

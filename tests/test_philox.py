@@ -1,5 +1,6 @@
 """Philox4x32-10 known-answer tests (Random123 kat_vectors) and the mask convention."""
 import numpy as np
+import pytest
 
 from oracle import philox
 from tests.helpers import load_golden
@@ -30,27 +31,33 @@ def test_philox_vectorised_matches_scalar():
 
 
 def test_threshold_and_scale():
+    assert [philox.site_bits(p) for p in (0.0, 0.25, 0.5, 0.75, 1.0, 0.125, 0.375, 0.0625, 1 / 256, 0.1, 0.2, 0.3)] == \
+        [2, 2, 2, 2, 2, 4, 4, 4, 8, 16, 16, 16]
     assert philox.drop_threshold(0.0) == 0
-    assert philox.drop_threshold(0.25) == 1 << 14
-    assert philox.drop_threshold(0.5) == 1 << 15
-    assert philox.drop_threshold(1.0) == 1 << 16
-    assert philox.drop_threshold(0.2) == 13107                      # quantised to 1/65536
+    assert philox.drop_threshold(0.25) == 1                         # 2 bits per element: drop iff field == 0
+    assert philox.drop_threshold(0.5) == 2
+    assert philox.drop_threshold(1.0) == 4                          # == 2**k: everything dropped
+    assert philox.drop_threshold(0.375) == 6 and philox.drop_threshold(0.125) == 2
+    assert philox.drop_threshold(0.2) == 13107                      # 16 bits: quantised to 1/65536
     assert philox.drop_scale(0.25) == np.float32(1.0) / np.float32(0.75)
     assert philox.drop_scale(1.0) == 0.0
 
 
-def test_mask_layout_rule():
-    """element index is NHWC-linear: ((b*H+h)*W+w)*C+c, eight consecutive channels per call,
-    16 bits per element (low half of the word first)."""
-    seed, site, t, p = 42, 3, 5, 0.25
-    B, C, H, W = 2, 8, 3, 2
+@pytest.mark.parametrize("p", [0.25, 0.375, 1 / 256, 0.2])
+def test_mask_layout_rule(p):
+    """element index is NHWC-linear: ((b*H+h)*W+w)*C+c; 128 // k consecutive elements per call, k bits each
+    (k = 2, 4, 8, 16 by p), fields in little-endian bit order over r[0..3]."""
+    seed, site, t = 42, 3, 5
+    B, C, H, W = 2, 24, 3, 5
+    k = philox.site_bits(p)
     m = philox.elementwise_mask((B, C, H, W), seed, site, t, p)
     thr = philox.drop_threshold(p)
-    for (b, c, h, w) in [(0, 0, 0, 0), (1, 5, 2, 1), (0, 7, 1, 0), (1, 3, 0, 1)]:
+    for (b, c, h, w) in [(0, 0, 0, 0), (1, 5, 2, 1), (0, 23, 1, 0), (1, 3, 0, 4), (1, 17, 2, 4)]:
         e = ((b * H + h) * W + w) * C + c
-        r = philox.philox4x32_10(e // 8, 0, t, site, seed, 0)
-        half = (int(r[(e % 8) // 2]) >> (16 * (e & 1))) & 0xFFFF
-        assert m[b, c, h, w] == float(half >= thr)
+        r = philox.philox4x32_10(e // (128 // k), 0, t, site, seed, 0)
+        bits128 = sum(int(r[i]) << (32 * i) for i in range(4))
+        field = (bits128 >> ((e % (128 // k)) * k)) & ((1 << k) - 1)
+        assert m[b, c, h, w] == float(field >= thr)
 
 
 def test_mask_statistics():
