@@ -290,8 +290,31 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
         if (rr + 1 < NR) { BMI_EPI_FETCH(rr + 1); }
         lds_barrier();
         // phase 2: 128 pixels x 16 groups of 8 channels = 2048 items, 8 per thread
+        // Shared Philox for elementwise sites at 2 bits per element (p = 0.25, 0.5, 0.75): one call masks 64 channels
+        // of a pixel, i.e. the items of 8 neighbouring lanes.  A 16-lane group needs 8 pixels x 2 halves = 16 calls in
+        // this round: lane k computes the one of pixel (k & 7), half (k >> 3), and every item fetches its call's words
+        // from lane (k & 8) | it with ds_bpermute: ONE Philox per thread and round instead of eight.
+#ifndef BMI_EPI_SHARE
+#define BMI_EPI_SHARE 1
+#endif
+        const bool share = BMI_EPI_SHARE && a.site.kind == BMI_SITE_ELEMENTWISE && a.site.log2_bits == 1 && !a.site.drop_all;
+        philox4 mine = {{0u, 0u, 0u, 0u}};
+        if (share) {
+            const int pl_ = (tid >> 4) + 16 * (k & 7);
+            int n_, rem_;
+            pixmap((pl_ >> 6) * (32 * TJ) + rr * 64 + (pl_ & 63), n_, rem_);
+            const int tl_ = n_ / a.B;
+            const uint64_t e0_ = (uint64_t)((n_ - tl_ * a.B) * (a.Ho * a.Wo) + rem_) * a.Cout + ch0 + 64 * (k >> 3);
+            mine = philox_site_call(a.site, e0_, (uint32_t)(a.t0 + tl_));
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+            philox4 theirs = mine;
+            if (share) {   // wave-uniform: every lane takes part in the exchange, valid pixel or not
+                const int src = (lane & 48) | (k & 8) | it;
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) theirs.w[wd] = (uint32_t)__shfl((int)mine.w[wd], src, 64);
+            }
             if (pn[rr][it] < 0) continue;
             const int pl = (tid >> 4) + 16 * it;
             const int s = pl & 31;
@@ -303,7 +326,13 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] * sc0[e] + bi0[e]; v[4 + e] = hi[e] * sc1[e] + bi1[e]; }
             const int c8 = ch0 + 8 * k;
             float m[8];
-            site_mult8(a, px, c8, m);
+            if (share) {
+                const uint32_t keep = philox_keep8(theirs, (uint32_t)((uint64_t)px.e_pix * a.Cout + c8), 1, a.site.thresh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = ((keep >> e) & 1u) ? a.site.scale : 0.f;
+            } else {
+                site_mult8(a, px, c8, m);
+            }
             if (a.site_inner) {   // mask between the conv and its BatchNorm shift (converter/pytorch rule)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];

@@ -379,3 +379,28 @@ def test_conv_kernels_are_not_pathologically_slow(name, kwargs):
     torch.cuda.synchronize()
     tflops = 3 * 2.0 * n * ho * ho * cout * k * k * cin / (e0.elapsed_time(e1) * 1e-3) / 1e12
     assert tflops > 150, f"{name} {kwargs}: {tflops:.0f} TFLOP/s"
+
+
+@pytest.mark.parametrize("p,in_stoch", [(0.25, False), (0.25, True), (0.5, False), (0.375, False), (1 / 256, True), (0.2, False)])
+def test_mask_apply_lane_shared_philox(p, in_stoch):
+    """Sites with 2 / 4 / 8 bits per element run the kernel in which a wave's lanes share Philox calls (one call masks
+    64 / 32 / 16 elements); p = 0.2 (16 bits) and ragged sizes take the per-item kernel.  Bit-exact against the oracle
+    either way, for an expanding launch (input [B]) and a same-size one (input [tc*B])."""
+    lib = _lib.lib()
+    B, tc, H, Cc, t0, seed = 4, 3, 8, 64, 5, (9 << 32) + 1            # 4*64*64 = 16384 elements per sample
+    g = _gen(6)
+    n_in = B * tc if in_stoch else B
+    x = torch.randn(n_in, H, H, Cc, generator=g).to(torch.float16).to(DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=3, p=p)
+    keep = []
+    s = gh.site_struct(site, keep)
+    out = torch.full((B * tc, H, H, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    _lib.check(lib.bmi_mask_apply(gh.ptr(x), gh.ptr(out), B * tc, n_in, H * H, Cc, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_mask_apply")
+    torch.cuda.synchronize()
+    mult = gh.folded_site_mask(site, B, Cc, H, H, tc, t0, seed)
+    xin = x.float().cpu().permute(0, 3, 1, 2)
+    if not in_stoch:
+        xin = xin.repeat(tc, 1, 1, 1)
+    ref = (xin * mult).to(torch.float16).float()
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)
+    assert 0 < float((mult == 0).float().mean()) < 1
