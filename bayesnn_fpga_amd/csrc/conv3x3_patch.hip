@@ -84,6 +84,9 @@ struct PatchGeom {
 #ifndef BMI_PATCH_SWPIPE
 #define BMI_PATCH_SWPIPE 0
 #endif
+#ifndef BMI_PATCH_WSPREAD   // issue the next weight tile's 4 DMA pieces one per k-substep, behind its MFMAs (not as a burst)
+#define BMI_PATCH_WSPREAD 0
+#endif
 
 template <int S, int TH, int TW, int IMGS, int TJ, int NB, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 __syncthreads();   // patch landed, W[step&1] written; every wave is done with W[(step+1)&1]
                 STAMP_ADD(5, tw0);
                 if (step == 0) { STAMP(1); }
-                if (step + 1 < nK) LOAD_W(w_koff(step + 1), buf ^ 1);
+                if (!(BMI_PATCH_WSPREAD && WDMA) && step + 1 < nK) LOAD_W(w_koff(step + 1), buf ^ 1);
             }
             const bool more = step + 1 < nK;
             const int ky = tap / 3, kx = tap - 3 * ky;
@@ -291,6 +294,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if constexpr (BMI_PATCH_WSPREAD && WDMA && NB == 2) {
+                    if (more)
+                        GLDS16(wsrc + (size_t)(32 * kk) * Ktot + w_koff(step + 1), wbuf + (buf ^ 1) * G::WTILE + (kk * 256 + wave * 64) * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #endif
             if (more) STORE_W(buf ^ 1);
