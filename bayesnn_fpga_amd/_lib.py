@@ -92,6 +92,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP library has not been built "
                 "(run `python -m bayesnn_fpga_amd._build`).  bayesnn_fpga_amd has no CPU fallback.")
+        # torch first: PyTorch-ROCm ships its own libamdhip64, and the process must end up with ONE HIP runtime.  Loaded
+        # before torch, this library binds the system ROCm runtime instead; the streams and device pointers torch
+        # hands over then belong to a different runtime and every launch fails (BMI_ERR_HIP).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)

@@ -168,3 +168,12 @@ def test_bmi_create_rejects_bad_descriptors():
     assert lib.bmi_plan(cg.handle, 0, 4, C.byref(ws)) == -22
     # forward without a workspace / with too small a workspace fails before any launch
     assert lib.bmi_forward_mcd(cg.handle, None, 1, 0, 1, 0, 0, None, None, None, None, 0, None) == -22
+
+
+def test_one_hip_runtime_in_the_process():
+    """PyTorch-ROCm bundles its own libamdhip64; loaded before torch, our library would bind the system ROCm runtime
+    and every launch on a torch stream would fail.  _lib.lib() imports torch first: exactly one runtime is mapped."""
+    _lib.lib()
+    with open("/proc/self/maps") as f:
+        paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    assert len(paths) == 1, paths
