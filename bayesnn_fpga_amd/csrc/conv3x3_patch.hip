@@ -84,6 +84,9 @@ struct PatchGeom {
 #ifndef BMI_PATCH_SWPIPE
 #define BMI_PATCH_SWPIPE 0
 #endif
+#ifndef BMI_PATCH_SETPRIO   // raise the wave's priority while it issues a k-substep's MFMAs (the other workgroup's wave loads meanwhile)
+#define BMI_PATCH_SETPRIO 0
+#endif
 #ifndef BMI_PATCH_WSPREAD   // issue the next weight tile's 4 DMA pieces one per k-substep, behind its MFMAs (not as a burst)
 #define BMI_PATCH_WSPREAD 0
 #endif
@@ -289,11 +292,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wt + a_off + i * 32 * 128 + ((ch ^ a_sw) << 4));
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(patch + boff[j] + ((ch ^ bsw[j]) << 4));
+                if (BMI_PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if (BMI_PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 if constexpr (BMI_PATCH_WSPREAD && WDMA && NB == 2) {
                     if (more)
                         GLDS16(wsrc + (size_t)(32 * kk) * Ktot + w_koff(step + 1), wbuf + (buf ^ 1) * G::WTILE + (kk * 256 + wave * 64) * 16);

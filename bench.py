@@ -224,6 +224,7 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
+                       "workspace_gb": round(eng.workspace_bytes / 2**30, 2),
                        "sharding": f"T over {world} rank(s), one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
             "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),
