@@ -87,6 +87,9 @@ struct PatchGeom {
 #ifndef BMI_PATCH_SETPRIO   // raise the wave's priority while it issues a k-substep's MFMAs (the other workgroup's wave loads meanwhile)
 #define BMI_PATCH_SETPRIO 0
 #endif
+#ifndef BMI_PATCH_RDEARLY   // fragment reads of k-substep kk+1 right behind the FIRST MFMA of kk (hipcc puts them behind the last)
+#define BMI_PATCH_RDEARLY 0
+#endif
 #ifndef BMI_PATCH_WSPREAD   // issue the next weight tile's 4 DMA pieces one per k-substep, behind its MFMAs (not as a burst)
 #define BMI_PATCH_WSPREAD 0
 #endif
@@ -283,6 +286,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * TJ, 0);
+#elif BMI_PATCH_RDEARLY
+            {
+                half8 fa[2][TI], fb[2][TJ];
+#define RDF(KK, SET)                                                                                              \
+    {                                                                                                             \
+        const int ch_ = 2 * (KK) + hh;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < TI; ++i) fa[SET][i] = *(const half8*)(wt + a_off + i * 32 * 128 + ((ch_ ^ a_sw) << 4)); \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j) fb[SET][j] = *(const half8*)(patch + boff[j] + ((ch_ ^ bsw[j]) << 4));      \
+    }
+                RDF(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int cur = kk & 1;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+                    if (kk < 3) RDF(kk + 1, cur ^ 1);
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+                            if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+                }
+#undef RDF
+                // pin: per substep 1 MFMA, then the next substep's reads, then the remaining MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ - 1, 0);
+                }
+            }
 #else
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from bayesnn_fpga_amd import _lib
 sys.argv += [] 
 name = sys.argv[1] if len(sys.argv) > 1 else "S2"
+NORES = "--nores" in sys.argv          # plain epilogue (BN + ReLU only) instead of the general one
 SH = {"S2": (128, 128, 16), "S3": (256, 256, 8), "S4": (512, 512, 4)}
 cin, cout, H = SH[name]
 lib = _lib.lib(); n = 1000; dev = "cuda:0"
@@ -17,7 +18,7 @@ wp = None
 if os.environ.get('BMI_CONV_IMPL','') == '':
     wpk = torch.empty_like(w); _lib.check(lib.bmi_pack_conv3x3_weights(w.data_ptr(), wpk.data_ptr(), cout, cin, st), 'pack'); wp = wpk.data_ptr()
 def run():
-    _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), wp, sc.data_ptr(), bi.data_ptr(), res.data_ptr(), out.data_ptr(), n, n, n, H, H, cin, cout, 3, 1, 1, 1, None, 250, 0, 42, 0, st), "conv")
+    _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), wp, sc.data_ptr(), bi.data_ptr(), None if NORES else res.data_ptr(), out.data_ptr(), n, n, n, H, H, cin, cout, 3, 1, 1, 1, None, 250, 0, 42, 0, st), "conv")
 for _ in range(5): run()
 torch.cuda.synchronize()
 l = C.CDLL(_lib.LIB_PATH)
