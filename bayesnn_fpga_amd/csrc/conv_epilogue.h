@@ -127,7 +127,8 @@ typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
 
 #define BMI_EPILOGUE_LDS_BYTES 65536
 
-__host__ __device__ inline bool conv_epilogue_is_plain(const ConvArgs& a) { return !a.res && a.site.kind == BMI_SITE_NONE; }   // (an inner site has kind != NONE)
+// launch-uniform: BN + ReLU only (an inner site also has kind != NONE)
+__host__ __device__ inline bool conv_epilogue_is_plain(const ConvArgs& a) { return !a.res && a.site.kind == BMI_SITE_NONE; }
 
 // LDS-only barrier: the epilogue's global stores / outstanding residual loads must NOT be drained
 // at the round boundaries (a __syncthreads() would add s_waitcnt vmcnt(0)).

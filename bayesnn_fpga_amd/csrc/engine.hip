@@ -683,9 +683,10 @@ int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* 
     return launch_mask_bits((uint8_t*)bits, n, hw, c, resolve_site(site, seed, 0), batch, t0, (hipStream_t)stream);
 }
 
-int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, const void* weight, const void* weight_packed, const float* scale, const float* bias, const void* res,
-                       void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
-                       int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
+int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, const void* weight,
+                       const void* weight_packed, const float* scale, const float* bias, const void* res, void* out,
+                       int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                       int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
     if (!in || !weight || !out || ksize < 1 || stride < 1 || pad < 0) return BMI_ERR_INVALID;
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;

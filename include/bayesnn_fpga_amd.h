@@ -194,9 +194,10 @@ int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* 
 
 /* in_keep_bits (or NULL): input-side MC-dropout — image n reads in[n % in_mod] with the dropped elements of
  * folded image n zeroed while staging; out_mul multiplies the BN scale (pass 1/(1-p) then, else 1). */
-int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, const void* weight, const void* weight_packed, const float* scale, const float* bias, const void* res,
-                       void* out, int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin,
-                       int32_t cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
+int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, const void* weight,
+                       const void* weight_packed, const float* scale, const float* bias, const void* res, void* out,
+                       int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                       int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
 
 /* out = relu?( conv3x3_s1_p1(in; weight) + conv1x1_stride2(in2; weight2) + bias ), the fused BasicBlock tail
