@@ -102,6 +102,13 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int ch = ch0 + 64 * i + rowt;
         wsrc[i] = (ch < split ? a.wgt + (size_t)ch * Ktot : a.wgt_b + (size_t)(ch - split) * Ktot) + srcchunk;
+    }
+    // the first weight tile is on its way while the pixel rows are decoded (divisions) and the accumulators cleared
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(wsrc[i], smem + (i * 512 + wave * 64) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
         const int m = pix0 + 64 * i + rowt;
         const bool vm = m < a.M;
         const int mm = vm ? m : 0;
@@ -127,6 +134,12 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         GLDS16(s_, (ST) + WBC * 128 + ((I) * 512 + wave * 64) * 16);                                   \
     }
 
+    {   // first activation tile (the weight tile was issued above)
+        char* st0 = smem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ISSUE_X(i, 0, 0, 0, st0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -141,14 +154,6 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 
     const int nK = a.ksize * a.ksize * (a.Cin / 64);
     int ky = 0, kx = 0, c0 = 0;
-    {
-        char* st0 = smem;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ISSUE_W(i, 0, st0);
-            ISSUE_X(i, 0, 0, 0, st0);
-        }
-    }
 #if BMI_WIDE_PINGPONG
     // ---- ping-pong main loop ------------------------------------------------------------------------------------
     // A K-step is four phases (one 16-deep k-substep each); a phase is a LOAD part (6 ds_read_b128 of the substep's
