@@ -308,6 +308,226 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of the kernel above for plain launches (BN + ReLU epilogue: every stride-2 conv of the path): one
+// workgroup per CU walks over tiles blockIdx, blockIdx + gridDim, ...  What it buys: the first K-step of a tile is an
+// HBM round trip (5.6k of a workgroup's 45-130k cycles, stamps) and a CU sits idle between the end of one workgroup and
+// the start of the next (6.5 % of a launch).  Here the next tile's first K-step is issued into stage buffer 0 as soon
+// as the main loop has released the buffers, and lands while the current tile's epilogue runs in stage buffer 1
+// (fp16, two rounds of 128 pixels per channel half).  BN scale / bias live in a small LDS table: an ordinary global
+// load in the epilogue would make hipcc drain the LDS-DMA (vmcnt(0)) at its first use.
+#define WBN_MAX 1024
+
+__global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArgs a, int n_tiles) {
+    constexpr int TI = 2, TJ = 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE + 2 * WBN_MAX * 4];
+    float* const bn_scale = (float*)(smem + 2 * WSTAGE);
+    float* const bn_bias = bn_scale + WBN_MAX;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
+    const int n_ctiles = a.Cout / WBC;
+    const int n_ptiles = (a.M + WBP - 1) / WBP;
+    const int HoWo = a.Ho * a.Wo;
+    const int Ktot = a.ksize * a.ksize * a.Cin;
+    const int split = a.wgt_b ? a.split : a.Cout;
+
+    for (int c = tid; c < a.Cout; c += 512) {
+        const bool second = c >= split;
+        const float* sp = second ? a.scale_b : a.scale;
+        const float* bp = second ? a.bias_b : a.bias;
+        const int cc = second ? c - split : c;
+        bn_scale[c] = (sp ? sp[cc] : 1.f) * a.out_mul;
+        bn_bias[c] = bp ? bp[cc] : 0.f;
+    }
+    __syncthreads();   // (no LDS-DMA in flight yet: the plain barrier and its waits are fine here)
+
+    const int rowt = tid >> 3;
+    const int srcchunk = ((tid & 7) ^ ((rowt >> 1) & 7)) * 8;
+    const int a_off = (g * 128 + wc * 64 + r) * 128;
+    const int b_off = WBC * 128 + (wp * 128 + r) * 128;
+    const int sw_r = (r >> 1) & 7;
+    const int nK = a.ksize * a.ksize * (a.Cin / 64);
+    const int dma_phase = g == 0 ? 1 : 0;
+    const _Float16* wsrc[4];
+    const _Float16* xsrc[4];
+    int iy0[4], ix0[4];
+    int ch0 = 0, pix0 = 0;
+
+#define ISSUE_W(I, KOFF, ST)  GLDS16(wsrc[I] + (KOFF), (ST) + ((I) * 512 + wave * 64) * 16)
+#define ISSUE_X(I, KY, KX, C0, ST)                                                                     \
+    {                                                                                                  \
+        const int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                            \
+        const bool ok_ = (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;               \
+        const _Float16* s_ = ok_ ? xsrc[I] + (size_t)(iy_ * a.W + ix_) * a.Cin + (C0)                  \
+                                 : (const _Float16*)g_zero_page_w;                                     \
+        GLDS16(s_, (ST) + WBC * 128 + ((I) * 512 + wave * 64) * 16);                                   \
+    }
+    // tile VB: DMA sources of this thread's 4 weight rows and 4 pixel rows, and its first K-step -> stage buffer 0
+#define SETUP_TILE(VB)                                                                                 \
+    {                                                                                                  \
+        int ptile_, ctile_;                                                                            \
+        xcd_tile_map((VB), n_ptiles, n_ctiles, ptile_, ctile_);                                        \
+        ch0 = ctile_ * WBC;                                                                            \
+        pix0 = ptile_ * WBP;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            const int ch = ch0 + 64 * i + rowt;                                                        \
+            wsrc[i] = (ch < split ? a.wgt + (size_t)ch * Ktot : a.wgt_b + (size_t)(ch - split) * Ktot) + srcchunk; \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) GLDS16(wsrc[i], smem + (i * 512 + wave * 64) * 16);           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            const int m = pix0 + 64 * i + rowt;                                                        \
+            const bool vm = m < a.M;                                                                   \
+            const int mm = vm ? m : 0;                                                                 \
+            const int n = mm / HoWo;                                                                   \
+            const int rem = mm - n * HoWo;                                                             \
+            const int oy = rem / a.Wo;                                                                 \
+            const int ox = rem - oy * a.Wo;                                                            \
+            iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;                                            \
+            ix0[i] = ox * a.stride - a.pad;                                                            \
+            xsrc[i] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + srcchunk;                    \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) ISSUE_X(i, 0, 0, 0, smem);                       \
+    }
+#define RAW_BARRIER()                                  \
+    {                                                  \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_sched_barrier(0);             \
+    }
+
+    int vb = blockIdx.x;
+    SETUP_TILE(vb);
+    while (vb < n_tiles) {
+        const int cur_ch0 = ch0, cur_pix0 = pix0;
+        f32x16 acc[TI][TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        // ---- ping-pong main loop (see conv_igemm_wide_kernel for the interval / hazard table) ----
+        int ky = 0, kx = 0, c0 = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first K-step (and the previous tile's stores)
+        RAW_BARRIER();
+        if (g == 1) RAW_BARRIER();
+        for (int ks = 0; ks < nK; ++ks) {
+            const int buf = ks & 1;
+            const bool more = ks + 1 < nK;
+            if (more) {
+                c0 += 64;
+                if (c0 == a.Cin) {
+                    c0 = 0;
+                    if (++kx == a.ksize) { kx = 0; ++ky; }
+                }
+            }
+            const int koff = (ky * a.ksize + kx) * a.Cin + c0;
+            char* nst = smem + (buf ^ 1) * WSTAGE;
+            const char* st = smem + buf * WSTAGE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int coff = ((2 * kk + hh) ^ sw_r) << 4;
+                half8 af[TI], bf[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(st + a_off + i * 32 * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(st + b_off + j * 32 * 128 + coff);
+                if (more && kk == dma_phase) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ISSUE_W(i, koff, nst);
+                }
+                if (more && kk == dma_phase + 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ISSUE_X(i, ky, kx, c0, nst);
+                }
+                if (kk == 3 && g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (kk == 3 && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+            }
+        }
+        if (g == 0) RAW_BARRIER();      // both groups aligned: every wave is done with both stage buffers
+
+        // ---- next tile's first K-step -> stage buffer 0; it lands during the epilogue below ----
+        const int nvb = vb + (int)gridDim.x;
+        if (nvb < n_tiles) SETUP_TILE(nvb);
+
+        // ---- epilogue of the current tile in stage buffer 1: 32 KB per channel half, two rounds of 128 pixels ----
+        {
+            char* const E = smem + WSTAGE + g * 32768;
+            const int tl = tid & 255;
+            const int chl = cur_ch0 + 128 * g;              // launch-wide channel of this half's channel 0 (BN table index)
+            _Float16* outp = a.out;
+            int oc = a.Cout, chg = chl;
+            if (a.wgt_b) {
+                if (chl >= split) { outp = a.out_b; oc = a.Cout - split; chg = chl - split; }
+                else oc = split;
+            }
+            const int hsw = hh ^ ((r >> 4) & 1);
+            const int k = tl & 15;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr) lds_barrier();                      // round 0's reads are done
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = q >> 2, g4 = q & 3;
+                    const int c4 = chl + wc * 64 + 32 * i + 8 * g4 + 4 * hh;
+                    const f32x4_e sc = *(const f32x4_e*)(bn_scale + c4), bi = *(const f32x4_e*)(bn_bias + c4);
+                    const int cq = wc * 8 + 4 * i + g4;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int p = wp * 64 + jj * 32 + r;                     // pixel inside the round
+                        half4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][2 * rr + jj][4 * g4 + e] * sc[e] + bi[e];
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            o[e] = (_Float16)v;
+                        }
+                        *(half4*)(E + p * 256 + ((cq ^ (r & 15)) << 4) + hsw * 8) = o;
+                    }
+                }
+                lds_barrier();
+                half8_e o8[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int pl = (tl >> 4) + 16 * it;
+                    o8[it] = *(const half8_e*)(E + pl * 256 + ((k ^ (pl & 15)) << 4));
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int pl = (tl >> 4) + 16 * it;
+                    const int m = cur_pix0 + (pl >> 6) * (32 * TJ) + rr * 64 + (pl & 63);
+                    if (m >= a.M) continue;
+                    half8_e v = o8[it];
+                    if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+                    *(half8_e*)(outp + (size_t)m * oc + chg + 8 * k) = v;
+                }
+            }
+        }
+        vb = nvb;
+    }
+#undef ISSUE_W
+#undef ISSUE_X
+#undef SETUP_TILE
+#undef RAW_BARRIER
+}
+
 // Shapes the wide kernel takes.  `cout` is the launch's total channel count (both convs of a pair).
 bool conv_takes_wide_kernel(int cin, int cout) {
     static const int on = [] { const char* v = std::getenv("BMI_IGEMM_WIDE"); return v ? std::atoi(v) : 1; }();
@@ -323,6 +543,17 @@ int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s) {
     }
     const long blocks = (((long)a.M + WBP - 1) / WBP) * (a.Cout / WBC);
     if (blocks > 0x7fffffffL) return BMI_ERR_INVALID;
+    static const int persist = [] { const char* v = std::getenv("BMI_WIDE_PERSIST"); return v ? std::atoi(v) : 1; }();
+    static const int n_cu = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+        return cu;
+    }();
+    if (persist && BMI_WIDE_PINGPONG && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks > 2L * n_cu) {
+        hipLaunchKernelGGL(conv_igemm_wide_persist_kernel, dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
+        BMI_CHECK_LAUNCH();
+        return BMI_OK;
+    }
     if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL(conv_igemm_wide_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(conv_igemm_wide_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, s, a);
     BMI_CHECK_LAUNCH();

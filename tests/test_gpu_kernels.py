@@ -404,3 +404,40 @@ def test_mask_apply_lane_shared_philox(p, in_stoch):
     ref = (xin * mult).to(torch.float16).float()
     assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)
     assert 0 < float((mult == 0).float().mean()) < 1
+
+
+@pytest.mark.parametrize("name,n", [("D3", 2111), ("D4", 4500), ("P4", 9001)])
+def test_conv_wide_persistent_kernel(name, n):
+    """More than 2 tiles per CU: the plain wide-tile launches run the persistent kernel (one workgroup per CU walks over
+    the tiles, the next tile's first K-step lands during the epilogue).  Ragged last tile, bit-exact repeatability."""
+    cin, cout, H, k, s, p = SHAPES[name]
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, n, 17, False)
+    ho = (H + 2 * p - k) // s + 1
+    tiles = -(-n * ho * ho // 256) * (cout // 256)
+    assert tiles > 512 and (n * ho * ho) % 256 != 0
+    out = gh.run_conv(x, w, scale, bias, None, True, s, p, n, n, 1)
+    ref = gh.conv_ref(x, w, scale, bias, None, True, s, p, n, n, 1)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=3e-3)
+    assert torch.equal(out, gh.run_conv(x, w, scale, bias, None, True, s, p, n, n, 1))
+
+
+def test_conv_pair_persistent_kernel():
+    lib = _lib.lib()
+    cin, ca, cb, H, k, s, p, n = 64, 128, 128, 32, 3, 2, 1, 600          # 600 tiles of 256 pixels
+    g = _gen(8)
+    x = torch.randn(n, H, H, cin, generator=g).to(torch.float16).to(DEV)
+    ws, scs, bis, outs = [], [], [], []
+    for c in (ca, cb):
+        ws.append((torch.randn(c, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(torch.float16).to(DEV))
+        scs.append((0.5 + torch.rand(c, generator=g)).to(DEV))
+        bis.append((0.2 * torch.randn(c, generator=g)).to(DEV))
+        outs.append(torch.full((n, 16, 16, c), float("nan"), dtype=torch.float16, device=DEV))
+    rc = lib.bmi_conv_pair_fwd(gh.ptr(x), gh.ptr(ws[0]), gh.ptr(scs[0]), gh.ptr(bis[0]), gh.ptr(outs[0]), gh.ptr(ws[1]), gh.ptr(scs[1]),
+                               gh.ptr(bis[1]), gh.ptr(outs[1]), n, n, H, H, cin, ca, cb, k, s, p, 1, gh.stream())
+    _lib.check(rc, "bmi_conv_pair_fwd")
+    torch.cuda.synchronize()
+    for i in range(2):
+        ref = gh.conv_ref(x, ws[i], scs[i], bis[i], None, True, s, p, n, n, 1)
+        torch.testing.assert_close(outs[i].float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3)
