@@ -102,8 +102,9 @@ def pmc_sq(workload, family):
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     if not os.path.exists(path):
         return {}
-    ks = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(family) and "sq" in v
-          and v["sq"]["mfma_busy_share"] > 0.05]          # (a 5-launch instantiation reads 0.04: counter glitch, skipped)
+    stem = family[:-len("_kernel")] if family.endswith("_kernel") else family     # conv_igemm_wide also covers ..._persist_kernel
+    ks = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(stem) and "sq" in v
+          and (stem != "conv_igemm" or k.startswith("conv_igemm_kernel")) and v["sq"]["mfma_busy_share"] > 0.05]
     n = sum(v["launches"] for v in ks)
     if not n:
         return {}
