@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = 1e-3
 
-CASES = ["exit_only", "block_exit", "block_noexit", "layer_exit", "mask4_block_exit", "mask8_exit_c100"]
+CASES = ["exit_only", "block_exit", "block_noexit", "layer_exit", "mask4_block_exit", "mask8_exit_c100", "block_exit_p02",
+         "layer_exit_p256"]
 
 
 def _product(cls, kw):

@@ -10,7 +10,8 @@ from oracle import mcd, metrics
 from oracle.resnet18 import ResNet18EarlyExit, ResNet18MC, ResNet18MCEarlyExit
 from tests.helpers import build_seeded, golden_kwargs, load_golden, state_checksum
 
-CASES = ["exit_only", "block_exit", "block_noexit", "layer_exit", "mask4_block_exit", "mask8_exit_c100"]
+CASES = ["exit_only", "block_exit", "block_noexit", "layer_exit", "mask4_block_exit", "mask8_exit_c100", "block_exit_p02",
+         "layer_exit_p256"]
 
 
 @pytest.mark.parametrize("name", CASES)

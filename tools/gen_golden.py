@@ -104,6 +104,9 @@ RESNET_CASES = {
                               out_dim=10), 4, 10),
     "mask8_exit_c100": (dict(dropout_exit=True, dropout=None, mask_type="mask", num_masks=8, mask_scale=4.0,
                              out_dim=100), 2, 8),
+    # p values that draw 16 and 8 bits per element (the cases above draw 2 and 4): oracle/philox.py site_bits
+    "block_exit_p02": (dict(dropout_exit=True, dropout="block", dropout_p=0.2, out_dim=10), 5, 4),
+    "layer_exit_p256": (dict(dropout_exit=True, dropout="layer", dropout_p=3.0 / 256.0, out_dim=10), 3, 3),
 }
 
 
