@@ -543,6 +543,10 @@ int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s) {
     }
     const long blocks = (((long)a.M + WBP - 1) / WBP) * (a.Cout / WBC);
     if (blocks > 0x7fffffffL) return BMI_ERR_INVALID;
+    // a grid that cannot fill the chip (small deterministic-prefix launches: B images, not samples x B) is better
+    // served by conv_igemm's 128 x 128 tiles (4x as many workgroups)
+    static const int min_blocks = [] { const char* v = std::getenv("BMI_WIDE_MIN_BLOCKS"); return v ? std::atoi(v) : 192; }();
+    if (!a.wgt_b && blocks < min_blocks) return BMI_ERR_UNSUPPORTED;
     static const int persist = [] { const char* v = std::getenv("BMI_WIDE_PERSIST"); return v ? std::atoi(v) : 1; }();
     static const int n_cu = [] {
         int dev = 0, cu = 0;

@@ -52,6 +52,9 @@ WORKLOADS = {
                              dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=100, mask_type="mask",
                                   num_masks=8, mask_scale=4.0), 250, 8,
                              "ResNet18MCEarlyExit C=100 Masksembles M=8 block+exit, batch 250 x T=8 (BASELINE configs[3])"),
+    "vgg19_me": ("bayesnn_fpga_amd.models.vgg19.vgg19:VGG19MCEarlyExit", "oracle.vgg19:VGG19MCEarlyExit",
+                 dict(dropout_exit=True, dropout=None, dropout_p=0.25, out_dim=100), 250, 100,
+                 "VGG19MCEarlyExit C=100, exit dropout p=0.25 (the only mode the reference can construct), batch 250 x T=100"),
     "resnet50_me": ("bayesnn_fpga_amd.models.extra:ResNet50MCEarlyExit", "oracle.extra_models:ResNet50MCEarlyExit",
                     MODEL_KW, 250, 64,
                     "ResNet50MCEarlyExit (build-defined) C=10 dropout=block+exit p=0.25, batch 250 x T=64 "

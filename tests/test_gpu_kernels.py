@@ -271,10 +271,11 @@ def test_conv3x3_with_fused_shortcut(name, cin2):
     torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3)
 
 
-@pytest.mark.parametrize("name,n", [("D3", 5), ("D4", 21), ("P4", 7)])
+@pytest.mark.parametrize("name,n", [("D3", 801), ("D4", 1601), ("P4", 1601), ("D3", 5)])
 def test_conv_wide_tile_kernel_tails_residual_and_site(name, n):
-    """Cout % 256 == 0 shapes run in the 256 x 256-tile LDS-DMA kernel (conv_igemm_wide.hip): ragged pixel tiles
-    (M = n*Ho*Wo is not a multiple of 256), residual, ReLU and a fused elementwise site, bit-exact mask."""
+    """Cout % 256 == 0 shapes with at least 192 tiles run in the 256 x 256-tile LDS-DMA kernel (conv_igemm_wide.hip;
+    smaller grids fall back to conv_igemm's 128 x 128 tiles: the n = 5 case): ragged pixel tiles (M = n*Ho*Wo is not a
+    multiple of 256), residual, ReLU and a fused elementwise site, bit-exact mask."""
     cin, cout, H, k, s, p = SHAPES[name]
     B, tc, t0, seed = n, 1, 3, 99
     x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, n, 31, True)
