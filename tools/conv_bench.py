@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--site", action="store_true", help="fuse an elementwise MC-dropout site into the epilogue")
     ap.add_argument("--nores", action="store_true")
     ap.add_argument("--noscale", action="store_true")
+    ap.add_argument("--zero-input", action="store_true", help="all-zero activations: the same instruction stream at the lowest operand-toggling power")
     ap.add_argument("--sparse-input", action="store_true", help="post-ReLU, 25 %% dropped activations (as inside the network) instead of N(0,1)")
     a = ap.parse_args()
     lib = _lib.lib()
@@ -45,6 +46,8 @@ def main():
         ho = (H + 2 * p - k) // s + 1
         g = torch.Generator().manual_seed(1)
         x = torch.randn(n, H, H, cin, generator=g)
+        if a.zero_input:
+            x = torch.zeros_like(x)
         if a.sparse_input:
             x = torch.relu(x) * (torch.rand(n, H, H, cin, generator=g) > 0.25)
         x = x.to(torch.float16).to(dev)
