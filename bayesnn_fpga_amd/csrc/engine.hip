@@ -25,6 +25,7 @@ struct TensorInfo {
     int h = 0, w = 0, c = 0;
     bool stoch = false;
     bool bits = false;          // holds keep bits (1 bit per element) instead of fp16 activations
+    bool f32 = false;           // fp32 activations (output of a DENSE op)
     int first = -1, last = -1;  // suffix op indices (stochastic tensors only)
     size_t offset = 0;          // byte offset in the workspace
 };
@@ -175,6 +176,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         if (!tensor_ok(d.in) || !written[d.in] || !site_ok(d.site)) { rc = BMI_ERR_INVALID; break; }
         const TensorInfo tin = e->tensors[d.in];
         bool in_st = tin.stoch;
+        if (tin.f32 && d.kind != BMI_OP_DENSE && d.kind != BMI_OP_HEAD) { rc = BMI_ERR_UNSUPPORTED; break; }
         switch (d.kind) {
             case BMI_OP_STEM:
             case BMI_OP_CONV: {
@@ -277,6 +279,25 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 op.ho = to.h; op.wo = to.w; op.cout = to.c;
                 e->tensors[d.out].stoch = in_st;
                 (in_st ? e->suffix : e->prefix).push_back(op);
+                written[d.out] = 1;
+                break;
+            }
+            case BMI_OP_DENSE: {
+                if (!tensor_ok(d.out) || d.out == 0 || written[d.out] || d.in == 0 || !d.weight || !d.bias ||
+                    d.site_pos != BMI_SITE_POS_OUTER) {
+                    rc = BMI_ERR_INVALID; break;
+                }
+                const TensorInfo& to = e->tensors[d.out];
+                if (tin.h != 1 || tin.w != 1 || to.h != 1 || to.w != 1) { rc = BMI_ERR_INVALID; break; }
+                if (tin.c % 16 != 0 || to.c % 128 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                op.d.residual = -1; op.d.in2 = -1;
+                // a site makes the layer per-sample even on a deterministic input (the layer is tiny: no conv + MASK split)
+                op.stoch = in_st || d.site.kind != BMI_SITE_NONE;
+                op.ho = 1; op.wo = 1; op.cout = to.c;
+                e->tensors[d.out].stoch = op.stoch;
+                e->tensors[d.out].f32 = true;
+                (op.stoch ? e->suffix : e->prefix).push_back(op);
+                (op.stoch ? e->suffix_macs : e->prefix_macs) += (int64_t)tin.c * to.c;
                 written[d.out] = 1;
                 break;
             }
@@ -411,7 +432,7 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
         TensorInfo& t = h->tensors[i];
         if (t.stoch) continue;
         t.offset = off;
-        off += align_up(B * t.h * t.w * t.c * 2, 256);
+        off += align_up(B * t.h * t.w * t.c * (t.f32 ? 4 : 2), 256);
     }
     // first-fit packing of the suffix tensors by live range
     struct Blk { size_t off, size; int last; };
@@ -426,7 +447,7 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
         TensorInfo& t = h->tensors[id];
         live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.last < t.first; }), live.end());
         std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
-        const size_t size = align_up(t.bits ? NS * t.h * t.w * t.c / 8 : NS * t.h * t.w * t.c * 2, 256);
+        const size_t size = align_up(t.bits ? NS * t.h * t.w * t.c / 8 : NS * t.h * t.w * t.c * (t.f32 ? 4 : 2), 256);
         size_t pos = 0;
         for (const Blk& b : live) {
             if (pos + size <= b.off) break;
@@ -566,10 +587,15 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         case BMI_OP_MAXPOOL:
             return launch_maxpool2((const _Float16*)(ws + tin.offset), (_Float16*)(ws + e->tensors[d.out].offset), N, tin.h,
                                    tin.w, tin.c, s);
+        case BMI_OP_DENSE:
+            return launch_dense_f32(ws + tin.offset, tin.f32 ? 1 : 0, (const float*)d.weight, d.bias,
+                                    (float*)(ws + e->tensors[d.out].offset), N, tin.stoch ? N : B, tin.c, op.cout, d.relu,
+                                    resolve_site(&d.site, seed, cnt0), B, t0, s);
         case BMI_OP_HEAD: {
             EltArgs a;
             std::memset(&a, 0, sizeof(a));
             a.in = (const _Float16*)(ws + tin.offset);
+            a.in_f32 = tin.f32 ? 1 : 0;
             a.out = feat;
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
             const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
@@ -611,7 +637,7 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
             const int rc = run_op(h, op, x_nchw, ws, N, batch, t0, seed, mask_cnt0, feat, probs, logits, s);
             if (rc != BMI_OK) return rc;
         }
-        ProfScope prof(h, 6, s);
+        ProfScope prof(h, BMI_PROFILE_SLOT_MOMENTS, s);
         const int rc = launch_moments(probs, logits, S1, S2, SL, tc, batch, h->out_dim, h->n_exits,
                                       (size_t)N * h->out_dim, (size_t)batch * h->out_dim, s);
         if (rc != BMI_OK) return rc;
@@ -785,6 +811,15 @@ int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const fl
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;
     return launch_linear_softmax(feat, weight_pad, bias, logits, probs, n, k, out_dim, resolve_site(site, seed, 0), batch, t0,
                                  (hipStream_t)stream);
+}
+
+int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const float* bias, float* out, int32_t n,
+                  int32_t in_mod, int32_t k, int32_t cout, int32_t relu, const bmi_site* site, int32_t batch, int32_t t0,
+                  uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
+    if (!in || !weight || !bias || !out) return BMI_ERR_INVALID;
+    if (site && !site_ok(*site)) return BMI_ERR_INVALID;
+    return launch_dense_f32(in, in_is_f32, weight, bias, out, n, in_mod, k, cout, relu, resolve_site(site, seed, mask_cnt0), batch,
+                            t0, (hipStream_t)stream);
 }
 
 int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,

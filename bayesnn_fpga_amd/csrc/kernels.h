@@ -47,6 +47,7 @@ struct ConvArgs {
 
 struct EltArgs {  // MASK / POOL ops
     const _Float16* in;
+    int in_f32;   // POOL: `in` is an fp32 [N][HW][C] tensor (a dense layer's output)
     void* out;    // MASK: fp16 [N][HW][C]; POOL: fp32 [N][C]
     int N, in_mod, HW, C;
     int B, t0;
@@ -70,6 +71,9 @@ int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int 
 // `site` (kind NONE to skip): dropout on the LOGITS ([B, out_dim] tensor: element = b*out_dim + c), sample n / batch
 int launch_linear_softmax(const float* feat, const float* w, const float* bias, float* logits, float* probs, int n,
                           int k, int out_dim, const SiteArgs& site, int batch, int t0, hipStream_t s);
+// hidden dense layer, fp32 weights [cout][k] / accumulate / output; `in` fp16 or fp32 [n or in_mod][k]
+int launch_dense_f32(const void* in, int in_is_f32, const float* w, const float* bias, float* out, int n, int in_mod, int k,
+                     int cout, int relu, const SiteArgs& site, int batch, int t0, hipStream_t s);
 int launch_moments(const float* probs, const float* logits, double* S1, double* S2, double* SL, int tc, int batch,
                    int out_dim, int n_exits, size_t exit_stride_scratch, size_t exit_stride_S, hipStream_t s);
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,

@@ -178,6 +178,7 @@ int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, 
 }
 
 // ---------------------------------------------------------------------------------------------
+template <typename TIN>
 __global__ __launch_bounds__(256) void pool_mask_kernel(EltArgs a) {
     const int cg = a.C >> 3;
     const long total = (long)a.N * cg;
@@ -187,12 +188,19 @@ __global__ __launch_bounds__(256) void pool_mask_kernel(EltArgs a) {
     const int n = (int)(i / cg);
     const int tl = n / a.B, b = n - tl * a.B;
     const int t = a.t0 + tl;
-    const _Float16* src = a.in + (size_t)(n % a.in_mod) * a.HW * a.C + c8;
+    const TIN* src = (const TIN*)a.in + (size_t)(n % a.in_mod) * a.HW * a.C + c8;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = 0; p < a.HW; ++p) {
-        const half8 x = *(const half8*)(src + (size_t)p * a.C);
+        if constexpr (sizeof(TIN) == 2) {
+            const half8 x = *(const half8*)(src + (size_t)p * a.C);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += fmaxf((float)x[e], 0.f);  // F.relu before the pool
+            for (int e = 0; e < 8; ++e) v[e] += fmaxf((float)x[e], 0.f);  // F.relu before the pool
+        } else {
+            const float4 x0 = *(const float4*)(src + (size_t)p * a.C), x1 = *(const float4*)(src + (size_t)p * a.C + 4);
+            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += fmaxf(x[e], 0.f);
+        }
     }
     const float inv = 1.0f / (float)a.HW;
 #pragma unroll
@@ -210,7 +218,8 @@ int launch_pool_mask(const EltArgs& a, hipStream_t s) {
     if (a.C % 8 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || a.HW <= 0) return BMI_ERR_INVALID;
     const long total = (long)a.N * (a.C >> 3);
-    hipLaunchKernelGGL(pool_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    if (a.in_f32) hipLaunchKernelGGL(pool_mask_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pool_mask_kernel<_Float16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

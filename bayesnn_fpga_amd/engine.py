@@ -135,15 +135,14 @@ class GraphBuilder:
         return out
 
     def dense(self, x, linear, relu, site=None):
-        """Hidden fully-connected layer on a [N,1,1,C] tensor as a 1x1 convolution (same MFMA kernel)."""
+        """Hidden fully-connected layer on a flattened [N,1,1,C] tensor, fp32 weights / accumulation / output
+        (BMI_OP_DENSE: as a 1x1 fp16 conv the two VGG-11 dense layers pushed the predictive mean past 1e-3 at B=250)."""
         h, w, cin = self.tensors[x]
         if (h, w) != (1, 1) or cin != linear.in_features:
             raise ValueError("dense layers run on flattened [N,1,1,C] tensors")
         out = self.tensor(1, 1, linear.out_features)
-        wk = linear.weight.detach().reshape(linear.out_features, 1, 1, cin)
-        self.ops.append(dict(kind=_lib.OP_CONV, in_=x, out=out, residual=-1, ksize=1, stride=1, pad=0, relu=int(relu),
-                             weight=self.dev(wk, torch.float16), weight_packed=None, in2=-1, weight2=None, scale=None,
-                             bias=self.dev(linear.bias, torch.float32), site=site))
+        self.ops.append(dict(kind=_lib.OP_DENSE, in_=x, out=out, residual=-1, relu=int(relu),
+                             weight=self.dev(linear.weight, torch.float32), bias=self.dev(linear.bias, torch.float32), site=site))
         return out
 
     def head(self, x, linear, exit_index, site=None, site_on_logits=False):
@@ -267,6 +266,7 @@ class CompiledGraph:
         t = self.graph.tensors
         self.stem_macs = sum(t[o["out"]][0] * t[o["out"]][1] * t[o["out"]][2] * 27 for o in self.graph.ops if o["kind"] == _lib.OP_STEM)
         self.head_macs = sum(t[o["in_"]][2] * self.out_dim for o in self.graph.ops if o["kind"] == _lib.OP_HEAD)
+        self.dense_macs = sum(t[o["in_"]][2] * t[o["out"]][2] for o in self.graph.ops if o["kind"] == _lib.OP_DENSE)
 
     def _make_desc(self):
         g = self.graph

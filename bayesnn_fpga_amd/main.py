@@ -36,10 +36,13 @@ def report_suffix(args):
 
 def evaluate_and_analyse(model, test_loader, val_loader, hyperparameters, args, experiment_id, test_loss_fn=None,
                          snapshot_dir="./snapshots"):
+    if test_loss_fn is None:                               # the reference's test loss is its multi-exit accuracy (main.py:63-66)
+        from .engine import model_exits
+        from .train.evaluate import MultiExitAccuracy
+        test_loss_fn = MultiExitAccuracy(model_exits(model))
     results = evaluate(test_loss_fn, test_loader, model, hyperparameters["gpu"], experiment_id,
                        hyperparameters["mc_dropout_passes"])
     os.makedirs(snapshot_dir, exist_ok=True)
-    model.invalidate_engine()                              # compiled engines hold device handles: not part of the pickle
     torch.save(model, os.path.join(snapshot_dir, "final_model_" + str(experiment_id)))
     suffix = report_suffix(args)
     if args.full_analysis_and_save:

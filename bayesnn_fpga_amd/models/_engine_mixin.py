@@ -23,6 +23,13 @@ class EngineModelMixin:
     def invalidate_engine(self):
         self._engines = {}
 
+    def __getstate__(self):
+        """Compiled engines hold ctypes handles and device workspaces: never part of a pickle / deepcopy
+        (torch.save(model) of SA/main.py:79 works without a manual invalidate_engine())."""
+        state = self.__dict__.copy()
+        state["_engines"] = {}
+        return state
+
     def engine(self, device, max_batch=None, chunk_samples=None):
         """The compiled HIP engine for ``device`` (built on first use, rebuilt when it must grow)."""
         from ..engine import MCDEngine

@@ -57,7 +57,11 @@ class FullAnalysis:
     def _predict(self, b_x):
         """T folded passes on the GPU -> dict of float64 numpy arrays [E,B,C]."""
         eng = self.model.engine(b_x.device, max_batch=b_x.shape[0])
-        r = eng.predict(b_x, self.mc_passes, seed=self.seed + self._batch_index, cnt0=self.model.mask_cnt0())
+        # Masksembles layers keep ONE counter per layer that carries over from batch to batch and from evaluate() into
+        # this run (SA/utils.py:165-169, :228-230): pass i of this batch uses mask (cnt + i) mod M with the layers'
+        # CURRENT cnt.  (The Philox sample index restarts at 0 for every batch; the batch index is part of the seed.)
+        ml = self.model.mask_layers()
+        r = eng.predict(b_x, self.mc_passes, seed=self.seed + self._batch_index, t_begin=0, cnt0=ml[0].cnt if ml else 0)
         self.model.advance(self.mc_passes)
         return {k: v.cpu().numpy() for k, v in r.items()}
 
@@ -85,7 +89,14 @@ class FullAnalysis:
 
     def _collect(self, loader):
         n_exits, C = self.model.n_exits if self.model.n_exits > 1 else len(self._probe_exits()), self.model.out_dim
-        n = len(loader.dataset) if hasattr(loader, "dataset") else sum(len(b[1]) for b in loader)
+        # rows = what the loader actually yields: a SubsetRandomSampler validation loader (SA/datasets/dataset_loader.py:
+        # 156-164) walks a subset of its dataset; the reference sizes by len(val_loader.sampler.indices) (:179-215)
+        if getattr(loader, "sampler", None) is not None and hasattr(loader.sampler, "__len__"):
+            n = len(loader.sampler)
+        elif hasattr(loader, "dataset"):
+            n = len(loader.dataset)
+        else:
+            n = sum(len(b[1]) for b in loader)
         preds = np.empty((n_exits, n, C))
         var = np.empty((n_exits, n, C))
         labels = np.zeros((n, C))
@@ -103,6 +114,8 @@ class FullAnalysis:
             preds[:, off:off + B] = output_sm_np
             var[:, off:off + B] = self.last_var
             off += B
+        if off != n:                                   # drop_last loaders and the like: never return unfilled rows
+            preds, var, labels = preds[:, :off], var[:, :off], labels[:off]
         return preds, exit_ensembles(preds), labels, var, trackers
 
     def _probe_exits(self):

@@ -139,8 +139,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if a.share_gpu and a.backend == "nccl":
+        raise SystemExit("--share-gpu is the 1-GPU dry run of the N>1 path and needs --backend gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if a.share_gpu:
@@ -209,7 +210,7 @@ def main():
         value = samples / dt
         my_T = t_hi - t_lo
         # conv FLOPs of rank 0's profiled step: prefix convs once + suffix convs x its samples
-        conv_flops = 2.0 * B * ((eng.prefix_macs) + my_T * (eng.suffix_macs - eng.head_macs))
+        conv_flops = 2.0 * B * ((eng.prefix_macs) + my_T * (eng.suffix_macs - eng.head_macs - eng.dense_macs))
         conv_ms, conv_launches = prof.get("conv_igemm", (0.0, 0))
         conv_flops -= 2.0 * B * eng.stem_macs        # the 3-channel stem runs in its own direct kernel
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0

@@ -84,6 +84,9 @@ typedef struct bmi_site {
 #define BMI_OP_MASK 3  /* stand-alone stochastic site on a tensor                      */
 #define BMI_OP_HEAD 4  /* global avg-pool + site + Linear + softmax -> exit `out`      */
 #define BMI_OP_MAXPOOL 5 /* 2x2 stride-2 max-pool                                      */
+#define BMI_OP_DENSE 6 /* hidden fully-connected layer on a flattened [1][1][K] tensor, fp32 weights,
+                          accumulation and OUTPUT (the tensor `out` is then fp32 in the workspace and may
+                          only feed another DENSE or a HEAD): out = relu?(in . weight^T + bias) (site)   */
 
 typedef struct bmi_tensor_desc {
     int32_t h, w, c; /* per-image NHWC extent; tensor 0 is the network input */
@@ -101,7 +104,7 @@ typedef struct bmi_op_desc {
     int32_t ksize, stride, pad;
     int32_t relu;      /* apply ReLU after scale/bias(+residual)                       */
     const void* weight;  /* device; CONV fp16 [Cout][k][k][Cin]; STEM fp32 [Cout][k][k][Cin];
-                            HEAD fp32 [ceil32(out_dim)][Cin]                           */
+                            HEAD fp32 [ceil32(out_dim)][Cin]; DENSE fp32 [Cout][Cin]   */
     const void* weight2;       /* CONV with in2: device fp16 [Cout][Cin2] (BN scale folded in)          */
     const void* weight_packed; /* CONV 3x3: the same weights repacked by bmi_pack_conv3x3_weights
                                   (MFMA fragment order), or NULL to run the LDS-tile kernels */
@@ -129,7 +132,9 @@ typedef struct bmi_model_desc {
 } bmi_model_desc;
 
 /* per-op-kind device time, filled by bmi_profile_read */
-#define BMI_PROFILE_SLOTS 8 /* index = BMI_OP_*; slot 6 = moments, slot 7 = finalize */
+#define BMI_PROFILE_SLOTS 10 /* index = BMI_OP_*; slot 8 = moments, slot 9 = finalize */
+#define BMI_PROFILE_SLOT_MOMENTS 8
+#define BMI_PROFILE_SLOT_FINALIZE 9
 
 int bmi_version(void);
 const char* bmi_error_string(int code);
@@ -232,6 +237,14 @@ int bmi_linear_softmax(const float* feat, const float* weight_pad, const float* 
 int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
                             int32_t n, int32_t k, int32_t out_dim, const bmi_site* site, int32_t batch, int32_t t0,
                             uint64_t seed, bmi_stream stream);
+
+/* Hidden dense layer in fp32 (BMI_OP_DENSE): out[n][c] = relu?(in[n % in_mod] . weight[c] + bias[c]) (site on the
+ * [batch, cout] tensor, sample index n / batch + t0).  `in` is fp16 (in_is_f32 = 0) or fp32 [.][k]; weight fp32 [cout][k];
+ * k % 16 == 0, cout % 128 == 0.  Replaces the Dense 512 layers of the VGG-11 classifier stack
+ * (Hardware_Artifact/bayes_hw/models/models.py:262-281) with their dropout (:268-281). */
+int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const float* bias, float* out, int32_t n,
+                  int32_t in_mod, int32_t k, int32_t cout, int32_t relu, const bmi_site* site, int32_t batch, int32_t t0,
+                  uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
 
 /* S1/S2/SL [batch][out_dim] += sum over the tc samples of probs / probs^2 / logits ([tc][batch][out_dim]) */
 int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,

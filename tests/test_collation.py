@@ -211,3 +211,92 @@ def test_gpu_main_eval_half_end_to_end(tmp_path, monkeypatch):
     with open(tmp_path / "test_predictions_42.npy", "rb") as f:
         preds = np.load(f)
     assert preds.shape == (4, 8, 10) and np.allclose(preds.sum(-1), 1.0, atol=1e-6)
+
+
+def test_validation_loader_with_subset_sampler(tmp_path, monkeypatch):
+    """The reference's validation loader is a SubsetRandomSampler over the FULL training set (SA/datasets/dataset_loader.py:
+    156-164) and get_validation_predictions sizes by len(val_loader.sampler.indices) (results_analyzer.py:179-215): the
+    saved arrays hold exactly the sampled rows, never uninitialised ones (round-1 advisor finding)."""
+    from torch.utils.data import DataLoader, SubsetRandomSampler, TensorDataset
+    rng = np.random.RandomState(3)
+    T, E, B, C, n_all, idx = 2, 4, 4, 10, 40, [3, 7, 11, 19, 23, 29, 31, 37]
+    logits = rng.randn(T, E, B, C)
+    probs = torch.softmax(torch.from_numpy(logits), -1).numpy()
+    ds = TensorDataset(torch.zeros(n_all, 3, 32, 32), torch.from_numpy(rng.randint(0, C, size=n_all)))
+    val = DataLoader(ds, batch_size=B, sampler=SubsetRandomSampler(idx))
+    test = [(torch.zeros(B, 3, 32, 32), torch.zeros(B, dtype=torch.int64))]
+
+    class M(_M):
+        def eval(self):
+            return self
+
+    class FA(_Injected):
+        def __init__(self):
+            self._l, self._p = logits, probs
+            FullAnalysis.__init__(self, M(), test, gpu=-1, mc_dropout=True, mc_passes=T)
+    fa = FA()
+    preds, ens, labels = fa.get_validation_predictions(val)
+    assert preds.shape == ens.shape == (E, len(idx), C) and labels.shape == (len(idx), C)
+    np.testing.assert_allclose(preds.sum(-1), 1.0, atol=1e-12)           # every row was written
+    assert labels.sum() == len(idx)
+    monkeypatch.chdir(tmp_path)
+    fa.save_validation("v", val)
+    with open(tmp_path / "validation_predictions_v.npy", "rb") as f:
+        a = np.load(f)
+    assert a.shape == (E, len(idx), C)
+
+
+def test_model_pickles_and_deepcopies_with_a_compiled_engine():
+    """torch.save(model) (SA/main.py:79) / copy.deepcopy must not need a manual invalidate_engine(): the engine cache
+    (ctypes handles) is dropped from the pickled state."""
+    import copy
+    import io
+    from bayesnn_fpga_amd.engine import CompiledGraph
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+    torch.manual_seed(0)
+    m = ResNet18MCEarlyExit(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    m._engines["cpu"] = CompiledGraph(m, "cpu", 4, 2)          # what engine() caches (host-only half: no GPU here)
+    c = copy.deepcopy(m)
+    assert c._engines == {} and len(m._engines) == 1
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert r._engines == {} and r.dropout == "block"
+
+
+def test_main_default_test_loss_is_multi_exit_accuracy():
+    """evaluate_and_analyse(..., test_loss_fn=None) builds the reference's test loss (main.py:63-66) instead of
+    forwarding None to evaluate() (round-1 advisor finding)."""
+    import inspect
+    from bayesnn_fpga_amd import main
+    src = inspect.getsource(main.evaluate_and_analyse)
+    assert "MultiExitAccuracy(model_exits(model))" in src
+
+
+@pytest.mark.gpu
+def test_gpu_masksembles_counter_carries_across_batches():
+    """Masksembles layers keep one counter across batches and across evaluate() -> FullAnalysis (SA/utils.py:165-169,
+    :228-230): with M=4, T=10 batch 0 sees masks 0,1,2,3,0,1,2,3,0,1 and batch 1 starts at mask 2.  The oracle's layers
+    count their own calls like the reference's; the mirror must agree batch by batch (round-1 advisor finding)."""
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
+    from oracle import mcd
+    from oracle import resnet18 as oresnet
+    from tests.helpers import build_seeded
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10, mask_type="mask", num_masks=4, mask_scale=4.0)
+    m, o = build_seeded(ResNet18MCEarlyExit, kw), build_seeded(oresnet.ResNet18MCEarlyExit, kw)
+    synthetic_weights_(m, 0)
+    synthetic_weights_(o, 0)
+    B, T = 4, 10
+    x, y = synthetic_images(3 * B, seed=3), synthetic_labels(3 * B, 10, seed=4)
+    loader = [(x[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(3)]
+    fa = FullAnalysis(m.to("cuda:0").eval(), loader, gpu=0, mc_dropout=True, mc_passes=T)
+    want = np.concatenate([mcd.mcd_predict(o, bx, T, seed=0)["mean"] for bx, _ in loader], axis=1)   # o's cnt carries over
+    np.testing.assert_allclose(fa.preds, want, rtol=0, atol=1e-3)
+    assert m.mask_layers()[0].cnt == (3 * T) % 4 == o.layer1[1].cnt
+    # the bug this guards against: every batch restarting at mask 0 is far outside the tolerance
+    o2 = build_seeded(oresnet.ResNet18MCEarlyExit, kw)
+    synthetic_weights_(o2, 0)
+    restart = mcd.mcd_predict(o2, loader[1][0], T, seed=0)["mean"]
+    assert np.abs(restart - want[:, B:2 * B]).max() > 5e-3

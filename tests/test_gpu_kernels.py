@@ -442,3 +442,44 @@ def test_conv_pair_persistent_kernel():
     for i in range(2):
         ref = gh.conv_ref(x, ws[i], scs[i], bis[i], None, True, s, p, n, n, 1)
         torch.testing.assert_close(outs[i].float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("in_f32,kind,relu", [(0, "none", 1), (0, _lib.SITE_ELEMENTWISE, 1), (1, _lib.SITE_ELEMENTWISE, 1),
+                                              (1, _lib.SITE_MASKSEMBLE, 0), (0, _lib.SITE_CHANNEL, 1)])
+def test_dense_f32(in_f32, kind, relu):
+    """BMI_OP_DENSE (hidden Dense of the VGG-11 classifier stack) in fp32 on the exact-f32 MFMA: fp16 or fp32 input,
+    deterministic input broadcast over the samples (in_mod = B), bit-exact site mask, ragged N (not a multiple of 32)."""
+    lib = _lib.lib()
+    B, tc, K, Cout, t0, seed, cnt0 = 7, 5, 512, 256, 3, (9 << 32) + 1, 2
+    N = B * tc
+    g = _gen(11)
+    in_mod = N if in_f32 else B
+    x = torch.randn(in_mod, K, generator=g)
+    xd = x.to(DEV) if in_f32 else x.half().to(DEV)
+    xr = xd.cpu().double()
+    w = 0.05 * torch.randn(Cout, K, generator=g)
+    b = 0.3 * torch.randn(Cout, generator=g)
+    wd, bd = w.to(DEV), b.to(DEV)
+    out = torch.full((N, Cout), float("nan"), device=DEV)
+    site = None
+    if kind == _lib.SITE_MASKSEMBLE:
+        site = dict(kind=kind, site_id=4, masks=(torch.rand(4, Cout, generator=g) < 0.6).float().numpy())
+    elif kind != "none":
+        site = dict(kind=kind, site_id=4, p=0.25)
+    keep = []
+    s = gh.site_struct(site, keep)
+    _lib.check(lib.bmi_dense_f32(gh.ptr(xd), in_f32, gh.ptr(wd), gh.ptr(bd), gh.ptr(out), N, in_mod, K, Cout, relu,
+                                 C.byref(s) if s is not None else None, B, t0, seed, cnt0, gh.stream()), "bmi_dense_f32")
+    torch.cuda.synchronize()
+    ref = xr[torch.arange(N) % in_mod] @ w.double().T + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    if site is not None:
+        # a per-(image, channel) draw on a [B, C] tensor is the elementwise draw
+        ms = dict(site, kind=_lib.SITE_ELEMENTWISE) if kind == _lib.SITE_CHANNEL else site
+        mult = gh.folded_site_mask(ms, B, Cout, 1, 1, tc, t0, seed, cnt0).reshape(N, Cout).double()
+        ref = ref * mult
+        assert torch.equal((out.cpu() == 0) | (ref == 0), (mult == 0) | (ref == 0)) and (mult == 0).any()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-5)
+    assert lib.bmi_dense_f32(gh.ptr(xd), in_f32, gh.ptr(wd), gh.ptr(bd), gh.ptr(out), N, in_mod, K, 200, relu, None, B, t0,
+                             seed, cnt0, gh.stream()) == -95
