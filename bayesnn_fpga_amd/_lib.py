@@ -30,7 +30,7 @@ class TensorDesc(C.Structure):
 class OpDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_", C.c_int32), ("out", C.c_int32), ("residual", C.c_int32), ("in2", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32),
-                ("weight", C.c_void_p), ("weight2", C.c_void_p), ("weight_packed", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site),
+                ("weight", C.c_void_p), ("weight2", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("site", Site),
                 ("bias_post", C.c_void_p), ("site_pos", C.c_int32)]
 
 
@@ -50,6 +50,7 @@ _lib = None
 _PROTOS = {
     "bmi_version": (C.c_int, []),
     "bmi_error_string": (C.c_char_p, [C.c_int]),
+    "bmi_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "bmi_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "bmi_destroy": (C.c_int, [C.c_void_p]),
     "bmi_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
@@ -63,10 +64,9 @@ _PROTOS = {
     "bmi_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bmi_philox_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "bmi_stem_conv_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 9 + [C.c_void_p]),
-    "bmi_pack_conv3x3_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "bmi_mask_bits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site), C.c_int32, C.c_int32, C.c_uint64,
                                 C.c_void_p]),
-    "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
+    "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 5 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
                                                                          C.c_uint64, C.c_int32, C.c_void_p]),
     "bmi_conv3x3_shortcut_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 7 + [C.c_void_p]),
     "bmi_profile_conv_families": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -114,6 +114,11 @@ def error_string(code):
 def check(code, what):
     if code != BMI_OK:
         raise BmiError(code, what)
+
+
+def set_option(name, value):
+    """Process-wide kernel-selection switch (bmi_set_option): e.g. set_option("mfma_shape_patch", 16)."""
+    check(lib().bmi_set_option(name.encode(), int(value)), f"bmi_set_option({name})")
 
 
 def make_site(kind=SITE_NONE, site_id=0, p=0.0, num_masks=0, masks_ptr=None):

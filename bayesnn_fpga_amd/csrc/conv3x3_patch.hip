@@ -7,11 +7,11 @@
 // shifting the per-lane fragment address; only the 16 KB weight tile streams per K-step.
 //
 //   work-group  = IMGS images x (TH x TW) output pixels (BP = 64*TJ pixels) x 128 output channels
-//   4 waves     = 2 (channels) x 2 (pixels); wave tile 64 channels x 32*TJ pixels of 32x32x16 MFMAs
+//   4 waves     = 2 (channels) x 2 (pixels); wave tile 64 channels x 32*TJ pixels of 32x32x16 or 16x16x32 MFMAs
 //   LDS         = patch [cells][64 ch] fp16 (128 B per cell) + 2 x weight tile [128][64]
 //   staging     = patch: global_load_lds_dwordx4 (LDS-DMA), no VGPR round trip, no ds_write; padding and
 //                 halo cells are DMA'd from a zero page, so there is no bounds logic in the loop.
-//                 weights: LDS-DMA one K-step ahead (or register-staged, BMI_PATCH_WDMA=0)
+//                 weights: LDS-DMA one K-step ahead
 //   swizzle     = 16-byte chunk c of a cell is stored at chunk (c ^ ((key >> 1) & 7)) with
 //                 key = patch_x + KA * patch_y chosen per tile shape so that the 16 lanes of every
 //                 ds_read_b128 group hit 16 distinct 16-byte slots; LDS-DMA writes linearly, so the
@@ -57,49 +57,35 @@ __device__ unsigned int g_zero_page[64];  // 256 B of zeros: DMA source for padd
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),       \
                                      (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
 
-template <int S, int TH, int TW, int IMGS, int TJ, int NB = 2>
+template <int TH, int TW, int IMGS, int TJ>
 struct PatchGeom {
-    static constexpr int BC = 128, TI = 2;
+    static constexpr int BC = 128;
     static constexpr int BP = IMGS * TH * TW;
     static_assert(BP == 64 * TJ, "pixel tile must be 2 waves x TJ x 32");
-    static constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-    static constexpr int HALF = S == 1 ? 0 : (((PW + 1) / 2 + 1) & ~1);        // even
-    static constexpr int PWP = S == 1 ? ((PW + 1) & ~1) : 2 * HALF;            // even pitch (cells)
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int PWP = (PW + 1) & ~1;                                  // even pitch (cells)
     static constexpr int KA = TW >= 16 ? 0 : (TW == 8 ? 8 : 4);
     static constexpr int CELLS = IMGS * PH * PWP;
     static constexpr int PIECES = CELLS * 8;
     static constexpr int ITER_P = (PIECES + 255) / 256;
     static constexpr int PATCH_BYTES = ITER_P * 256 * 16;
     static constexpr int WTILE = BC * 128;
-    static constexpr int MAIN_BYTES = PATCH_BYTES + NB * WTILE;
+    static constexpr int MAIN_BYTES = PATCH_BYTES + 2 * WTILE;
     static constexpr int LDS_BYTES = MAIN_BYTES > BMI_EPILOGUE_LDS_BYTES ? MAIN_BYTES : BMI_EPILOGUE_LDS_BYTES;
 };
 
-#ifndef BMI_PATCH_WDMA
-#define BMI_PATCH_WDMA 1
-#endif
-#ifndef BMI_PATCH_NB_S3
-#define BMI_PATCH_NB_S3 2
-#endif
-#ifndef BMI_PATCH_SWPIPE
-#define BMI_PATCH_SWPIPE 0
-#endif
-#ifndef BMI_PATCH_SETPRIO   // raise the wave's priority while it issues a k-substep's MFMAs (the other workgroup's wave loads meanwhile)
-#define BMI_PATCH_SETPRIO 0
-#endif
-#ifndef BMI_PATCH_RDEARLY   // fragment reads of k-substep kk+1 right behind the FIRST MFMA of kk (hipcc puts them behind the last)
-#define BMI_PATCH_RDEARLY 0
-#endif
-#ifndef BMI_PATCH_WSPREAD   // issue the next weight tile's 4 DMA pieces one per k-substep, behind its MFMAs (not as a burst)
-#define BMI_PATCH_WSPREAD 0
-#endif
-
-template <int S, int TH, int TW, int IMGS, int TJ, int NB, bool PLAIN>
+// MS = MFMA shape: 32 -> v_mfma_f32_32x32x16_f16 (wave tile = 2 x TJ tiles), 16 -> v_mfma_f32_16x16x32_f16 (4 x 2TJ
+// tiles).  Same wave tile (64 channels x 32*TJ pixels), same LDS bytes per FLOP (a ds_read_b128 is a 32 x 16 or a
+// 16 x 32 fragment), same LDS layout and swizzle (the 16 lanes of a read group are 16 consecutive rows either way).
+// Which one is faster is a clock question, not a cycle question (MI355X_MICROARCH.md, DVFS give-back item 7): both are
+// built and launch_conv3x3_patch picks by measured wall time (BMI_MFMA_SHAPE overrides).
+template <int TH, int TW, int IMGS, int TJ, bool PLAIN, int MS>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
-    constexpr bool WDMA = BMI_PATCH_WDMA != 0;
-    static_assert(NB == 2 || WDMA, "deeper weight prefetch is implemented for the LDS-DMA path");
-    using G = PatchGeom<S, TH, TW, IMGS, TJ, NB>;
-    constexpr int BC = G::BC, TI = G::TI, PH = G::PH, PW = G::PW, PWP = G::PWP, HALF = G::HALF, KA = G::KA;
+    using G = PatchGeom<TH, TW, IMGS, TJ>;
+    constexpr int BC = G::BC, PH = G::PH, PW = G::PW, PWP = G::PWP, KA = G::KA;
+    constexpr int TI = MS == 32 ? 2 : 4;          // channel tiles per wave
+    constexpr int TP = MS == 32 ? TJ : 2 * TJ;    // pixel tiles per wave
+    constexpr int RW = MS;                        // rows (channels / pixels) per MFMA tile
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     char* const patch = smem;
     char* const wbuf = smem + G::PATCH_BYTES;
@@ -108,7 +94,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     STAMP(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
+    const int r = lane & (RW - 1);                // row of the lane inside an MFMA tile
+    const int kq = lane / RW;                     // which 8-element k group of the MFMA's K the lane holds (0..64/RW-1)
+    constexpr int KSUB = MS == 32 ? 4 : 2;        // MFMA k-substeps per 64-deep K-step
+    constexpr int KQ = 64 / RW;                   // 16-byte chunks of a 128-byte row consumed per substep
     const int wc = wave >> 1, wp = wave & 1;
 
     // ---- tile coordinates (channel tile fastest) ------------------------------------------------
@@ -131,28 +120,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     for (int i = 0; i < G::ITER_P; ++i) {
         const int q = tid + 256 * i;
         const int cell = q >> 3, cp = q & 7;
-        const int rowc = cell / PWP, col = cell - rowc * PWP;
+        const int rowc = cell / PWP, px = cell - rowc * PWP;
         const int img = rowc / PH, py = rowc - img * PH;
-        int px, key;
-        if (S == 1) { px = col; key = px + KA * py; }
-        else { const int par = col / HALF, hx = col - par * HALF; px = 2 * hx + par; key = hx + KA * py; }
+        const int key = px + KA * py;
         const int c = cp ^ ((key >> 1) & 7);
         const int n = n0 + img;
-        const int iy = y0 * S - 1 + py, ix = x0 * S - 1 + px;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = cell < G::CELLS && px < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         psrc[i] = ok ? (int)((((size_t)(n % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + c * 8) : -1;
     }
-    // weight tile, build-time variants (same-box A/B on S2/S3/S4, tools/ab_run.sh): LDS-DMA one K-step
-    // ahead with plain per-substep fragment reads is the default (910 TF/s); register staging
-    // (BMI_PATCH_WDMA=0) -10 %, hand-pipelined fragment reads (BMI_PATCH_SWPIPE=1) -3 %, a third
-    // weight buffer with counted vmcnt (NB=3) -4 % on S3: per-phase stamps (tools/stamps.py) show the
-    // weight-DMA wait is only ~70 cycles per K-step; the losses are the ~680-cycle barrier skew per
-    // K-step and the prologue / epilogue phases.
+    // Weight tile: LDS-DMA one K-step ahead, double buffered, issued as one burst behind the barrier.  Recorded
+    // negatives (round 1, same-box A/B on S2/S3/S4): register staging -10 %, hand-pipelined fragment reads -3 %, a third
+    // buffer with counted vmcnt -4 %, one DMA piece per k-substep -2..-7 %, s_setprio around the MFMAs -2 %,
+    // stride-2 convs through this kernel (1 workgroup per CU) -20..-35 % vs the wide per-tap kernel.
     const int w_row = tid >> 3;
     const int w_sw = (w_row >> 1) & 7;
-    const _Float16* wsrc = a.wgt + (size_t)(ch0 + w_row) * Ktot + (WDMA ? ((tid & 7) ^ w_sw) : (tid & 7)) * 8;
-    const int w_st = w_row * 128 + (((tid & 7) ^ w_sw) << 4);
-    u32x4 wreg[4];
+    const _Float16* wsrc = a.wgt + (size_t)(ch0 + w_row) * Ktot + ((tid & 7) ^ w_sw) * 8;
 
 #define ISSUE_PATCH(C0)                                                                           \
     {                                                                                             \
@@ -162,185 +145,79 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     }
 #define LOAD_W(KOFF, BUF)                                                                         \
     {                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-            if constexpr (WDMA)                                                                   \
-                GLDS16(wsrc + (size_t)(32 * i) * Ktot + (KOFF),                                   \
-                       wbuf + (BUF) * G::WTILE + (i * 256 + wave * 64) * 16);                     \
-            else                                                                                  \
-                wreg[i] = *(const u32x4*)(wsrc + (size_t)(32 * i) * Ktot + (KOFF));               \
-        }                                                                                         \
-    }
-#define STORE_W(BUF)                                                                              \
-    {                                                                                             \
-        if constexpr (!WDMA) {                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
-                *(u32x4*)(wbuf + (BUF) * G::WTILE + w_st + i * 32 * 128) = wreg[i];               \
-        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+            GLDS16(wsrc + (size_t)(32 * i) * Ktot + (KOFF),                                       \
+                   wbuf + (BUF) * G::WTILE + (i * 256 + wave * 64) * 16);                         \
     }
 
     // ---- per-lane fragment geometry --------------------------------------------------------------
-    int bcell[TJ], bkey[TJ];
+    int bcell[TP], bkey[TP];
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const int p = wp * (32 * TJ) + 32 * j + r;
+    for (int j = 0; j < TP; ++j) {
+        const int p = wp * (32 * TJ) + RW * j + r;
         const int img = p / (TH * TW), rem = p - img * (TH * TW);
         const int oy = rem / TW, ox = rem - oy * TW;
-        bcell[j] = (img * PH + oy * S) * PWP + (S == 1 ? ox : ox);   // tap (0,0); S=2: column part added per tap
-        bkey[j] = (S == 1 ? ox : ox) + KA * (oy * S);
+        bcell[j] = (img * PH + oy) * PWP + ox;   // tap (0,0)
+        bkey[j] = ox + KA * oy;
     }
     const int a_off = (wc * 64 + r) * 128;
     const int a_sw = (r >> 1) & 7;
 
-    f32x16 acc[TI][TJ];
+    typedef float accv __attribute__((ext_vector_type(MS == 32 ? 16 : 4)));
+    accv acc[TI][TP];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
+        for (int j = 0; j < TP; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < (MS == 32 ? 16 : 4); ++e) acc[i][j][e] = 0.f;
+
+#define PATCH_MFMA(AF, BF, ACC)                                                                   \
+    if constexpr (MS == 32) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF, BF, ACC, 0, 0, 0);   \
+    else ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF, BF, ACC, 0, 0, 0);
 
     const int nchunks = a.Cin / 64;
     const int nK = 9 * nchunks;
-    // K-step s = chunk * 9 + tap uses weight buffer s % NB.  The weight tiles of steps s+1 .. s+NB-1
-    // are in flight while step s computes (L2 latency under load is about one whole K-step, so
-    // NB = 3 keeps two tiles in flight and waits with a COUNTED vmcnt).
+    // K-step s = chunk * 9 + tap uses weight buffer s & 1; the tile of step s+1 is in flight while step s computes
     auto w_koff = [&](int st) { const int c = st / 9, t = st - 9 * c; return t * a.Cin + c * 64; };
     ISSUE_PATCH(0);
     LOAD_W(0, 0);
-    STORE_W(0);
-    if constexpr (NB == 3) {
-        if (nK > 1) LOAD_W(w_koff(1), 1);
-    }
     int step = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < 9; ++tap, ++step) {
-            const int buf = step % NB;
-            if constexpr (NB == 3) {
-                // all but the youngest weight tile (4 DMA instructions per wave) must have landed;
-                // at a chunk start the patch DMA (issued last) must have landed too
-                if (tap == 0 || step + 1 >= nK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                lds_barrier();
-                if (step + 2 < nK) LOAD_W(w_koff(step + 2), (step + 2) % NB);
-            } else {
+            const int buf = step & 1;
 #ifdef BMI_PATCH_STAMPS
-                const unsigned long long tw0 = __builtin_readcyclecounter();
+            const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                STAMP_ADD(4, tw0);
-                __syncthreads();   // patch landed, W[step&1] written; every wave is done with W[(step+1)&1]
-                STAMP_ADD(5, tw0);
-                if (step == 0) { STAMP(1); }
-                if (!(BMI_PATCH_WSPREAD && WDMA) && step + 1 < nK) LOAD_W(w_koff(step + 1), buf ^ 1);
-            }
-            const bool more = step + 1 < nK;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP_ADD(4, tw0);
+            __syncthreads();   // patch landed, W[step&1] written; every wave is done with W[(step+1)&1]
+            STAMP_ADD(5, tw0);
+            if (step == 0) { STAMP(1); }
+            if (step + 1 < nK) LOAD_W(w_koff(step + 1), buf ^ 1);
             const int ky = tap / 3, kx = tap - 3 * ky;
             // per-tap cell shift and swizzle key shift
-            int coff, koff;
-            if (S == 1) { coff = ky * PWP + kx; koff = kx + KA * ky; }
-            else { coff = ky * PWP + (kx & 1) * HALF + (kx >> 1); koff = (kx >> 1) + KA * ky; }
+            const int coff = ky * PWP + kx, koff = kx + KA * ky;
             const char* wt = wbuf + buf * G::WTILE;
-            int boff[TJ], bsw[TJ];
+            int boff[TP], bsw[TP];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
+            for (int j = 0; j < TP; ++j) {
                 boff[j] = (bcell[j] + coff) * 128;
                 bsw[j] = ((bkey[j] + koff) >> 1) & 7;
             }
-#if BMI_PATCH_SWPIPE
-            // Fragment reads are software-pipelined by hand: the reads for k-substep kk+1 are issued
-            // between the MFMAs of kk, each into the registers whose last MFMA use has just been issued,
-            // so the LDS latency hides under the remaining MFMAs instead of stalling every substep.
-            half8 af[TI], bf[TJ];
-#define RD_A(I, KK) af[I] = *(const half8*)(wt + a_off + (I) * 32 * 128 + (((2 * (KK) + hh) ^ a_sw) << 4))
-#define RD_B(J, KK) bf[J] = *(const half8*)(patch + boff[J] + (((2 * (KK) + hh) ^ bsw[J]) << 4))
 #pragma unroll
-            for (int i = 0; i < TI; ++i) RD_A(i, 0);
+            for (int kk = 0; kk < KSUB; ++kk) {
+                const int ch = KQ * kk + kq;
+                half8 af[TI], bf[TP];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) RD_B(j, 0);
+                for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wt + a_off + i * RW * 128 + ((ch ^ a_sw) << 4));
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[j], acc[0][j], 0, 0, 0);
-                if (kk < 3) RD_A(0, kk + 1);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[j], acc[1][j], 0, 0, 0);
-                    if (kk < 3) RD_B(j, kk + 1);
-                }
-                if (kk < 3) RD_A(1, kk + 1);
-            }
-#undef RD_A
-#undef RD_B
-            // pin the interleave (LLVM sched groups: 0x008 = MFMA, 0x100 = DS read)
-            __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                __builtin_amdgcn_sched_group_barrier(0x008, TJ, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TJ, 0);
-#elif BMI_PATCH_RDEARLY
-            {
-                half8 fa[2][TI], fb[2][TJ];
-#define RDF(KK, SET)                                                                                              \
-    {                                                                                                             \
-        const int ch_ = 2 * (KK) + hh;                                                                            \
-        _Pragma("unroll") for (int i = 0; i < TI; ++i) fa[SET][i] = *(const half8*)(wt + a_off + i * 32 * 128 + ((ch_ ^ a_sw) << 4)); \
-        _Pragma("unroll") for (int j = 0; j < TJ; ++j) fb[SET][j] = *(const half8*)(patch + boff[j] + ((ch_ ^ bsw[j]) << 4));      \
-    }
-                RDF(0, 0);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int cur = kk & 1;
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
-                    if (kk < 3) RDF(kk + 1, cur ^ 1);
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int j = 0; j < TJ; ++j)
-                            if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-                }
-#undef RDF
-                // pin: per substep 1 MFMA, then the next substep's reads, then the remaining MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ - 1, 0);
-                }
-            }
-#else
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int ch = 2 * kk + hh;
-                half8 af[TI], bf[TJ];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wt + a_off + i * 32 * 128 + ((ch ^ a_sw) << 4));
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(patch + boff[j] + ((ch ^ bsw[j]) << 4));
-                if (BMI_PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                for (int j = 0; j < TP; ++j) bf[j] = *(const half8*)(patch + boff[j] + ((ch ^ bsw[j]) << 4));
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                if (BMI_PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
-                if constexpr (BMI_PATCH_WSPREAD && WDMA && NB == 2) {
-                    if (more)
-                        GLDS16(wsrc + (size_t)(32 * kk) * Ktot + w_koff(step + 1), wbuf + (buf ^ 1) * G::WTILE + (kk * 256 + wave * 64) * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                    for (int j = 0; j < TP; ++j) { PATCH_MFMA(af[i], bf[j], acc[i][j]); }
             }
-#endif
-            if (more) STORE_W(buf ^ 1);
             if (tap == 8 && chunk + 1 < nchunks) {
                 lds_barrier();                 // every wave is done reading this chunk's patch
                 ISSUE_PATCH((chunk + 1) * 64);
@@ -349,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     }
 #undef ISSUE_PATCH
 #undef LOAD_W
-#undef STORE_W
 
     // ---- fused 1x1 strided shortcut: extra K-steps on a halo-free "patch" of the block input -----
     // (the downsample conv of BasicBlock: as its own launch it is a K = 64..256 GEMM that costs 10 % of
@@ -379,14 +255,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int ch = 2 * kk + hh;
-                half8 af[TI], bf[TJ];
+            for (int kk = 0; kk < KSUB; ++kk) {
+                const int ch = KQ * kk + kq;
+                half8 af[TI], bf[TP];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wbuf + a_off + i * 32 * 128 + ((ch ^ a_sw) << 4));
+                for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wbuf + a_off + i * RW * 128 + ((ch ^ a_sw) << 4));
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    const int p = wp * (32 * TJ) + 32 * j + r;
+                for (int j = 0; j < TP; ++j) {
+                    const int p = wp * (32 * TJ) + RW * j + r;
                     const int rem = p % (TH * TW);
                     const int sw = (((rem % TW) + KA * (rem / TW)) >> 1) & 7;
                     bf[j] = *(const half8*)(patch + p * 128 + ((ch ^ sw) << 4));
@@ -394,11 +270,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TP; ++j) { PATCH_MFMA(af[i], bf[j], acc[i][j]); }
             }
         }
     }
+#undef PATCH_MFMA
 
     STAMP(2);
     // ---- epilogue (coalesced through LDS) ----------------------------------------------------------
@@ -415,16 +291,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         off = ((size_t)n * (a.Ho * a.Wo) + rem) * a.Cout;
         return ok;
     };
-    epilogue_coalesced<TJ, PLAIN>(a, acc, smem, tid, ch0, pixmap, offmap);
+    epilogue_coalesced<TJ, PLAIN, MS>(a, acc, smem, tid, ch0, pixmap, offmap);
     STAMP(3);
 }
 
-template <int S, int TH, int TW, int IMGS, int TJ, int NB = 2>
+template <int TH, int TW, int IMGS, int TJ>
 static int launch_patch(const ConvArgs& a, hipStream_t s) {
     const long tiles = (long)((a.N + IMGS - 1) / IMGS) * (a.Ho / TH) * (a.Wo / TW) * (a.Cout / 128);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
-    if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv3x3_patch_kernel<S, TH, TW, IMGS, TJ, NB, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<S, TH, TW, IMGS, TJ, NB, false>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    const bool plain = conv_epilogue_is_plain(a);
+    const dim3 grid((unsigned)tiles), block(256);
+    if (opt_mfma_shape_patch() == 16) {   // bmi_set_option / BMI_MFMA_SHAPE; default chosen by measured wall time
+        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16>), grid, block, 0, s, a);
+    } else {
+        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 32>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 32>), grid, block, 0, s, a);
+    }
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -440,20 +323,12 @@ bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, 
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s) {
     if (a.in_bits) return BMI_ERR_UNSUPPORTED;   // the patch is filled by DMA: no place to apply keep bits
     if (a.in2 && (!a.wgt2 || a.Cin2 % 64 != 0 || a.in2_mod <= 0 || a.stride2 < 1)) return BMI_ERR_INVALID;
-    if (a.ksize != 3 || a.pad != 1 || a.Cin % 64 != 0 || a.Cout % 128 != 0) return BMI_ERR_UNSUPPORTED;
+    if (a.ksize != 3 || a.pad != 1 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % 128 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
     if ((size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets
-    if (a.stride == 1) {
-        if (a.Ho == 16 && a.Wo == 16) return launch_patch<1, 16, 16, 1, 4>(a, s);
-        if (a.Ho == 8 && a.Wo == 8) return launch_patch<1, 8, 8, 2, 2, BMI_PATCH_NB_S3>(a, s);
-        if (a.Ho == 4 && a.Wo == 4) return launch_patch<1, 4, 4, 8, 2>(a, s);
-        if (a.Ho % 8 == 0 && a.Wo == 32) return launch_patch<1, 8, 32, 1, 4>(a, s);
-    }
-    static const int s2 = [] { const char* v = std::getenv("BMI_PATCH_S2"); return v ? std::atoi(v) : 0; }();
-    if (a.stride == 2 && s2) {   // experimental: stride-2 through the patch kernel (1 workgroup per CU)
-        if (a.Ho == 8 && a.Wo == 8) return launch_patch<2, 8, 8, 2, 2>(a, s);
-        if (a.Ho == 4 && a.Wo == 4) return launch_patch<2, 4, 4, 8, 2>(a, s);
-        if (a.Ho == 16 && a.Wo == 16) return launch_patch<2, 8, 16, 1, 2>(a, s);
-    }
+    if (a.Ho == 16 && a.Wo == 16) return launch_patch<16, 16, 1, 4>(a, s);
+    if (a.Ho == 8 && a.Wo == 8) return launch_patch<8, 8, 2, 2>(a, s);
+    if (a.Ho == 4 && a.Wo == 4) return launch_patch<4, 4, 8, 2>(a, s);
+    if (a.Ho % 8 == 0 && a.Wo == 32) return launch_patch<8, 32, 1, 4>(a, s);
     return BMI_ERR_UNSUPPORTED;
 }

@@ -126,6 +126,9 @@ typedef float f32x4_e __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
 
 #define BMI_EPILOGUE_LDS_BYTES 65536
+#ifndef BMI_DEFAULT_MFMA_SHAPE
+#define BMI_DEFAULT_MFMA_SHAPE 16   // v_mfma_f32_16x16x32_f16 (same-process A/B on the headline step: 26.04 vs 26.82 ms with 32x32x16, bit-identical results)
+#endif
 
 // launch-uniform: BN + ReLU only (an inner site also has kind != NONE)
 __host__ __device__ inline bool conv_epilogue_is_plain(const ConvArgs& a) { return !a.res && a.site.kind == BMI_SITE_NONE; }
@@ -146,11 +149,40 @@ __device__ __forceinline__ void lds_barrier() {
 //   LDS tile [64*TJ pixels][128 ch] fp16, 256-byte rows; the 16-byte chunk q (8 channels) of pixel row p lives at
 //   chunk q ^ (p & 15), and its two 8-byte quads are swapped when (p >> 4) & 1: the 32 lanes of a ds_write_b64
 //   (32 pixels, one channel quad) then hit 32 distinct 8-byte bank pairs.
-template <int TJ, class OffMap>
-__device__ __forceinline__ void epilogue_plain(const ConvArgs& a, f32x16_e (&acc)[2][TJ], char* lds, int tid, int ch0, OffMap offmap) {
+// MS = 16 (v_mfma_f32_16x16x32 accumulators: lane = pixel l & 15 of a 16-pixel tile, registers = 4 consecutive channels
+// 16*i + 4*(l >> 4) ..): the same LDS image is written from the other register layout — a lane's quad is channel quad
+// 4*i + (l >> 4) of the wave's 16, i.e. 16-byte chunk 2*i + (l >> 5), half (l >> 4) & 1; 32 lanes of a ds_write_b64 are
+// 16 pixels x 2 halves of one chunk column: 32 distinct 8-byte slots.
+template <int TJ, int MS, class ACC, class OffMap>
+__device__ __forceinline__ void epilogue_plain(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0, OffMap offmap) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int wc = wave >> 1, wp = wave & 1;
+    if constexpr (MS == 16) {
+        const int l16 = lane & 15, q4 = lane >> 4;
+        lds_barrier();   // the main loop is done with the LDS
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = ch0 + wc * 64 + 16 * i + 4 * q4;
+            f32x4_e sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+            if (a.scale) sc = *(const f32x4_e*)(a.scale + c4);
+            if (a.bias) bi = *(const f32x4_e*)(a.bias + c4);
+            sc *= a.out_mul;
+            const int cq = wc * 8 + 2 * i + (q4 >> 1);
+#pragma unroll
+            for (int j = 0; j < 2 * TJ; ++j) {
+                const int p = wp * (32 * TJ) + 16 * j + l16;
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][e] * sc[e] + bi[e];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    o[e] = (_Float16)v;
+                }
+                *(half4*)(lds + p * 256 + ((cq ^ l16) << 4) + (((q4 ^ j) & 1) << 3)) = o;   // (p >> 4) & 1 == j & 1: quads swapped
+            }
+        }
+    } else {
     // BN vectors of the 8 channel quads this lane holds (channel = ch0 + wc*64 + 32*i + 8*g4 + 4*hh), fetched one
     // quad ahead of their use: all eight at once would be 64 VGPRs on top of the 128 accumulators
     const int cl = ch0 + wc * 64 + 4 * hh;
@@ -188,6 +220,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, f32x16_e (&acc
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef BMI_EPI_BN
+    }
     lds_barrier();
     // phase 2: 64*TJ pixels x 16 chunks of 8 channels, 4*TJ per thread.  All LDS reads are issued before the first
     // store (the accumulators are dead: registers are free), rows beyond the tensor are only skipped at the store.
@@ -234,12 +267,13 @@ __device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px
 // offmap(p, off) -> bool: the same pixel's element offset in the output tensor (no division for linear tiles).
 // PLAIN (chosen per launch: no residual, no site) selects epilogue_plain at compile time: with both paths in one
 // kernel the register allocator spills 56-80 VGPRs in the other one.
-template <int TJ, bool PLAIN, class PixMap, class OffMap>
-__device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (&acc)[2][TJ], char* lds, int tid, int ch0,
+template <int TJ, bool PLAIN, int MS, class ACC, class PixMap, class OffMap>
+__device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
                                                    PixMap pixmap, OffMap offmap) {
     static_assert(TJ == 2 || TJ == 4, "two pixel tiles per round");
+    static_assert(MS == 32 || MS == 16, "MFMA shape");
     if constexpr (PLAIN) {
-        epilogue_plain<TJ>(a, acc, lds, tid, ch0, offmap);
+        epilogue_plain<TJ, MS>(a, acc, lds, tid, ch0, offmap);
         return;
     }
     constexpr int NR = TJ / 2;
@@ -275,6 +309,23 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
         lds_barrier();   // main loop (or previous round's phase 2) is done with the LDS
         // phase 1: raw fp32 accumulators into the swizzled LDS tile (BN is applied in phase 2, where
         // a thread owns the same 8 channels for all its rows, so the BN vectors are loaded once)
+        if constexpr (MS == 16) {
+            // 16x16x32 accumulators: a register quad IS 4 consecutive channels (16*i + 4*(lane >> 4) ..) of pixel lane & 15;
+            // 16 consecutive lanes = 16 pixels, one chunk column: 16 distinct 16-byte slots per ds_write_b128 group
+            const int l16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int pl = wp * 64 + jj * 16 + l16;   // pixel inside the round
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4_e v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * rr + jj][e];
+                    const int cq = wc * 16 + 4 * i + q4;
+                    *(f32x4_e*)(lds + pl * 512 + ((cq ^ (pl & 31)) << 4)) = v;
+                }
+            }
+        } else {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int pl = wp * 64 + jj * 32 + r;   // pixel inside the round
@@ -287,6 +338,7 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, f32x16_e (
                 const int cq = wc * 16 + 8 * i + 2 * g4 + hh;
                 *(f32x4_e*)(lds + pl * 512 + ((cq ^ (pl & 31)) << 4)) = v;
             }
+        }
         }
         if (rr + 1 < NR) { BMI_EPI_FETCH(rr + 1); }
         lds_barrier();

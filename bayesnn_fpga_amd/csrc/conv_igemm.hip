@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             off = (size_t)(pix0 + p) * a.Cout;
             return pix0 + p < a.M;
         };
-        epilogue_coalesced<TJ, PLAIN>(a, acc, smem, tid, ch0, pixmap, offmap);
+        epilogue_coalesced<TJ, PLAIN, 32>(a, acc, smem, tid, ch0, pixmap, offmap);
     } else {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {

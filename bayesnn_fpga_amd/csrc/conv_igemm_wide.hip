@@ -59,16 +59,47 @@ extern "C" int bmi_debug_wide_stamps_clear() {
 #define STAMP_T0(V)
 #endif
 
-#ifndef BMI_WIDE_PINGPONG
-#define BMI_WIDE_PINGPONG 1
-#endif
 #define WBC 256
 #define WBP 256
 #define WSTAGE ((WBC + WBP) * 128)
 
-template <bool PLAIN>
+// MS = MFMA shape (32: v_mfma_f32_32x32x16_f16, 16: v_mfma_f32_16x16x32_f16), same wave tile and LDS traffic either way;
+// chosen per launch (see conv3x3_patch.hip).
+#define WIDE_SHAPE_CONSTS                                                                              \
+    constexpr int TJ = 4;                                                                              \
+    constexpr int TI = MS == 32 ? 2 : 4, TP = MS == 32 ? 4 : 8, RW = MS;                               \
+    typedef float accv __attribute__((ext_vector_type(MS == 32 ? 16 : 4)));
+#define WIDE_MFMA(AF, BF, ACC)                                                                         \
+    if constexpr (MS == 32) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF, BF, ACC, 0, 0, 0);        \
+    else ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF, BF, ACC, 0, 0, 0);
+// One phase of the ping-pong loop: LOAD part (fragment reads of k-substep / pixel half KK of the K-step in stage ST, plus
+// this wave's share of the next K-step's DMA), barrier, MFMA part, barrier.  MS = 32: phase = one 16-deep k-substep,
+// 2 + 4 reads, 8 MFMAs of 32 cycles.  MS = 16: phase = one pixel half (4 of the 8 pixel tiles) of a 32-deep k-substep,
+// 4 (first half only: the channel fragments are kept for the second) + 4 reads, 16 MFMAs of 16 cycles.
+#define WIDE_PHASE_LOAD(KK, ST)                                                                        \
+    if constexpr (MS == 32) {                                                                          \
+        const int coff = ((2 * (KK) + kq) ^ sw_r) << 4;                                                \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = *(const half8*)((ST) + a_off + i * 32 * 128 + coff);  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)((ST) + b_off + j * 32 * 128 + coff);  \
+    } else {                                                                                           \
+        const int coff = ((4 * ((KK) >> 1) + kq) ^ sw_r) << 4;                                         \
+        if (((KK) & 1) == 0) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = *(const half8*)((ST) + a_off + i * 16 * 128 + coff); \
+        }                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)((ST) + b_off + (4 * ((KK) & 1) + j) * 16 * 128 + coff); \
+    }
+#define WIDE_PHASE_MFMA(KK)                                                                            \
+    if constexpr (MS == 32) {                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { WIDE_MFMA(af[i], bf[j], acc[i][j]); }      \
+    } else {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { WIDE_MFMA(af[i], bf[j], acc[i][4 * ((KK) & 1) + j]); } \
+    }
+
+template <bool PLAIN, int MS>
 __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
-    constexpr int TI = 2, TJ = 4;
+    WIDE_SHAPE_CONSTS
     __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE];
     static_assert(2 * WSTAGE == 2 * BMI_EPILOGUE_LDS_BYTES, "one epilogue staging area per channel half");
 
@@ -80,7 +111,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 #endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
+    const int r = lane & (RW - 1), kq = lane / RW;
     const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
 
     const int n_ctiles = a.Cout / WBC;
@@ -140,13 +171,13 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         for (int i = 0; i < 4; ++i) ISSUE_X(i, 0, 0, 0, st0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc[TI][TJ];
+    accv acc[TI][TP];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
+        for (int j = 0; j < TP; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < (MS == 32 ? 16 : 4); ++e) acc[i][j][e] = 0.f;
 
     const int a_off = (g * 128 + wc * 64 + r) * 128;
     const int b_off = WBC * 128 + (wp * 128 + r) * 128;
@@ -154,7 +185,6 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 
     const int nK = a.ksize * a.ksize * (a.Cin / 64);
     int ky = 0, kx = 0, c0 = 0;
-#if BMI_WIDE_PINGPONG
     // ---- ping-pong main loop ------------------------------------------------------------------------------------
     // A K-step is four phases (one 16-deep k-substep each); a phase is a LOAD part (6 ds_read_b128 of the substep's
     // fragments + this wave's share of the next K-step's LDS-DMA), a barrier, an MFMA part (8 MFMAs at raised
@@ -198,15 +228,11 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         const int koff = (ky * a.ksize + kx) * a.Cin + c0;
         char* nst = smem + (buf ^ 1) * WSTAGE;
         const char* st = smem + buf * WSTAGE;
+        half8 af[TI], bf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             // LOAD part
-            const int coff = ((2 * kk + hh) ^ sw_r) << 4;
-            half8 af[TI], bf[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(st + a_off + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(st + b_off + j * 32 * 128 + coff);
+            WIDE_PHASE_LOAD(kk, st);
             if (more && kk == dma_phase) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ISSUE_W(i, koff, nst);
@@ -220,11 +246,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
             // MFMA part
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            WIDE_PHASE_MFMA(kk);
             __builtin_amdgcn_s_setprio(0);
             if (kk == 3 && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // interval 8T+7 (group 0: MFMA part)
             RAW_BARRIER();
@@ -232,48 +254,6 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
     }
     if (g == 0) RAW_BARRIER();          // re-align the two groups before the epilogue reuses the LDS
 #undef RAW_BARRIER
-#else
-    for (int ks = 0; ks < nK; ++ks) {
-        const int buf = ks & 1;
-        STAMP_T0(tw0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP_ADD(4, tw0);
-        __syncthreads();   // this step's tiles have landed; every wave is done reading the other buffer
-        STAMP_ADD(5, tw0);
-        if (ks == 0) { STAMP(1); }
-        STAMP_T0(tw1);
-        // next K-step's (tap, chunk); after the last step the same tiles are fetched once more into the idle
-        // buffer (no branch in the MFMA stream; drained before the epilogue reuses the LDS)
-        if (ks + 1 < nK) {
-            c0 += 64;
-            if (c0 == a.Cin) {
-                c0 = 0;
-                if (++kx == a.ksize) { kx = 0; ++ky; }
-            }
-        }
-        const int koff = (ky * a.ksize + kx) * a.Cin + c0;
-        char* nst = smem + (buf ^ 1) * WSTAGE;
-        const char* st = smem + buf * WSTAGE;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int coff = ((2 * kk + hh) ^ sw_r) << 4;
-            half8 af[TI], bf[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(st + a_off + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(st + b_off + j * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[j], acc[0][j], 0, 0, 0);
-            ISSUE_W(kk, koff, nst);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[j], acc[1][j], 0, 0, 0);
-            ISSUE_X(kk, ky, kx, c0, nst);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        STAMP_ADD(6, tw1);
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ISSUE_W
 #undef ISSUE_X
@@ -301,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         off = (size_t)(pix0 + p) * b.Cout;
         return pix0 + p < a.M;
     };
-    epilogue_coalesced<TJ, PLAIN>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+    epilogue_coalesced<TJ, PLAIN, MS>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
     STAMP(3);
 #ifdef BMI_WIDE_STAMPS
     if (tid == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -318,8 +298,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 // load in the epilogue would make hipcc drain the LDS-DMA (vmcnt(0)) at its first use.
 #define WBN_MAX 1024
 
+template <int MS>
 __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArgs a, int n_tiles) {
-    constexpr int TI = 2, TJ = 4;
+    WIDE_SHAPE_CONSTS
     __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE + 2 * WBN_MAX * 4];
     float* const bn_scale = (float*)(smem + 2 * WSTAGE);
     float* const bn_bias = bn_scale + WBN_MAX;
@@ -327,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
+    const int r = lane & (RW - 1), kq = lane / RW;
     const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
     const int n_ctiles = a.Cout / WBC;
     const int n_ptiles = (a.M + WBP - 1) / WBP;
@@ -405,13 +386,13 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
     SETUP_TILE(vb);
     while (vb < n_tiles) {
         const int cur_ch0 = ch0, cur_pix0 = pix0;
-        f32x16 acc[TI][TJ];
+        accv acc[TI][TP];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
+            for (int j = 0; j < TP; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < (MS == 32 ? 16 : 4); ++e) acc[i][j][e] = 0.f;
 
         // ---- ping-pong main loop (see conv_igemm_wide_kernel for the interval / hazard table) ----
         int ky = 0, kx = 0, c0 = 0;
@@ -431,14 +412,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
             const int koff = (ky * a.ksize + kx) * a.Cin + c0;
             char* nst = smem + (buf ^ 1) * WSTAGE;
             const char* st = smem + buf * WSTAGE;
+            half8 af[TI], bf[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int coff = ((2 * kk + hh) ^ sw_r) << 4;
-                half8 af[TI], bf[TJ];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(st + a_off + i * 32 * 128 + coff);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[j] = *(const half8*)(st + b_off + j * 32 * 128 + coff);
+                WIDE_PHASE_LOAD(kk, st);
                 if (more && kk == dma_phase) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ISSUE_W(i, koff, nst);
@@ -451,11 +428,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
                 RAW_BARRIER();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                WIDE_PHASE_MFMA(kk);
                 __builtin_amdgcn_s_setprio(0);
                 if (kk == 3 && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 RAW_BARRIER();
@@ -478,11 +451,31 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
                 if (chl >= split) { outp = a.out_b; oc = a.Cout - split; chg = chl - split; }
                 else oc = split;
             }
-            const int hsw = hh ^ ((r >> 4) & 1);
             const int k = tl & 15;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 if (rr) lds_barrier();                      // round 0's reads are done
+                if constexpr (MS == 16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c4 = chl + wc * 64 + 16 * i + 4 * kq;
+                        const f32x4_e sc = *(const f32x4_e*)(bn_scale + c4), bi = *(const f32x4_e*)(bn_bias + c4);
+                        const int cq = wc * 8 + 2 * i + (kq >> 1);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int p = wp * 64 + jj * 16 + r;                     // pixel inside the round
+                            half4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[i][4 * rr + jj][e] * sc[e] + bi[e];
+                                if (a.relu) v = fmaxf(v, 0.f);
+                                o[e] = (_Float16)v;
+                            }
+                            *(half4*)(E + p * 256 + ((cq ^ r) << 4) + (((kq ^ jj) & 1) << 3)) = o;
+                        }
+                    }
+                } else {
+                const int hh = kq, hsw = hh ^ ((r >> 4) & 1);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int i = q >> 2, g4 = q & 3;
@@ -501,6 +494,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
                         }
                         *(half4*)(E + p * 256 + ((cq ^ (r & 15)) << 4) + hsw * 8) = o;
                     }
+                }
                 }
                 lds_barrier();
                 half8_e o8[8];
@@ -553,13 +547,21 @@ int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
         return cu;
     }();
-    if (persist && BMI_WIDE_PINGPONG && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks > 2L * n_cu) {
-        hipLaunchKernelGGL(conv_igemm_wide_persist_kernel, dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
+    const int shape = opt_mfma_shape_wide();
+    if (persist && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks > 2L * n_cu) {
+        if (shape == 16) hipLaunchKernelGGL(conv_igemm_wide_persist_kernel<16>, dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
+        else hipLaunchKernelGGL(conv_igemm_wide_persist_kernel<32>, dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
         BMI_CHECK_LAUNCH();
         return BMI_OK;
     }
-    if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL(conv_igemm_wide_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(conv_igemm_wide_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, s, a);
+    const dim3 grid((unsigned)blocks), block(512);
+    if (shape == 16) {
+        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16>), grid, block, 0, s, a);
+    } else {
+        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 32>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 32>), grid, block, 0, s, a);
+    }
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

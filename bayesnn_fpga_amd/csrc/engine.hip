@@ -17,6 +17,7 @@
 #include <new>
 #include <vector>
 
+#include "conv_epilogue.h"
 #include "kernels.h"
 
 namespace {
@@ -94,23 +95,14 @@ SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
 
 // Kernel selection for one conv launch: LDS-tile 3x3 patch kernel -> wide-tile per-tap implicit GEMM (Cout % 256 == 0)
 // -> per-tap implicit GEMM.
-// BMI_CONV_IMPL=igemm skips the patch kernel, BMI_CONV_IMPL=wreg tries the experimental
-// register-weight kernel first (it needs packed weights; same-box A/B: 12-20 % slower than the
-// patch kernel because the two pixel-waves of a workgroup each stream the same weights from L2).
+// BMI_CONV_IMPL=igemm skips the patch kernel (A/B, tests).
 int launch_conv(const ConvArgs& a, hipStream_t s, int* family) {
     int fam_dummy;
     if (!family) family = &fam_dummy;
     static const int mode = [] {
         const char* v = std::getenv("BMI_CONV_IMPL");
-        if (v && std::strcmp(v, "igemm") == 0) return 2;
-        if (v && std::strcmp(v, "wreg") == 0) return 0;
-        return 1;
+        return (v && std::strcmp(v, "igemm") == 0) ? 2 : 1;
     }();
-    if (mode == 0) {
-        *family = BMI_CONV_FAMILY_WREG;
-        const int rc = launch_conv3x3_wreg(a, s);
-        if (rc != BMI_ERR_UNSUPPORTED) return rc;
-    }
     if (mode <= 1) {
         *family = BMI_CONV_FAMILY_PATCH;
         const int rc = launch_conv3x3_patch(a, s);
@@ -135,9 +127,27 @@ static bool site_ok(const bmi_site& s) {
     }
 }
 
+static int shape_from_env(const char* primary, const char* fallback) {
+    const char* v = std::getenv(primary);
+    if (!v && fallback) v = std::getenv(fallback);
+    const int x = v ? std::atoi(v) : 0;
+    return x == 16 || x == 32 ? x : BMI_DEFAULT_MFMA_SHAPE;
+}
+int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nullptr); return v; }
+int& opt_mfma_shape_wide() { static int v = shape_from_env("BMI_MFMA_SHAPE_WIDE", "BMI_MFMA_SHAPE"); return v; }
+
 extern "C" {
 
 int bmi_version(void) { return BMI_VERSION; }
+
+int bmi_set_option(const char* name, int32_t value) {
+    if (!name) return BMI_ERR_INVALID;
+    const bool patch = std::strcmp(name, "mfma_shape_patch") == 0, wide = std::strcmp(name, "mfma_shape_wide") == 0;
+    if (!patch && !wide) return BMI_ERR_INVALID;
+    if (value != 0 && value != 16 && value != 32) return BMI_ERR_INVALID;
+    (patch ? opt_mfma_shape_patch() : opt_mfma_shape_wide()) = value ? value : BMI_DEFAULT_MFMA_SHAPE;
+    return BMI_OK;
+}
 
 const char* bmi_error_string(int code) {
     switch (code) {
@@ -289,7 +299,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 }
                 const TensorInfo& to = e->tensors[d.out];
                 if (tin.h != 1 || tin.w != 1 || to.h != 1 || to.w != 1) { rc = BMI_ERR_INVALID; break; }
-                if (tin.c % 16 != 0 || to.c % 128 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                if (tin.c % 16 != 0 || to.c % 64 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
                 op.d.residual = -1; op.d.in2 = -1;
                 // a site makes the layer per-sample even on a deterministic input (the layer is tiny: no conv + MASK split)
                 op.stoch = in_st || d.site.kind != BMI_SITE_NONE;
@@ -522,7 +532,6 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             std::memset(&a, 0, sizeof(a));
             a.in = (const _Float16*)(ws + tin.offset);
             a.wgt = (const _Float16*)d.weight;
-            a.wpk = (const _Float16*)d.weight_packed;
             a.scale = d.scale; a.bias = d.bias;
             a.out = (_Float16*)(ws + e->tensors[d.out].offset);
             a.N = N;
@@ -698,11 +707,6 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
                             (hipStream_t)stream);
 }
 
-int bmi_pack_conv3x3_weights(const void* weight, void* packed, int32_t cout, int32_t cin, bmi_stream stream) {
-    if (!weight || !packed) return BMI_ERR_INVALID;
-    return launch_pack_conv3x3_weights((const _Float16*)weight, (_Float16*)packed, cout, cin, (hipStream_t)stream);
-}
-
 int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* site, int32_t batch, int32_t t0,
                   uint64_t seed, bmi_stream stream) {
     if (!bits || !site || !site_ok(*site)) return BMI_ERR_INVALID;
@@ -710,7 +714,7 @@ int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* 
 }
 
 int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, const void* weight,
-                       const void* weight_packed, const float* scale, const float* bias, const void* res, void* out,
+                       const float* scale, const float* bias, const void* res, void* out,
                        int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin, int32_t cout,
                        int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
@@ -718,7 +722,7 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.wpk = (const _Float16*)weight_packed; a.scale = scale; a.bias = bias;
+    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.scale = scale; a.bias = bias;
     a.res = (const _Float16*)res; a.out = (_Float16*)out;
     a.N = n; a.in_mod = in_mod; a.res_mod = res_mod;
     a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;

@@ -9,7 +9,6 @@
 struct ConvArgs {
     const _Float16* in;
     const _Float16* wgt;  // [Cout][k*k*Cin]
-    const _Float16* wpk;  // same weights in MFMA A-fragment order (conv3x3_wreg.hip), or null
     const float* scale;   // may be null
     const float* bias;    // may be null
     const _Float16* res;  // may be null
@@ -60,8 +59,6 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s);  // 256x256 tiles; BMI_ERR_UNSUPPORTED -> conv_igemm
 bool conv_takes_wide_kernel(int cin, int cout);
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
-int launch_conv3x3_wreg(const ConvArgs& a, hipStream_t s);    // needs a.wpk; BMI_ERR_UNSUPPORTED -> next kernel
-int launch_pack_conv3x3_weights(const _Float16* w, _Float16* out, int cout, int cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, hipStream_t s, int* family = nullptr);   // picks the kernel; *family = BMI_CONV_FAMILY_*
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s);
@@ -81,6 +78,10 @@ int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, 
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
 int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s);
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);
+
+// process-wide kernel-selection switches (bmi_set_option); 16 or 32
+int& opt_mfma_shape_patch();
+int& opt_mfma_shape_wide();
 
 SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0);
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void linear_softmax_kernel(const float* __restr
 // models.py:262-281), kept in fp32 end to end: out[n][c] = relu?(in[n % in_mod] . W[c] + bias[c]) (site).
 // With fp16 outputs (the layer as a 1x1 conv) two more roundings land on logits of magnitude ~10 and the predictive mean
 // misses the 1e-3 bar at B = 250 (measured 1.3e-3); the layer is 0.1 % of the FLOPs, so it runs on the exact-f32 MFMA
-// like the classifier above.  One wave = 32 samples x 128 output features; the input is fp16 (a conv / pool / mask
+// like the classifier above.  One wave = 32 samples x 64 output features; the input is fp16 (a conv / pool / mask
 // output) or fp32 (a previous dense layer).
 typedef _Float16 half8_d __attribute__((ext_vector_type(8)));
 
@@ -101,49 +101,61 @@ template <typename TIN>
 __global__ __launch_bounds__(64) void dense_f32_kernel(const TIN* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
                                                        int in_mod, int K, int Cout, int relu, SiteArgs site, int B, int t0) {
+    constexpr int RT = 2;                       // 64 output features per wave: two waves per SIMD at N = 7500, Cout = 512
     const int lane = threadIdx.x;
     const int r = lane & 31, hh = lane >> 5;
     const int n = blockIdx.x * 32 + r;
     const bool valid = n < N;
-    const int c0 = blockIdx.y * 128;
+    const int c0 = blockIdx.y * (32 * RT);
     const int kh = K >> 1;
     const TIN* ip = in + (size_t)(valid ? n % in_mod : 0) * K + hh * kh;
     const float* wp = w + (size_t)(c0 + r) * K + hh * kh;
 
-    f32x16 acc[4];
+    f32x16 acc[RT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    for (int s = 0; s < kh; s += 8) {
-        float b[8];
-        if constexpr (sizeof(TIN) == 2) {
-            const half8_d h = *(const half8_d*)(ip + s);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) b[e] = (float)h[e];
-        } else {
-            const float4 b0 = *(const float4*)(ip + s), b1 = *(const float4*)(ip + s + 4);
-            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
-        }
-        if (!valid) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) b[e] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 a0 = *(const float4*)(wp + (size_t)(32 * i) * K + s), a1 = *(const float4*)(wp + (size_t)(32 * i) * K + s + 4);
-            const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[i], 0, 0, 0);
-        }
+    // operands of step s+8 are requested before the 16 MFMAs (1024 cycles) of step s
+    float b[8], a[RT][8];
+#define DENSE_LOAD(S)                                                                                                  \
+    {                                                                                                                  \
+        if constexpr (sizeof(TIN) == 2) {                                                                              \
+            const half8_d h_ = *(const half8_d*)(ip + (S));                                                            \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) b[e] = (float)h_[e];                                         \
+        } else {                                                                                                       \
+            const float4 b0_ = *(const float4*)(ip + (S)), b1_ = *(const float4*)(ip + (S) + 4);                       \
+            b[0] = b0_.x; b[1] = b0_.y; b[2] = b0_.z; b[3] = b0_.w; b[4] = b1_.x; b[5] = b1_.y; b[6] = b1_.z; b[7] = b1_.w; \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < RT; ++i) {                                                               \
+            const float4 a0_ = *(const float4*)(wp + (size_t)(32 * i) * K + (S)), a1_ = *(const float4*)(wp + (size_t)(32 * i) * K + (S) + 4); \
+            a[i][0] = a0_.x; a[i][1] = a0_.y; a[i][2] = a0_.z; a[i][3] = a0_.w;                                        \
+            a[i][4] = a1_.x; a[i][5] = a1_.y; a[i][6] = a1_.z; a[i][7] = a1_.w;                                        \
+        }                                                                                                              \
     }
+    DENSE_LOAD(0);
+    for (int s = 0; s < kh; s += 8) {
+        float bc[8], ac[RT][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bc[e] = valid ? b[e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) ac[i][e] = a[i][e];
+        }
+        if (s + 8 < kh) DENSE_LOAD(s + 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][e], bc[e], acc[i], 0, 0, 0);
+    }
+#undef DENSE_LOAD
     if (!valid) return;
     const int tl = n / B, bimg = n - tl * B;
     const uint32_t t = (uint32_t)(t0 + tl);
     const float* mrow = site.kind == BMI_SITE_MASKSEMBLE ? site.masks + (size_t)((site.cnt0 + (int)t) % site.num_masks) * Cout : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = c0 + 32 * i + 8 * q + 4 * hh;      // 4 consecutive output features: registers 4q .. 4q+3
@@ -170,8 +182,8 @@ __global__ __launch_bounds__(64) void dense_f32_kernel(const TIN* __restrict__ i
 int launch_dense_f32(const void* in, int in_is_f32, const float* w, const float* bias, float* out, int n, int in_mod, int k,
                      int cout, int relu, const SiteArgs& site, int batch, int t0, hipStream_t s) {
     if (n <= 0 || in_mod <= 0 || batch <= 0) return BMI_ERR_INVALID;
-    if (k % 16 != 0 || cout % 128 != 0) return BMI_ERR_UNSUPPORTED;
-    const dim3 grid((n + 31) / 32, cout / 128), block(64);
+    if (k % 16 != 0 || cout % 64 != 0) return BMI_ERR_UNSUPPORTED;
+    const dim3 grid((n + 31) / 32, cout / 64), block(64);
     if (in_is_f32) hipLaunchKernelGGL(dense_f32_kernel<float>, grid, block, 0, s, (const float*)in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
     else hipLaunchKernelGGL(dense_f32_kernel<_Float16>, grid, block, 0, s, (const _Float16*)in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
     BMI_CHECK_LAUNCH();

@@ -104,18 +104,8 @@ class GraphBuilder:
             scale = None
             in2 = x2
         wdev = self.dev(wk, torch.float32 if stem else torch.float16)
-        packed = None
-        if (not stem and k == 3 and p == 1 and cin % 64 == 0 and conv.out_channels % 128 == 0
-                and torch.device(self.device).type == "cuda" and os.environ.get("BMI_CONV_IMPL") == "wreg"):
-            # one-off re-layout into MFMA fragment order for the register-weight kernel
-            packed = torch.empty_like(wdev)
-            self.keep.append(packed)
-            with torch.cuda.device(self.device):
-                st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-                _lib.check(_lib.lib().bmi_pack_conv3x3_weights(wdev.data_ptr(), packed.data_ptr(), conv.out_channels, cin, st),
-                           "bmi_pack_conv3x3_weights")
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
-                             stride=s, pad=p, relu=int(relu), weight=wdev, weight_packed=packed, in2=in2, weight2=w2dev,
+                             stride=s, pad=p, relu=int(relu), weight=wdev, in2=in2, weight2=w2dev,
                              scale=self.dev(scale, torch.float32) if scale is not None else None,
                              bias=self.dev(bias, torch.float32), site=site,
                              bias_post=self.dev(bias_post, torch.float32) if bias_post is not None else None,
@@ -278,7 +268,7 @@ class CompiledGraph:
             d.ksize, d.stride, d.pad, d.relu = op.get("ksize", 0), op.get("stride", 0), op.get("pad", 0), op.get("relu", 0)
             d.in2 = op.get("in2", -1)
             d.site_pos = op.get("site_pos", _lib.SITE_POS_OUTER)
-            for f in ("weight", "weight2", "weight_packed", "scale", "bias", "bias_post"):
+            for f in ("weight", "weight2", "scale", "bias", "bias_post"):
                 t = op.get(f)
                 setattr(d, f, t.data_ptr() if t is not None else None)
             s = op.get("site")
@@ -400,8 +390,8 @@ class MCDEngine(CompiledGraph):
         n = (C.c_int64 * _lib.PROFILE_SLOTS)()
         _lib.check(self.lib.bmi_profile_read(self.handle, ms, n), "bmi_profile_read")
         out = {_lib.PROFILE_NAMES.get(i, str(i)): (ms[i], n[i]) for i in range(_lib.PROFILE_SLOTS) if n[i]}
-        fms, fn, ffl = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)()
+        fms, fn, ffl = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
         _lib.check(self.lib.bmi_profile_conv_families(self.handle, fms, fn, ffl), "bmi_profile_conv_families")
-        names = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_wreg_kernel")
-        self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i]) for i in range(4) if fn[i]}
+        names = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel")
+        self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i]) for i in range(3) if fn[i]}
         return out

@@ -22,7 +22,6 @@
  *                              the counter-based Philox convention of csrc/philox.h
  *   bmi_stem_conv_fwd, bmi_conv_igemm_fwd   conv+BN(+residual)(+ReLU) of BasicBlock.forward
  *                              (resnet18.py:32-48) and of the exit heads (:306-308,:318-319,:329)
- *   bmi_pack_conv3x3_weights   (no reference counterpart: one-off re-layout of conv weights at load time)
  *   bmi_mask_apply, bmi_mask_bits   MCDropout / Masksembles2D on a stage output (:278-280)
  *   bmi_pool_mask              F.avg_pool2d(F.relu(.),4) + flatten + exit dropout (:309-313)
  *   bmi_linear_softmax         ex{1,2,3}linear / linear (:314,:325,:335,:344) + softmax
@@ -50,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BMI_VERSION 100
+#define BMI_VERSION 200
 
 #define BMI_OK 0
 #define BMI_ERR_INVALID (-22)      /* EINVAL: bad descriptor / argument            */
@@ -106,8 +105,6 @@ typedef struct bmi_op_desc {
     const void* weight;  /* device; CONV fp16 [Cout][k][k][Cin]; STEM fp32 [Cout][k][k][Cin];
                             HEAD fp32 [ceil32(out_dim)][Cin]; DENSE fp32 [Cout][Cin]   */
     const void* weight2;       /* CONV with in2: device fp16 [Cout][Cin2] (BN scale folded in)          */
-    const void* weight_packed; /* CONV 3x3: the same weights repacked by bmi_pack_conv3x3_weights
-                                  (MFMA fragment order), or NULL to run the LDS-tile kernels */
     const float* scale;  /* device fp32 [Cout] folded BN scale (NULL = 1)              */
     const float* bias;   /* device fp32 [Cout] folded BN bias / Linear bias            */
     bmi_site site;       /* CONV/STEM/MASK: applied to the op's output; HEAD: applied to
@@ -138,6 +135,14 @@ typedef struct bmi_model_desc {
 
 int bmi_version(void);
 const char* bmi_error_string(int code);
+
+/* Process-wide kernel-selection switches (speed only, never results beyond fp32 summation order inside one MFMA tile;
+ * used for same-process A/B measurement and by the tests to cover both code paths).  Returns BMI_ERR_INVALID for an
+ * unknown name / value.  Names:
+ *   "mfma_shape_patch", "mfma_shape_wide"   16 | 32: MFMA instruction shape of conv3x3_patch / conv_igemm_wide
+ *                                           (v_mfma_f32_16x16x32_f16 | v_mfma_f32_32x32x16_f16); 0 = built-in default
+ * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE). */
+int bmi_set_option(const char* name, int32_t value);
 
 /* Host-only: validates and copies the graph, marks which tensors are stochastic, splits a
  * conv that carries a site but has only deterministic inputs into conv + MASK (so the
@@ -172,8 +177,7 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
 #define BMI_CONV_FAMILY_PATCH 0 /* conv3x3_patch_kernel  */
 #define BMI_CONV_FAMILY_WIDE 1  /* conv_igemm_wide_kernel */
 #define BMI_CONV_FAMILY_IGEMM 2 /* conv_igemm_kernel */
-#define BMI_CONV_FAMILY_WREG 3  /* conv3x3_wreg_kernel (experimental) */
-#define BMI_CONV_FAMILIES 4
+#define BMI_CONV_FAMILIES 3
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
                               double flops[BMI_CONV_FAMILIES]);
 
@@ -188,10 +192,6 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
 
 /* out[n] = conv(in[n % in_mod]) * scale + bias (+ res[n % res_mod]) (ReLU) (site); `batch` is
  * the per-sample image count B used by the site's element index (n = t_local*B + b). */
-/* fp16 [Cout][3][3][Cin] -> the fragment-ordered copy the register-weight 3x3 kernel streams
- * (Cout % 128 == 0, Cin % 64 == 0; same byte size). */
-int bmi_pack_conv3x3_weights(const void* weight, void* packed, int32_t cout, int32_t cin, bmi_stream stream);
-
 /* keep bits (1 bit per element, byte g = elements 8g..8g+7) of an elementwise site for the folded batch
  * n = samples*batch images of hw pixels x c channels */
 int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* site, int32_t batch, int32_t t0,
@@ -200,7 +200,7 @@ int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* 
 /* in_keep_bits (or NULL): input-side MC-dropout — image n reads in[n % in_mod] with the dropped elements of
  * folded image n zeroed while staging; out_mul multiplies the BN scale (pass 1/(1-p) then, else 1). */
 int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, const void* weight,
-                       const void* weight_packed, const float* scale, const float* bias, const void* res, void* out,
+                       const float* scale, const float* bias, const void* res, void* out,
                        int32_t n, int32_t in_mod, int32_t res_mod, int32_t h, int32_t w, int32_t cin, int32_t cout,
                        int32_t ksize, int32_t stride, int32_t pad, int32_t relu, const bmi_site* site,
                        int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
@@ -240,7 +240,7 @@ int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const fl
 
 /* Hidden dense layer in fp32 (BMI_OP_DENSE): out[n][c] = relu?(in[n % in_mod] . weight[c] + bias[c]) (site on the
  * [batch, cout] tensor, sample index n / batch + t0).  `in` is fp16 (in_is_f32 = 0) or fp32 [.][k]; weight fp32 [cout][k];
- * k % 16 == 0, cout % 128 == 0.  Replaces the Dense 512 layers of the VGG-11 classifier stack
+ * k % 16 == 0, cout % 64 == 0.  Replaces the Dense 512 layers of the VGG-11 classifier stack
  * (Hardware_Artifact/bayes_hw/models/models.py:262-281) with their dropout (:268-281). */
 int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const float* bias, float* out, int32_t n,
                   int32_t in_mod, int32_t k, int32_t cout, int32_t relu, const bmi_site* site, int32_t batch, int32_t t0,

@@ -74,11 +74,7 @@ def run_conv(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod, site
     out = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.float16, device=DEV)
     keep = []
     s = site_struct(site, keep)
-    wp = None
-    if k == 3 and pad == 1 and cin % 64 == 0 and cout % 128 == 0:      # only used under BMI_CONV_IMPL=wreg
-        wp = torch.empty_like(w)
-        _lib.check(lib.bmi_pack_conv3x3_weights(ptr(w), ptr(wp), cout, cin, stream()), "bmi_pack_conv3x3_weights")
-    rc = lib.bmi_conv_igemm_fwd(ptr(x), ptr(in_bits), float(out_mul), ptr(w), ptr(wp), ptr(scale), ptr(bias), ptr(res), ptr(out), n, in_mod, res_mod, H, W, cin,
+    rc = lib.bmi_conv_igemm_fwd(ptr(x), ptr(in_bits), float(out_mul), ptr(w), ptr(scale), ptr(bias), ptr(res), ptr(out), n, in_mod, res_mod, H, W, cin,
                                 cout, k, stride, pad, int(relu), C.byref(s) if s is not None else None,
                                 batch if batch is not None else n, t0, seed, cnt0, stream())
     _lib.check(rc, "bmi_conv_igemm_fwd")

@@ -18,6 +18,23 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def pytest_generate_tests(metafunc):
+    """Every conv test runs under both MFMA instruction shapes (v_mfma_f32_32x32x16_f16 / 16x16x32_f16: different
+    accumulator layouts, hence different main-loop addressing and epilogue code in conv3x3_patch / conv_igemm_wide)."""
+    if metafunc.function.__name__.startswith("test_conv"):
+        metafunc.fixturenames.append("mfma_shape")
+        metafunc.parametrize("mfma_shape", [32, 16], indirect=True, ids=["mfma32", "mfma16"])
+
+
+@pytest.fixture
+def mfma_shape(request):
+    for k in ("mfma_shape_patch", "mfma_shape_wide"):
+        _lib.set_option(k, request.param)
+    yield request.param
+    for k in ("mfma_shape_patch", "mfma_shape_wide"):
+        _lib.set_option(k, 0)
+
+
 @pytest.mark.parametrize("seed,site,t,p,n", [(42, 0, 0, 0.25, 4096), (7, 3, 99, 0.5, 1003), ((1 << 40) + 5, 6, 5, 0.125, 64),
                                               (1, 1, 1, 0.0, 16), (1, 1, 1, 1.0, 16), (3, 2, 17, 0.2, 777)])
 def test_philox_mask_bit_exact(seed, site, t, p, n):
@@ -109,7 +126,7 @@ def test_conv_rejects_unsupported_shapes():
     x = torch.zeros(1, 8, 8, 48, dtype=torch.float16, device=DEV)
     w = torch.zeros(64, 3, 3, 48, dtype=torch.float16, device=DEV)
     o = torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=DEV)
-    rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), None, 1.0, gh.ptr(w), None, None, None, None, gh.ptr(o), 1, 1, 1, 8, 8, 48, 64, 3, 1, 1, 0, None, 1,
+    rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), None, 1.0, gh.ptr(w), None, None, None, gh.ptr(o), 1, 1, 1, 8, 8, 48, 64, 3, 1, 1, 0, None, 1,
                                 0, 0, 0, gh.stream())
     assert rc == -95
 

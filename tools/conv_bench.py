@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--images", type=int, default=1000)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--rounds", type=int, default=1, help="timed rounds per variant (interleaved)")
+    ap.add_argument("--ab", default="", help="comma list of option sets for a same-process A/B, e.g. "
+                                             "mfma_shape_patch=32+mfma_shape_wide=32,mfma_shape_patch=16+mfma_shape_wide=16")
     ap.add_argument("--site", action="store_true", help="fuse an elementwise MC-dropout site into the epilogue")
     ap.add_argument("--nores", action="store_true")
     ap.add_argument("--noscale", action="store_true")
@@ -56,31 +59,43 @@ def main():
         bias = (0.1 * torch.randn(cout, generator=g)).to(dev)
         res = torch.randn(n, ho, ho, cout, generator=g).to(torch.float16).to(dev)
         out = torch.empty(n, ho, ho, cout, dtype=torch.float16, device=dev)
-        wp = None
-        if k == 3 and p == 1 and cin % 64 == 0 and cout % 128 == 0:
-            wp = torch.empty_like(w)
-            _lib.check(lib.bmi_pack_conv3x3_weights(w.data_ptr(), wp.data_ptr(), cout, cin, st), "pack")
         site = _lib.make_site(_lib.SITE_ELEMENTWISE, 2, 0.25) if a.site else None
 
         def run():
-            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), wp.data_ptr() if wp is not None else None, None if a.noscale else scale.data_ptr(),
+            rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), None if a.noscale else scale.data_ptr(),
                                         None if a.noscale else bias.data_ptr(), None if a.nores else res.data_ptr(),
                                         out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1,
                                         C.byref(site) if site is not None else None, 250, 0, 42, 0, st)
             _lib.check(rc, "bmi_conv_igemm_fwd")
-        for _ in range(3):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.iters
         flops = 2.0 * n * ho * ho * cout * k * k * cin
-        total_t += ms
+        variants = [v for v in a.ab.split(",") if v] or [""]      # e.g. mfma_shape_patch=32,mfma_shape_patch=16
+        times = {v: [] for v in variants}
+
+        def select(v):
+            for kv in (v.split("+") if v else []):
+                nm, _, val = kv.partition("=")
+                _lib.set_option(nm, int(val))
+        for v in variants:
+            select(v)
+            for _ in range(3):
+                run()
+        for _ in range(a.rounds):                       # interleaved rounds in ONE process: variance is correlated
+            for v in variants:
+                select(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / a.iters)
+        for v in variants:
+            t = sorted(times[v])
+            ms = t[len(t) // 2]
+            print(f"{name} {v or 'default':28s}: median {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s   min {t[0] * 1e3:8.1f} us "
+                  f"{flops / t[0] / 1e9:7.1f} TFLOP/s   (M={n * ho * ho}, N={cout}, K={k * k * cin})", flush=True)
+        total_t += sorted(times[variants[0]])[len(times[variants[0]]) // 2]
         total_f += flops
-        print(f"{name}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s   (M={n * ho * ho}, N={cout}, K={k * k * cin})", flush=True)
     print(f"all: {total_f / total_t / 1e9:7.1f} TFLOP/s")
 
 

@@ -42,7 +42,7 @@ def main():
 
     def run(c):
         x, w, sc, bi, out, (n, H, cin, cout, k, s, p) = c
-        _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), None, sc.data_ptr(), bi.data_ptr(), None, out.data_ptr(),
+        _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), sc.data_ptr(), bi.data_ptr(), None, out.data_ptr(),
                                           n, n, n, H, H, cin, cout, k, s, p, 1, None, n, 0, 1, 0, st), "conv")
     first = []
     for c in cases:

@@ -16,7 +16,7 @@ x = torch.randn(n, H, H, cin, generator=g).half().to(dev); w = (torch.randn(cout
 sc = torch.ones(cout, device=dev); bi = torch.zeros(cout, device=dev)
 out = torch.empty(n, ho, ho, cout, dtype=torch.float16, device=dev); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def run():
-    _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), None, sc.data_ptr(), bi.data_ptr(), None, out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1, None, 250, 0, 42, 0, st), "conv")
+    _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), sc.data_ptr(), bi.data_ptr(), None, out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1, None, 250, 0, 42, 0, st), "conv")
 for _ in range(5): run()
 torch.cuda.synchronize()
 l = C.CDLL(_lib.LIB_PATH)
