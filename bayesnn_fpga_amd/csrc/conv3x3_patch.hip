@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     const int n_ctiles = a.Cout / BC;
     const int tiles_x = a.Wo / TW, tiles_y = a.Ho / TH;
     int bid, ctile;
-    xcd_tile_map(blockIdx.x, (int)(gridDim.x / n_ctiles), n_ctiles, bid, ctile);
+    xcd_tile_map(blockIdx.x, (int)(gridDim.x / n_ctiles), n_ctiles, bid, ctile, a.xcd_split);
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int n0 = (bid / tiles_y) * IMGS;
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 }
 
 template <int TH, int TW, int IMGS, int TJ>
-static int launch_patch(const ConvArgs& a, hipStream_t s) {
+static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    a.xcd_split = xcd_split_for(a.Cout / 128, (size_t)a.Cout * 9 * a.Cin * 2);
     const long tiles = (long)((a.N + IMGS - 1) / IMGS) * (a.Ho / TH) * (a.Wo / TW) * (a.Cout / 128);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const bool plain = conv_epilogue_is_plain(a);

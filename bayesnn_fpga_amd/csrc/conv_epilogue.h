@@ -14,13 +14,24 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // (measured: FETCH_SIZE 3.3-3.8x the algorithmic input bytes at Cout = 512).  Within a group of
 // 8 * n_ct consecutive blocks, block j takes pixel tile (j % 8) of the group and channel tile j / 8.
 // Placement only changes speed, never results; the tail group falls back to the plain order.
-__device__ __forceinline__ void xcd_tile_map(int bid, int n_pt, int n_ct, int& ptile, int& ctile) {
+//
+// `cs` (1, 2 or 4; n_ct % cs == 0) splits the channel tiles into cs classes and gives each class its own XCDs: XCD x only
+// ever streams the weights of class x % cs.  With cs = 1 every XCD streams ALL the weights of the conv; at 512 -> 512
+// channels that is 4.7 MB of fp16 through a 4 MB L2 in a cyclic pattern, and the workgroups re-fetch their 1.18 MB
+// slices from beyond L2 (measured round 1: FETCH_SIZE 2.7 GB per launch against 0.82 GB algorithmic on the 4x4-map
+// convs).  With cs = 2 an XCD's weights are 2.4 MB (resident) and a pixel tile's input is fetched by two XCDs instead
+// of one (the second fetch is a hit in the memory-side cache).  The launcher picks cs from the weight bytes.
+__device__ __forceinline__ void xcd_tile_map(int bid, int n_pt, int n_ct, int& ptile, int& ctile, int cs = 1) {
     const int group = 8 * n_ct;
     const int full = (n_pt / 8) * group;
     if (bid < full) {
         const int g = bid / group, j = bid - g * group;
-        ptile = g * 8 + (j & 7);
-        ctile = j >> 3;
+        const int x = j & 7, s = j >> 3;          // XCD, position in the XCD's share of the group
+        const int cpc = n_ct / cs;                // channel tiles per class
+        const int cls = x % cs, xg = x / cs;
+        const int sc = s % cpc, sp = s / cpc;
+        ptile = g * 8 + xg * cs + sp;
+        ctile = cls * cpc + sc;
     } else {
         const int t = bid - full;
         ptile = (n_pt / 8) * 8 + t / n_ct;

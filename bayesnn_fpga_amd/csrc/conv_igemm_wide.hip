@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 
     const int n_ctiles = a.Cout / WBC;
     int ptile, ctile;
-    xcd_tile_map(blockIdx.x, (a.M + WBP - 1) / WBP, n_ctiles, ptile, ctile);
+    xcd_tile_map(blockIdx.x, (a.M + WBP - 1) / WBP, n_ctiles, ptile, ctile, a.xcd_split);
     const int ch0 = ctile * WBC;
     const int pix0 = ptile * WBP;
     const int HoWo = a.Ho * a.Wo;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
 #define SETUP_TILE(VB)                                                                                 \
     {                                                                                                  \
         int ptile_, ctile_;                                                                            \
-        xcd_tile_map((VB), n_ptiles, n_ctiles, ptile_, ctile_);                                        \
+        xcd_tile_map((VB), n_ptiles, n_ctiles, ptile_, ctile_, a.xcd_split);                           \
         ch0 = ctile_ * WBC;                                                                            \
         pix0 = ptile_ * WBP;                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
@@ -528,7 +528,9 @@ bool conv_takes_wide_kernel(int cin, int cout) {
     return on && cin % 64 == 0 && cout % WBC == 0;
 }
 
-int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s) {
+int launch_conv_igemm_wide(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    a.xcd_split = xcd_split_for(a.Cout / WBC, (size_t)a.Cout * a.ksize * a.ksize * a.Cin * 2);
     if (!conv_takes_wide_kernel(a.Cin, a.Cout) || a.in2 || a.in_bits) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
     if (a.wgt_b) {

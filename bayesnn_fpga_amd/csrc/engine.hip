@@ -134,6 +134,17 @@ static int shape_from_env(const char* primary, const char* fallback) {
     return x == 16 || x == 32 ? x : BMI_DEFAULT_MFMA_SHAPE;
 }
 int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nullptr); return v; }
+int& opt_xcd_split() {
+    static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
+    return v;
+}
+// Channel-tile classes for xcd_tile_map: keep the weights one XCD streams under ~2.5 MB of its 4 MB L2.
+int xcd_split_for(int n_ctiles, size_t weight_bytes) {
+    int cs = opt_xcd_split();
+    if (cs == 0) cs = weight_bytes > (8u << 20) ? 4 : (weight_bytes > (3u << 20) ? 2 : 1);
+    while (cs > 1 && n_ctiles % cs != 0) cs >>= 1;
+    return cs;
+}
 int& opt_mfma_shape_wide() { static int v = shape_from_env("BMI_MFMA_SHAPE_WIDE", "BMI_MFMA_SHAPE"); return v; }
 
 extern "C" {
@@ -142,6 +153,11 @@ int bmi_version(void) { return BMI_VERSION; }
 
 int bmi_set_option(const char* name, int32_t value) {
     if (!name) return BMI_ERR_INVALID;
+    if (std::strcmp(name, "xcd_split") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return BMI_ERR_INVALID;
+        opt_xcd_split() = value;
+        return BMI_OK;
+    }
     const bool patch = std::strcmp(name, "mfma_shape_patch") == 0, wide = std::strcmp(name, "mfma_shape_wide") == 0;
     if (!patch && !wide) return BMI_ERR_INVALID;
     if (value != 0 && value != 16 && value != 32) return BMI_ERR_INVALID;

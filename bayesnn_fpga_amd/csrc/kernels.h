@@ -41,6 +41,7 @@ struct ConvArgs {
     int M;         // N * Ho * Wo
     int B;         // images per Monte-Carlo sample
     int t0;        // first sample index of this launch
+    int xcd_split; // channel-tile classes of the XCD-aware tile order (xcd_tile_map's cs); set by the launcher
     SiteArgs site;
 };
 
@@ -82,6 +83,8 @@ bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, 
 // process-wide kernel-selection switches (bmi_set_option); 16 or 32
 int& opt_mfma_shape_patch();
 int& opt_mfma_shape_wide();
+int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
+int xcd_split_for(int n_ctiles, size_t weight_bytes);
 
 SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0);
 

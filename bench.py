@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="dry run of the N>1 code path on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-T", type=int, default=10, help="MC passes of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-1t-images", type=int, default=16, help="images of the 1-thread CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dump-mean", default="", help="rank 0 writes the final predictive mean [E,B,C] float64 to this .npy (tests)")
     return ap.parse_args()
 
 
@@ -113,6 +115,39 @@ def pmc_sq(workload, family):
         return {}
     return {"mfma_busy_share_pmc": round(sum(v["sq"]["mfma_busy_share"] * v["launches"] for v in ks) / n, 4),
             "effective_clock_ghz_pmc": round(sum(v["sq"]["effective_clock_ghz"] * v["launches"] for v in ks) / n, 3)}
+
+
+def physical_cores():
+    """Physical cores of this host (unique (package, core) pairs of /proc/cpuinfo); None when it cannot be told."""
+    try:
+        ids, phys = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                ids.add((phys, ln.split(":")[1].strip()))
+        return len(ids) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline_1thread(wl, images, T, seed):
+    """The same oracle loop on ONE thread (SURVEY §8.4 asks for the 1-thread figure next to the all-cores one), on a
+    smaller bounded sample (``images`` images x T passes)."""
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
+    from oracle import mcd
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        m = synthetic_weights_(_load(wl[1])(**wl[2]), 0)
+        x = synthetic_images(images, seed=1234)
+        t0 = time.perf_counter()
+        mcd.mcd_predict(m, x, T, seed)
+        return images * T / (time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(n)
 
 
 def cpu_baseline(wl, batch, T, seed):
@@ -157,7 +192,7 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
-    from bayesnn_fpga_amd.sharding import shard_range
+    from bayesnn_fpga_amd.sharding import accumulate_sharded, shard_range
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
     from bayesnn_fpga_amd.train.metrics import ece_hist_binary
 
@@ -174,10 +209,9 @@ def main():
 
     def step():
         S.zero_()
-        if t_hi > t_lo:
-            eng.accumulate(x, S, t_lo, t_hi - t_lo, a.seed)
-        if dist is not None:
-            dist.all_reduce(S)                  # one RCCL all-reduce of [3,E,B,C] float64 over xGMI
+        # the library's N>1 path (bayesnn_fpga_amd/sharding.py): this rank's t-shard into S, then ONE all-reduce (RCCL
+        # over xGMI) of the [3,E,B,C] float64 buffer; a single rank skips the collective
+        accumulate_sharded(lambda buf, t0, n: eng.accumulate(x, buf, t0, n, a.seed), S, T)
         return eng.finalize(S, T)
 
     def fence():
@@ -219,6 +253,8 @@ def main():
         traffic, traffic_src = (hbm_traffic(a.workload, max(alg_launches, 1))
                                 if (world == 1 and not a.batch and not a.T and not a.chunk) else (None, None))
         mean = out["mean"].cpu().numpy()
+        if a.dump_mean:
+            np.save(a.dump_mean, mean)
         labels = synthetic_labels(B, kw["out_dim"], seed=1235).numpy()
         onehot = np.eye(kw["out_dim"])[labels]
         line = {
@@ -255,8 +291,12 @@ def main():
         if not a.no_cpu_baseline and world == 1:        # the CPU baseline is reported at N=1 only
             cpu_val, threads, cpu_mean = cpu_baseline(wl, B, a.cpu_T, a.seed)
             gpu_same = eng.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()
+            one = cpu_baseline_1thread(wl, a.cpu_1t_images, 2, a.seed) if a.cpu_1t_images > 0 else None
             line["cpu_baseline"] = {
                 "value": round(cpu_val, 1), "unit": "MCD-samples/s", "cores": threads, "kind": "port",
+                "threads": threads, "cores_physical": physical_cores(), "logical_cpus": os.cpu_count(),
+                "value_1thread": None if one is None else round(one, 2),
+                "sample_1thread": f"same oracle loop, torch.set_num_threads(1), {a.cpu_1t_images} images x T=2",
                 "sample": f"oracle (port of FullAnalysis._get_output loop), 1 batch of {B} images x T={a.cpu_T}, fp32, "
                           f"torch {torch.__version__} CPU, {os.cpu_count()} logical CPUs",
                 "ece_hist_final_exit_cpu": round(ece_hist_binary(cpu_mean[-1], onehot), 6),

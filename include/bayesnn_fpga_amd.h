@@ -141,7 +141,9 @@ const char* bmi_error_string(int code);
  * unknown name / value.  Names:
  *   "mfma_shape_patch", "mfma_shape_wide"   16 | 32: MFMA instruction shape of conv3x3_patch / conv_igemm_wide
  *                                           (v_mfma_f32_16x16x32_f16 | v_mfma_f32_32x32x16_f16); 0 = built-in default
- * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE). */
+ *   "xcd_split"                             0 | 1 | 2 | 4: channel-tile classes of the XCD-aware tile order (0 = chosen from
+ *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
+ * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT). */
 int bmi_set_option(const char* name, int32_t value);
 
 /* Host-only: validates and copies the graph, marks which tensors are stochastic, splits a

@@ -30,3 +30,42 @@ def test_bench_prints_the_contract_line():
     assert set(rf["by_kernel"]) >= {"conv3x3_patch_kernel", "conv_igemm_wide_kernel"}
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_mean_diff_gpu_vs_cpu"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_equals_one_rank(tmp_path):
+    """The N>1 path as the driver launches it (python -m torch.distributed.run, one process per rank, fresh
+    subprocesses), dry-run on ONE GPU: both ranks share cuda:0 and reduce over gloo instead of RCCL — the same
+    bench.py / sharding.accumulate_sharded code, t-shards [0,4) and [4,8).  The reduced predictive mean must equal the
+    1-rank run to 1e-12 (every per-sample value is bit-identical; only the float64 summation order differs)."""
+    import socket
+    import numpy as np
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "1", "--warmup", "0", "--T", "8", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    f1, f2 = str(tmp_path / "m1.npy"), str(tmp_path / "m2.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--dump-mean", f1],
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                         *common, "--dump-mean", f2], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    d1 = json.loads([ln for ln in r1.stdout.strip().split("\n") if ln.startswith("{")][0])
+    lines2 = [ln for ln in r2.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines2) == 1, "exactly one JSON line (rank 0) for the whole job"
+    d2 = json.loads(lines2[0])
+    assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1 and "cpu_baseline" not in d2
+    m1, m2 = np.load(f1), np.load(f2)
+    assert m1.shape == m2.shape == (4, 250, 10)
+    np.testing.assert_allclose(m2, m1, rtol=0, atol=1e-12)
+    assert d1["ece_hist_final_exit"] == d2["ece_hist_final_exit"]
+
+
+@pytest.mark.gpu
+def test_bench_rejects_mismatched_world_size():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
