@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libbayesnn_fpga_amd.so")
 BMI_OK = 0
 SITE_NONE, SITE_ELEMENTWISE, SITE_CHANNEL, SITE_MASKSEMBLE = 0, 1, 2, 3
 SITE_POS_OUTER, SITE_POS_INNER = 0, 1
+DTYPE_F16, DTYPE_BF16 = 0, 1
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
 PROFILE_SLOTS = 10
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
@@ -36,7 +37,7 @@ class OpDesc(C.Structure):
 
 class ModelDesc(C.Structure):
     _fields_ = [("n_tensors", C.c_int32), ("tensors", C.POINTER(TensorDesc)), ("n_ops", C.c_int32),
-                ("ops", C.POINTER(OpDesc)), ("n_exits", C.c_int32), ("out_dim", C.c_int32)]
+                ("ops", C.POINTER(OpDesc)), ("n_exits", C.c_int32), ("out_dim", C.c_int32), ("dtype", C.c_int32)]
 
 
 class BmiError(RuntimeError):

@@ -79,7 +79,7 @@ struct PatchGeom {
 // 16 x 32 fragment), same LDS layout and swizzle (the 16 lanes of a read group are 16 consecutive rows either way).
 // Which one is faster is a clock question, not a cycle question (MI355X_MICROARCH.md, DVFS give-back item 7): both are
 // built and launch_conv3x3_patch picks by measured wall time (BMI_MFMA_SHAPE overrides).
-template <int TH, int TW, int IMGS, int TJ, bool PLAIN, int MS>
+template <int TH, int TW, int IMGS, int TJ, bool PLAIN, int MS, bool BF>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     using G = PatchGeom<TH, TW, IMGS, TJ>;
     constexpr int BC = G::BC, PH = G::PH, PW = G::PW, PWP = G::PWP, KA = G::KA;
@@ -172,9 +172,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < (MS == 32 ? 16 : 4); ++e) acc[i][j][e] = 0.f;
 
-#define PATCH_MFMA(AF, BF, ACC)                                                                   \
-    if constexpr (MS == 32) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF, BF, ACC, 0, 0, 0);   \
-    else ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF, BF, ACC, 0, 0, 0);
+#define PATCH_MFMA(AFR, BFR, ACC)                                                                 \
+    if constexpr (MS == 32) ACC = mfma_32x32x16<BF>(AFR, BFR, ACC);                               \
+    else ACC = mfma_16x16x32<BF>(AFR, BFR, ACC);
 
     const int nchunks = a.Cin / 64;
     const int nK = 9 * nchunks;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         off = ((size_t)n * (a.Ho * a.Wo) + rem) * a.Cout;
         return ok;
     };
-    epilogue_coalesced<TJ, PLAIN, MS>(a, acc, smem, tid, ch0, pixmap, offmap);
+    epilogue_coalesced<TJ, PLAIN, MS, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
     STAMP(3);
 }
 
@@ -303,12 +303,15 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const bool plain = conv_epilogue_is_plain(a);
     const dim3 grid((unsigned)tiles), block(256);
-    if (opt_mfma_shape_patch() == 16) {   // bmi_set_option / BMI_MFMA_SHAPE; default chosen by measured wall time
-        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16>), grid, block, 0, s, a);
+    if (a.bf16) {                                  // bf16 operands: the 16x16x32 shape only
+        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, true>), grid, block, 0, s, a);
+    } else if (opt_mfma_shape_patch() == 16) {     // bmi_set_option / BMI_MFMA_SHAPE; default chosen by measured wall time
+        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, false>), grid, block, 0, s, a);
     } else {
-        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 32>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 32>), grid, block, 0, s, a);
+        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 32, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 32, false>), grid, block, 0, s, a);
     }
     BMI_CHECK_LAUNCH();
     return BMI_OK;

@@ -8,6 +8,34 @@
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+// Activation / weight element type.  Everything 16-bit is STORED as `_Float16` lanes (an opaque 16-bit container: the
+// pointer types, LDS images, DMA and fragment reads never look inside); BF = true means the bits are bfloat16.  Only
+// the two ends differ: the MFMA instruction (v_mfma_*_bf16) and the fp32 <-> 16-bit conversions below.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+template <bool BF>
+__device__ __forceinline__ float a16_to_f32(_Float16 h) {
+    if constexpr (BF) return (float)__builtin_bit_cast(__bf16, h);
+    else return (float)h;
+}
+template <bool BF>
+__device__ __forceinline__ _Float16 a16_from_f32(float v) {
+    if constexpr (BF) return __builtin_bit_cast(_Float16, (__bf16)v);   // v_cvt_pk_bf16_f32: round to nearest even
+    else return (_Float16)v;
+}
+typedef float f32x4_m __attribute__((ext_vector_type(4)));
+typedef float f32x16_m __attribute__((ext_vector_type(16)));
+template <bool BF>
+__device__ __forceinline__ f32x4_m mfma_16x16x32(half8_t a, half8_t b, f32x4_m c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ f32x16_m mfma_32x32x16(half8_t a, half8_t b, f32x16_m c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8,
 // each with its own L2), so the n_ct channel tiles that share ONE pixel tile must get block ids
 // that are congruent mod 8, or every XCD fetches that pixel tile's input again from beyond its L2
@@ -79,6 +107,7 @@ __device__ __forceinline__ void site_mult4(const ConvArgs& a, const PixelCtx& p,
     }
 }
 
+template <bool BF>
 __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx& p, float v[4], int c4) {
     if (a.scale) {
         const float4 s4 = *(const float4*)(a.scale + c4);
@@ -104,7 +133,7 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
     if (p.resp) {
         const half4 r4 = *(const half4*)(p.resp + c4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+        for (int e = 0; e < 4; ++e) v[e] += a16_to_f32<BF>(r4[e]);
     }
     if (a.relu) {
 #pragma unroll
@@ -116,7 +145,7 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
     }
     half4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+    for (int e = 0; e < 4; ++e) o[e] = a16_from_f32<BF>(v[e]);
     *(half4*)(a.out + p.out_off + c4) = o;
 }
 
@@ -164,7 +193,7 @@ __device__ __forceinline__ void lds_barrier() {
 // 16*i + 4*(l >> 4) ..): the same LDS image is written from the other register layout — a lane's quad is channel quad
 // 4*i + (l >> 4) of the wave's 16, i.e. 16-byte chunk 2*i + (l >> 5), half (l >> 4) & 1; 32 lanes of a ds_write_b64 are
 // 16 pixels x 2 halves of one chunk column: 32 distinct 8-byte slots.
-template <int TJ, int MS, class ACC, class OffMap>
+template <int TJ, int MS, bool BF, class ACC, class OffMap>
 __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0, OffMap offmap) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -188,7 +217,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, ACC& acc, char
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[i][j][e] * sc[e] + bi[e];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    o[e] = (_Float16)v;
+                    o[e] = a16_from_f32<BF>(v);
                 }
                 *(half4*)(lds + p * 256 + ((cq ^ l16) << 4) + (((q4 ^ j) & 1) << 3)) = o;   // (p >> 4) & 1 == j & 1: quads swapped
             }
@@ -224,7 +253,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, ACC& acc, char
             for (int e = 0; e < 4; ++e) {
                 float v = acc[i][j][4 * g4 + e] * sc[e] + bi[e];
                 if (a.relu) v = fmaxf(v, 0.f);
-                o[e] = (_Float16)v;
+                o[e] = a16_from_f32<BF>(v);
             }
             *(half4*)(lds + p * 256 + ((cq ^ (r & 15)) << 4) + hsw * 8) = o;
         }
@@ -278,13 +307,13 @@ __device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px
 // offmap(p, off) -> bool: the same pixel's element offset in the output tensor (no division for linear tiles).
 // PLAIN (chosen per launch: no residual, no site) selects epilogue_plain at compile time: with both paths in one
 // kernel the register allocator spills 56-80 VGPRs in the other one.
-template <int TJ, bool PLAIN, int MS, class ACC, class PixMap, class OffMap>
+template <int TJ, bool PLAIN, int MS, bool BF, class ACC, class PixMap, class OffMap>
 __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
                                                    PixMap pixmap, OffMap offmap) {
     static_assert(TJ == 2 || TJ == 4, "two pixel tiles per round");
     static_assert(MS == 32 || MS == 16, "MFMA shape");
     if constexpr (PLAIN) {
-        epilogue_plain<TJ, MS>(a, acc, lds, tid, ch0, offmap);
+        epilogue_plain<TJ, MS, BF>(a, acc, lds, tid, ch0, offmap);
         return;
     }
     constexpr int NR = TJ / 2;
@@ -408,7 +437,7 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, 
             }
             if (px.resp) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)resv[rr][it][e];
+                for (int e = 0; e < 8; ++e) v[e] += a16_to_f32<BF>(resv[rr][it][e]);
             }
             if (a.relu) {
 #pragma unroll
@@ -420,7 +449,7 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, 
             }
             half8_e o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+            for (int e = 0; e < 8; ++e) o[e] = a16_from_f32<BF>(v[e]);
             *(half8_e*)(a.out + px.out_off + c8) = o;
         }
     }

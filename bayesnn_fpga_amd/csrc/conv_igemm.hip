@@ -30,7 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK, bool PLAIN>
+template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK, bool PLAIN, bool BF>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TI = BC / WC / 32;   // 32x32 MFMA tiles per wave along channels
     constexpr int TJ = BP / WP / 32;   // ... along pixels
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16<BF>(af[i], bf[j], acc[i][j]);
         }
         if constexpr (DBUF) {
             if (more) LSTORE(buf ^ 1);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             off = (size_t)(pix0 + p) * a.Cout;
             return pix0 + p < a.M;
         };
-        epilogue_coalesced<TJ, PLAIN, 32>(a, acc, smem, tid, ch0, pixmap, offmap);
+        epilogue_coalesced<TJ, PLAIN, 32, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
     } else {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e];
-                    epilogue_quad(a, px, v, c4);
+                    epilogue_quad<BF>(a, px, v, c4);
                 }
             }
         }
@@ -220,10 +220,15 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     const long n_ptiles = ((long)a.M + BP - 1) / BP;
     const long blocks = n_ptiles * n_ctiles;
     if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_INVALID;
-    if (BC == 128 && conv_epilogue_is_plain(a))   // the 64-channel tiles use the per-quad epilogue: one instantiation
-        hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, BC == 128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)blocks), block(256);
+    const bool plain = BC == 128 && conv_epilogue_is_plain(a);   // the 64-channel tiles use the per-quad epilogue: one instantiation
+    if (a.bf16) {
+        if (plain) hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, BC == 128, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, false, true>), grid, block, 0, s, a);
+    } else {
+        if (plain) hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, BC == 128, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, false, false>), grid, block, 0, s, a);
+    }
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

@@ -69,9 +69,9 @@ extern "C" int bmi_debug_wide_stamps_clear() {
     constexpr int TJ = 4;                                                                              \
     constexpr int TI = MS == 32 ? 2 : 4, TP = MS == 32 ? 4 : 8, RW = MS;                               \
     typedef float accv __attribute__((ext_vector_type(MS == 32 ? 16 : 4)));
-#define WIDE_MFMA(AF, BF, ACC)                                                                         \
-    if constexpr (MS == 32) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF, BF, ACC, 0, 0, 0);        \
-    else ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF, BF, ACC, 0, 0, 0);
+#define WIDE_MFMA(AFR, BFR, ACC)                                                                       \
+    if constexpr (MS == 32) ACC = mfma_32x32x16<BF>(AFR, BFR, ACC);                                    \
+    else ACC = mfma_16x16x32<BF>(AFR, BFR, ACC);
 // One phase of the ping-pong loop: LOAD part (fragment reads of k-substep / pixel half KK of the K-step in stage ST, plus
 // this wave's share of the next K-step's DMA), barrier, MFMA part, barrier.  MS = 32: phase = one 16-deep k-substep,
 // 2 + 4 reads, 8 MFMAs of 32 cycles.  MS = 16: phase = one pixel half (4 of the 8 pixel tiles) of a 32-deep k-substep,
@@ -97,7 +97,7 @@ extern "C" int bmi_debug_wide_stamps_clear() {
             _Pragma("unroll") for (int j = 0; j < 4; ++j) { WIDE_MFMA(af[i], bf[j], acc[i][4 * ((KK) & 1) + j]); } \
     }
 
-template <bool PLAIN, int MS>
+template <bool PLAIN, int MS, bool BF>
 __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
     WIDE_SHAPE_CONSTS
     __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         off = (size_t)(pix0 + p) * b.Cout;
         return pix0 + p < a.M;
     };
-    epilogue_coalesced<TJ, PLAIN, MS>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+    epilogue_coalesced<TJ, PLAIN, MS, BF>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
     STAMP(3);
 #ifdef BMI_WIDE_STAMPS
     if (tid == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
 // load in the epilogue would make hipcc drain the LDS-DMA (vmcnt(0)) at its first use.
 #define WBN_MAX 1024
 
-template <int MS>
+template <int MS, bool BF>
 __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArgs a, int n_tiles) {
     WIDE_SHAPE_CONSTS
     __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE + 2 * WBN_MAX * 4];
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
                             for (int e = 0; e < 4; ++e) {
                                 float v = acc[i][4 * rr + jj][e] * sc[e] + bi[e];
                                 if (a.relu) v = fmaxf(v, 0.f);
-                                o[e] = (_Float16)v;
+                                o[e] = a16_from_f32<BF>(v);
                             }
                             *(half4*)(E + p * 256 + ((cq ^ r) << 4) + (((kq ^ jj) & 1) << 3)) = o;
                         }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
                         for (int e = 0; e < 4; ++e) {
                             float v = acc[i][2 * rr + jj][4 * g4 + e] * sc[e] + bi[e];
                             if (a.relu) v = fmaxf(v, 0.f);
-                            o[e] = (_Float16)v;
+                            o[e] = a16_from_f32<BF>(v);
                         }
                         *(half4*)(E + p * 256 + ((cq ^ (r & 15)) << 4) + hsw * 8) = o;
                     }
@@ -551,18 +551,22 @@ int launch_conv_igemm_wide(const ConvArgs& a_in, hipStream_t s) {
     }();
     const int shape = opt_mfma_shape_wide();
     if (persist && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks > 2L * n_cu) {
-        if (shape == 16) hipLaunchKernelGGL(conv_igemm_wide_persist_kernel<16>, dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
-        else hipLaunchKernelGGL(conv_igemm_wide_persist_kernel<32>, dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
+        if (a.bf16) hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<16, true>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
+        else if (shape == 16) hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<16, false>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
+        else hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<32, false>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
         BMI_CHECK_LAUNCH();
         return BMI_OK;
     }
     const dim3 grid((unsigned)blocks), block(512);
-    if (shape == 16) {
-        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16>), grid, block, 0, s, a);
+    if (a.bf16) {
+        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, true>), grid, block, 0, s, a);
+    } else if (shape == 16) {
+        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, false>), grid, block, 0, s, a);
     } else {
-        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 32>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 32>), grid, block, 0, s, a);
+        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 32, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 32, false>), grid, block, 0, s, a);
     }
     BMI_CHECK_LAUNCH();
     return BMI_OK;

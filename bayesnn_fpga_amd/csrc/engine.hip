@@ -59,6 +59,7 @@ struct bmi_engine_s {
     std::vector<TensorInfo> tensors;
     std::vector<OpInfo> prefix, suffix;
     int n_exits = 0, out_dim = 0;
+    int bf16 = 0;               // BMI_DTYPE_BF16
     int64_t prefix_macs = 0, suffix_macs = 0;
     // plan
     int max_batch = 0, chunk = 0;
@@ -134,6 +135,7 @@ static int shape_from_env(const char* primary, const char* fallback) {
     return x == 16 || x == 32 ? x : BMI_DEFAULT_MFMA_SHAPE;
 }
 int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nullptr); return v; }
+int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
     return v;
@@ -153,6 +155,11 @@ int bmi_version(void) { return BMI_VERSION; }
 
 int bmi_set_option(const char* name, int32_t value) {
     if (!name) return BMI_ERR_INVALID;
+    if (std::strcmp(name, "unit_entry_dtype") == 0) {
+        if (value != BMI_DTYPE_F16 && value != BMI_DTYPE_BF16) return BMI_ERR_INVALID;
+        opt_unit_dtype() = value;
+        return BMI_OK;
+    }
     if (std::strcmp(name, "xcd_split") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return BMI_ERR_INVALID;
         opt_xcd_split() = value;
@@ -180,10 +187,12 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     if (!desc || !out || desc->n_tensors < 2 || desc->n_ops < 1 || !desc->tensors || !desc->ops) return BMI_ERR_INVALID;
     if (desc->n_exits < 1 || desc->out_dim < 1) return BMI_ERR_INVALID;
     if (desc->out_dim > 128) return BMI_ERR_UNSUPPORTED;
+    if (desc->dtype != BMI_DTYPE_F16 && desc->dtype != BMI_DTYPE_BF16) return BMI_ERR_INVALID;
     bmi_engine_s* e = new (std::nothrow) bmi_engine_s();
     if (!e) return BMI_ERR_NOMEM;
     e->n_exits = desc->n_exits;
     e->out_dim = desc->out_dim;
+    e->bf16 = desc->dtype == BMI_DTYPE_BF16;
     e->tensors.resize(desc->n_tensors);
     for (int i = 0; i < desc->n_tensors; ++i) {
         const bmi_tensor_desc& t = desc->tensors[i];
@@ -542,10 +551,11 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     switch (d.kind) {
         case BMI_OP_STEM:
             return launch_stem_conv(x, (const float*)d.weight, d.scale, d.bias, (_Float16*)(ws + e->tensors[d.out].offset), N,
-                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, s);
+                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, e->bf16, s);
         case BMI_OP_CONV: {
             ConvArgs a;
             std::memset(&a, 0, sizeof(a));
+            a.bf16 = e->bf16;
             a.in = (const _Float16*)(ws + tin.offset);
             a.wgt = (const _Float16*)d.weight;
             a.scale = d.scale; a.bias = d.bias;
@@ -602,6 +612,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         case BMI_OP_MASK: {
             EltArgs a;
             std::memset(&a, 0, sizeof(a));
+            a.bf16 = e->bf16;
             a.in = (const _Float16*)(ws + tin.offset);
             a.out = ws + e->tensors[d.out].offset;
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
@@ -611,15 +622,16 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         }
         case BMI_OP_MAXPOOL:
             return launch_maxpool2((const _Float16*)(ws + tin.offset), (_Float16*)(ws + e->tensors[d.out].offset), N, tin.h,
-                                   tin.w, tin.c, s);
+                                   tin.w, tin.c, e->bf16, s);
         case BMI_OP_DENSE:
-            return launch_dense_f32(ws + tin.offset, tin.f32 ? 1 : 0, (const float*)d.weight, d.bias,
+            return launch_dense_f32(ws + tin.offset, tin.f32 ? 1 : (e->bf16 ? 2 : 0), (const float*)d.weight, d.bias,
                                     (float*)(ws + e->tensors[d.out].offset), N, tin.stoch ? N : B, tin.c, op.cout, d.relu,
                                     resolve_site(&d.site, seed, cnt0), B, t0, s);
         case BMI_OP_HEAD: {
             EltArgs a;
             std::memset(&a, 0, sizeof(a));
             a.in = (const _Float16*)(ws + tin.offset);
+            a.bf16 = e->bf16;
             a.in_f32 = tin.f32 ? 1 : 0;
             a.out = feat;
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
@@ -720,7 +732,7 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
                       int32_t pad, int32_t relu, bmi_stream stream) {
     if (!x_nchw || !weight || !out_nhwc) return BMI_ERR_INVALID;
     return launch_stem_conv(x_nchw, weight, scale, bias, (_Float16*)out_nhwc, n, cin, h, w, cout, ksize, stride, pad, relu,
-                            (hipStream_t)stream);
+                            opt_unit_dtype() == BMI_DTYPE_BF16, (hipStream_t)stream);
 }
 
 int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* site, int32_t batch, int32_t t0,
@@ -738,6 +750,7 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
+    a.bf16 = opt_unit_dtype() == BMI_DTYPE_BF16;
     a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.scale = scale; a.bias = bias;
     a.res = (const _Float16*)res; a.out = (_Float16*)out;
     a.N = n; a.in_mod = in_mod; a.res_mod = res_mod;
@@ -760,6 +773,7 @@ int bmi_conv_pair_fwd(const void* in, const void* weight_a, const float* scale_a
     if (!in || !weight_a || !weight_b || !out_a || !out_b || ksize < 1 || stride < 1 || pad < 0) return BMI_ERR_INVALID;
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
+    a.bf16 = opt_unit_dtype() == BMI_DTYPE_BF16;
     a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight_a; a.scale = scale_a; a.bias = bias_a; a.out = (_Float16*)out_a;
     a.wgt_b = (const _Float16*)weight_b; a.scale_b = scale_b; a.bias_b = bias_b; a.out_b = (_Float16*)out_b;
     a.split = cout_a;
@@ -779,6 +793,7 @@ int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2
     if (!in || !weight || !in2 || !weight2 || !out) return BMI_ERR_INVALID;
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
+    a.bf16 = opt_unit_dtype() == BMI_DTYPE_BF16;
     a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight; a.bias = bias; a.out = (_Float16*)out;
     a.N = n; a.in_mod = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.Ho = h; a.Wo = w;
     a.ksize = 3; a.stride = 1; a.pad = 1; a.relu = relu; a.M = n * h * w; a.B = n; a.out_mul = 1.f;
@@ -793,6 +808,7 @@ static int elt_args(EltArgs& a, const void* in, void* out, int n, int in_mod, in
     if (!in || !out) return BMI_ERR_INVALID;
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;
     std::memset(&a, 0, sizeof(a));
+    a.bf16 = opt_unit_dtype() == BMI_DTYPE_BF16;
     a.in = (const _Float16*)in; a.out = out; a.N = n; a.in_mod = in_mod; a.HW = hw; a.C = c; a.B = batch; a.t0 = t0;
     a.site = resolve_site(site, seed, cnt0);
     return BMI_OK;
@@ -807,7 +823,7 @@ int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t
 
 int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c, bmi_stream stream) {
     if (!in || !out) return BMI_ERR_INVALID;
-    return launch_maxpool2((const _Float16*)in, (_Float16*)out, n, h, w, c, (hipStream_t)stream);
+    return launch_maxpool2((const _Float16*)in, (_Float16*)out, n, h, w, c, opt_unit_dtype() == BMI_DTYPE_BF16, (hipStream_t)stream);
 }
 
 int bmi_pool_mask(const void* in, float* feat, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
@@ -838,7 +854,7 @@ int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const 
                   uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
     if (!in || !weight || !bias || !out) return BMI_ERR_INVALID;
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;
-    return launch_dense_f32(in, in_is_f32, weight, bias, out, n, in_mod, k, cout, relu, resolve_site(site, seed, mask_cnt0), batch,
+    return launch_dense_f32(in, in_is_f32 ? 1 : (opt_unit_dtype() == BMI_DTYPE_BF16 ? 2 : 0), weight, bias, out, n, in_mod, k, cout, relu, resolve_site(site, seed, mask_cnt0), batch,
                             t0, (hipStream_t)stream);
 }
 

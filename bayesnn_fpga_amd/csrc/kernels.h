@@ -41,11 +41,13 @@ struct ConvArgs {
     int M;         // N * Ho * Wo
     int B;         // images per Monte-Carlo sample
     int t0;        // first sample index of this launch
+    int bf16;      // 1: activations / weights are bfloat16 bits (v_mfma_*_bf16), 0: fp16
     int xcd_split; // channel-tile classes of the XCD-aware tile order (xcd_tile_map's cs); set by the launcher
     SiteArgs site;
 };
 
 struct EltArgs {  // MASK / POOL ops
+    int bf16;     // 16-bit tensors hold bfloat16 bits
     const _Float16* in;
     int in_f32;   // POOL: `in` is an fp32 [N][HW][C] tensor (a dense layer's output)
     void* out;    // MASK: fp16 [N][HW][C]; POOL: fp32 [N][C]
@@ -62,15 +64,15 @@ bool conv_takes_wide_kernel(int cin, int cout);
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
 int launch_conv(const ConvArgs& a, hipStream_t s, int* family = nullptr);   // picks the kernel; *family = BMI_CONV_FAMILY_*
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
-                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s);
+                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int bf16, hipStream_t s);
 int launch_mask_apply(const EltArgs& a, hipStream_t s);
 int launch_pool_mask(const EltArgs& a, hipStream_t s);
-int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, hipStream_t s);
+int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, int bf16, hipStream_t s);
 // `site` (kind NONE to skip): dropout on the LOGITS ([B, out_dim] tensor: element = b*out_dim + c), sample n / batch
 int launch_linear_softmax(const float* feat, const float* w, const float* bias, float* logits, float* probs, int n,
                           int k, int out_dim, const SiteArgs& site, int batch, int t0, hipStream_t s);
-// hidden dense layer, fp32 weights [cout][k] / accumulate / output; `in` fp16 or fp32 [n or in_mod][k]
-int launch_dense_f32(const void* in, int in_is_f32, const float* w, const float* bias, float* out, int n, int in_mod, int k,
+// hidden dense layer, fp32 weights [cout][k] / accumulate / output; `in` 16-bit (in_kind 0: fp16, 2: bf16) or fp32 (1) [n or in_mod][k]
+int launch_dense_f32(const void* in, int in_kind, const float* w, const float* bias, float* out, int n, int in_mod, int k,
                      int cout, int relu, const SiteArgs& site, int batch, int t0, hipStream_t s);
 int launch_moments(const float* probs, const float* logits, double* S1, double* S2, double* SL, int tc, int batch,
                    int out_dim, int n_exits, size_t exit_stride_scratch, size_t exit_stride_S, hipStream_t s);
@@ -83,6 +85,7 @@ bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, 
 // process-wide kernel-selection switches (bmi_set_option); 16 or 32
 int& opt_mfma_shape_patch();
 int& opt_mfma_shape_wide();
+int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);
 

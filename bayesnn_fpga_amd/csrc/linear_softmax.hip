@@ -7,6 +7,7 @@
 // 32-class tile, so the softmax max/sum are in-lane reductions plus ONE cross-half shuffle
 // (lane ^ 32).  The K index is permuted (lane half h takes k in [h*K/2, (h+1)*K/2)), which a
 // dot product does not care about, so every lane streams its row with float4 loads.
+#include "conv_epilogue.h"
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64) void linear_softmax_kernel(const float* __restr
 // output) or fp32 (a previous dense layer).
 typedef _Float16 half8_d __attribute__((ext_vector_type(8)));
 
-template <typename TIN>
+template <typename TIN, bool BF>
 __global__ __launch_bounds__(64) void dense_f32_kernel(const TIN* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
                                                        int in_mod, int K, int Cout, int relu, SiteArgs site, int B, int t0) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64) void dense_f32_kernel(const TIN* __restrict__ i
     {                                                                                                                  \
         if constexpr (sizeof(TIN) == 2) {                                                                              \
             const half8_d h_ = *(const half8_d*)(ip + (S));                                                            \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) b[e] = (float)h_[e];                                         \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) b[e] = a16_to_f32<BF>(h_[e]);                                \
         } else {                                                                                                       \
             const float4 b0_ = *(const float4*)(ip + (S)), b1_ = *(const float4*)(ip + (S) + 4);                       \
             b[0] = b0_.x; b[1] = b0_.y; b[2] = b0_.z; b[3] = b0_.w; b[4] = b1_.x; b[5] = b1_.y; b[6] = b1_.z; b[7] = b1_.w; \
@@ -179,13 +180,15 @@ __global__ __launch_bounds__(64) void dense_f32_kernel(const TIN* __restrict__ i
         }
 }
 
-int launch_dense_f32(const void* in, int in_is_f32, const float* w, const float* bias, float* out, int n, int in_mod, int k,
+int launch_dense_f32(const void* in, int in_kind, const float* w, const float* bias, float* out, int n, int in_mod, int k,
                      int cout, int relu, const SiteArgs& site, int batch, int t0, hipStream_t s) {
     if (n <= 0 || in_mod <= 0 || batch <= 0) return BMI_ERR_INVALID;
     if (k % 16 != 0 || cout % 64 != 0) return BMI_ERR_UNSUPPORTED;
     const dim3 grid((n + 31) / 32, cout / 64), block(64);
-    if (in_is_f32) hipLaunchKernelGGL(dense_f32_kernel<float>, grid, block, 0, s, (const float*)in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
-    else hipLaunchKernelGGL(dense_f32_kernel<_Float16>, grid, block, 0, s, (const _Float16*)in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+    if (in_kind == 1) hipLaunchKernelGGL((dense_f32_kernel<float, false>), grid, block, 0, s, (const float*)in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+    else if (in_kind == 2) hipLaunchKernelGGL((dense_f32_kernel<_Float16, true>), grid, block, 0, s, (const _Float16*)in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+    else if (in_kind == 0) hipLaunchKernelGGL((dense_f32_kernel<_Float16, false>), grid, block, 0, s, (const _Float16*)in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+    else return BMI_ERR_INVALID;
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

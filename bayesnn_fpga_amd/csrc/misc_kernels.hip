@@ -11,6 +11,7 @@
 //   philox_mask    keep bits, for unit tests
 #include <cstdlib>
 
+#include "conv_epilogue.h"
 #include "kernels.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -29,6 +30,7 @@ __device__ __forceinline__ void site_mask8(const SiteArgs& s, float v[8], uint64
 }
 
 // ---------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(256) void mask_apply_kernel(EltArgs a) {
     const int cg = a.C >> 3;  // 8-channel groups per pixel
     const long total = (long)a.N * a.HW * cg;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(EltArgs a) {
         const half8 x = *(const half8*)(a.in + ((size_t)(n % a.in_mod) * a.HW + p) * a.C + c8);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+        for (int e = 0; e < 8; ++e) v[e] = a16_to_f32<BF>(x[e]);
         const uint64_t elem0 = a.site.kind == BMI_SITE_CHANNEL ? (uint64_t)b * a.C + c8
                                                                 : ((uint64_t)b * a.HW + p) * a.C + c8;
         const float* mrow = a.site.kind == BMI_SITE_MASKSEMBLE
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(EltArgs a) {
         }
         half8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+        for (int e = 0; e < 8; ++e) o[e] = a16_from_f32<BF>(v[e]);
         *(half8*)((_Float16*)a.out + ((size_t)n * a.HW + p) * a.C + c8) = o;
     }
 }
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void mask_apply_kernel(EltArgs a) {
 // R items fetches the four words of the owning lane with ds_bpermute.  Philox is 480 of the ~700 cycles a wave spends
 // per item otherwise (v_mad_u64_u32 is quarter rate): at p = 0.25 (R = 8) this turns the kernel from Philox-bound into
 // HBM-bound.  Needs the sample's element count to be a multiple of the super-block (64 * 128 / k elements).
-template <int LB>
+template <int LB, bool BF>
 __global__ __launch_bounds__(256) void mask_apply_shared_kernel(EltArgs a) {
     constexpr int R = 16 >> LB;                    // items (8 elements each) per call
     const int lane = threadIdx.x & 63;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void mask_apply_shared_kernel(EltArgs a) {
             const half8 x = *(const half8*)(a.in + (size_t)tl * in_sample_stride + e0);
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? (float)x[e] * a.site.scale : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? a16_to_f32<BF>(x[e]) * a.site.scale : 0.f;
             if (a.bias_post) {
                 const int c8 = (int)(e0 % (size_t)a.C);
                 const float4 p0 = *(const float4*)(a.bias_post + c8), p1 = *(const float4*)(a.bias_post + c8 + 4);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void mask_apply_shared_kernel(EltArgs a) {
             }
             half8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+            for (int e = 0; e < 8; ++e) o[e] = a16_from_f32<BF>(v[e]);
             *(half8*)((_Float16*)a.out + (size_t)tl * sample_elems + e0) = o;
         }
     }
@@ -130,13 +132,21 @@ int launch_mask_apply(const EltArgs& a, hipStream_t s) {
         const long n_sb = sample_elems / (64L * (128 >> lb)) * (a.N / a.B);
         long wblocks = (n_sb + 3) / 4;                 // 4 waves per block, one super-block per wave and iteration
         if (wblocks > 256 * 16) wblocks = 256 * 16;
-        if (lb == 1) hipLaunchKernelGGL(mask_apply_shared_kernel<1>, dim3((unsigned)wblocks), dim3(256), 0, s, a);
-        else if (lb == 2) hipLaunchKernelGGL(mask_apply_shared_kernel<2>, dim3((unsigned)wblocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(mask_apply_shared_kernel<3>, dim3((unsigned)wblocks), dim3(256), 0, s, a);
+        const dim3 g((unsigned)wblocks), b(256);
+        if (a.bf16) {
+            if (lb == 1) hipLaunchKernelGGL((mask_apply_shared_kernel<1, true>), g, b, 0, s, a);
+            else if (lb == 2) hipLaunchKernelGGL((mask_apply_shared_kernel<2, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((mask_apply_shared_kernel<3, true>), g, b, 0, s, a);
+        } else {
+            if (lb == 1) hipLaunchKernelGGL((mask_apply_shared_kernel<1, false>), g, b, 0, s, a);
+            else if (lb == 2) hipLaunchKernelGGL((mask_apply_shared_kernel<2, false>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((mask_apply_shared_kernel<3, false>), g, b, 0, s, a);
+        }
         BMI_CHECK_LAUNCH();
         return BMI_OK;
     }
-    hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.bf16) hipLaunchKernelGGL(mask_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mask_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -178,7 +188,7 @@ int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename TIN>
+template <typename TIN, bool BF>
 __global__ __launch_bounds__(256) void pool_mask_kernel(EltArgs a) {
     const int cg = a.C >> 3;
     const long total = (long)a.N * cg;
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void pool_mask_kernel(EltArgs a) {
         if constexpr (sizeof(TIN) == 2) {
             const half8 x = *(const half8*)(src + (size_t)p * a.C);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += fmaxf((float)x[e], 0.f);  // F.relu before the pool
+            for (int e = 0; e < 8; ++e) v[e] += fmaxf(a16_to_f32<BF>(x[e]), 0.f);  // F.relu before the pool
         } else {
             const float4 x0 = *(const float4*)(src + (size_t)p * a.C), x1 = *(const float4*)(src + (size_t)p * a.C + 4);
             const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -218,13 +228,16 @@ int launch_pool_mask(const EltArgs& a, hipStream_t s) {
     if (a.C % 8 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || a.HW <= 0) return BMI_ERR_INVALID;
     const long total = (long)a.N * (a.C >> 3);
-    if (a.in_f32) hipLaunchKernelGGL(pool_mask_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(pool_mask_kernel<_Float16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
+    if (a.in_f32) hipLaunchKernelGGL((pool_mask_kernel<float, false>), g, b, 0, s, a);
+    else if (a.bf16) hipLaunchKernelGGL((pool_mask_kernel<_Float16, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((pool_mask_kernel<_Float16, false>), g, b, 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C) {
     const int cg = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * Ho * Wo * cg;
@@ -240,20 +253,21 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const _Float16* in, _Floa
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float m = fmaxf(fmaxf((float)a0[e], (float)a1[e]), fmaxf((float)a2[e], (float)a3[e]));
-            o[e] = (_Float16)m;
+            const float m = fmaxf(fmaxf(a16_to_f32<BF>(a0[e]), a16_to_f32<BF>(a1[e])), fmaxf(a16_to_f32<BF>(a2[e]), a16_to_f32<BF>(a3[e])));
+            o[e] = a16_from_f32<BF>(m);
         }
         *(half8*)(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c8) = o;
     }
 }
 
-int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, hipStream_t s) {
+int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, int bf16, hipStream_t s) {
     if (c % 8 != 0 || (h & 1) || (w & 1)) return BMI_ERR_UNSUPPORTED;
     const long total = (long)n * (h / 2) * (w / 2) * (c / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks <= 0) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n, h, w, c);
+    if (bf16) hipLaunchKernelGGL(maxpool2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n, h, w, c);
+    else hipLaunchKernelGGL(maxpool2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n, h, w, c);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -262,6 +276,7 @@ int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int 
 // Direct convolution for the 3-channel network input.  One thread = one output pixel x 8 output
 // channels; weights [Cout][k][k][Cin] fp32 staged in LDS.  fp32 math, fp16 NHWC store.
 #define STEM_MAX_W 4096  // floats of weight in LDS (64 x 3x3x3 = 1728)
+template <bool BF>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         _Float16* __restrict__ out, int N, int Cin, int H, int W, int Cout,
@@ -301,19 +316,21 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         if (scale) v *= scale[c8 + e];
         if (bias) v += bias[c8 + e];
         if (relu) v = fmaxf(v, 0.f);
-        o[e] = (_Float16)v;
+        o[e] = a16_from_f32<BF>(v);
     }
     *(half8*)(out + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c8) = o;
 }
 
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
-                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, hipStream_t s) {
+                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int bf16, hipStream_t s) {
     if (cout % 8 != 0 || cout * ksize * ksize * cin > STEM_MAX_W) return BMI_ERR_UNSUPPORTED;
     if (n <= 0) return BMI_ERR_INVALID;
     const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wdt + 2 * pad - ksize) / stride + 1;
     const long total = (long)n * ho * wo * (cout / 8);
-    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, bias, out,
-                       n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+    if (bf16) hipLaunchKernelGGL(stem_conv_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, bias, out,
+                                 n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+    else hipLaunchKernelGGL(stem_conv_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, bias, out,
+                            n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

@@ -43,8 +43,12 @@ def fold_bn(bn, conv_bias=None):
 class GraphBuilder:
     """Collects tensors / ops / device-resident weights for one model on one device."""
 
-    def __init__(self, device):
+    def __init__(self, device, dtype="f16"):
+        if dtype not in ("f16", "bf16"):
+            raise ValueError(f"dtype must be 'f16' or 'bf16', got {dtype!r}")
         self.device = device
+        self.dtype = dtype
+        self.act_dtype = torch.float16 if dtype == "f16" else torch.bfloat16     # conv weights / activations
         self.tensors = []          # (h, w, c)
         self.ops = []              # dicts
         self.keep = []             # device tensors that must outlive the engine
@@ -99,11 +103,11 @@ class GraphBuilder:
             x2, conv_s, bn_s = shortcut
             s_scale, s_bias = fold_bn(bn_s, conv_s.bias)
             wk = wk.float() * scale[:, None, None, None]
-            w2dev = self.dev(conv_s.weight.detach().float()[:, :, 0, 0] * s_scale[:, None], torch.float16)   # [Cout][Cin2]
+            w2dev = self.dev(conv_s.weight.detach().float()[:, :, 0, 0] * s_scale[:, None], self.act_dtype)   # [Cout][Cin2]
             bias = bias + s_bias
             scale = None
             in2 = x2
-        wdev = self.dev(wk, torch.float32 if stem else torch.float16)
+        wdev = self.dev(wk, torch.float32 if stem else self.act_dtype)
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
                              stride=s, pad=p, relu=int(relu), weight=wdev, in2=in2, weight2=w2dev,
                              scale=self.dev(scale, torch.float32) if scale is not None else None,
@@ -212,8 +216,8 @@ def model_exits(model):
     return 4 if getattr(model, "multi_exit", True) else 1
 
 
-def build_graph(model, device):
-    g = GraphBuilder(device)
+def build_graph(model, device, dtype="f16"):
+    g = GraphBuilder(device, dtype)
     fam = getattr(model, "family", None)
     if fam == "resnet":
         build_resnet_graph(model, g)
@@ -231,12 +235,13 @@ class CompiledGraph:
     """Host-only half of the engine: graph -> C descriptors -> bmi_create / bmi_plan / bmi_query.
     Touches no GPU API (weights only need to be addressable), so it also runs on a CPU-only box."""
 
-    def __init__(self, model, device, max_batch, chunk_samples=None):
+    def __init__(self, model, device, max_batch, chunk_samples=None, dtype="f16"):
         self.lib = _lib.lib()
         self.device = torch.device(device)
         self.n_exits = model_exits(model)
         self.out_dim = int(model.out_dim)
-        self.graph = build_graph(model, self.device)
+        self.dtype = dtype
+        self.graph = build_graph(model, self.device, dtype)
         self.max_batch = int(max_batch)
         self.chunk_explicit = chunk_samples is not None
         if chunk_samples is None:
@@ -277,7 +282,8 @@ class CompiledGraph:
                                         s["masks"].data_ptr() if "masks" in s else None)
             else:
                 d.site = _lib.make_site()
-        desc = _lib.ModelDesc(len(g.tensors), tarr, len(g.ops), oarr, self.n_exits, self.out_dim)
+        desc = _lib.ModelDesc(len(g.tensors), tarr, len(g.ops), oarr, self.n_exits, self.out_dim,
+                              _lib.DTYPE_BF16 if self.dtype == "bf16" else _lib.DTYPE_F16)
         return (desc, tarr, oarr)
 
     def flops_per_batch(self, batch, T):
@@ -321,13 +327,13 @@ class MCDEngine(CompiledGraph):
     """One model compiled for one GPU.  All methods are asynchronous on the current torch stream
     (the stream handle is what the C ABI receives); results are device tensors."""
 
-    def __init__(self, model, device, max_batch=256, chunk_samples=None):
+    def __init__(self, model, device, max_batch=256, chunk_samples=None, dtype="f16"):
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("MCDEngine needs a HIP device (torch device type 'cuda' on ROCm); there is no CPU path")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        super().__init__(model, device, max_batch, chunk_samples)
+        super().__init__(model, device, max_batch, chunk_samples, dtype)
         self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
 
     # ---- the path ------------------------------------------------------------------------------

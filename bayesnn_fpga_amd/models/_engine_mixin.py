@@ -30,10 +30,13 @@ class EngineModelMixin:
         state["_engines"] = {}
         return state
 
-    def engine(self, device, max_batch=None, chunk_samples=None):
-        """The compiled HIP engine for ``device`` (built on first use, rebuilt when it must grow)."""
+    def engine(self, device, max_batch=None, chunk_samples=None, dtype=None):
+        """The compiled HIP engine for ``device`` (built on first use, rebuilt when it must grow).
+        ``dtype``: "f16" (default; meets the 1e-3 parity bar) or "bf16" — the 16-bit type of the activations and conv
+        weights; ``model.engine_dtype`` sets the default for calls that do not pass one (``model(x)``, FullAnalysis)."""
         from ..engine import MCDEngine
-        key = str(device)
+        dtype = dtype or getattr(self, "engine_dtype", "f16")
+        key = f"{device}/{dtype}"
         eng = self._engines.get(key)
         need_b = max_batch or 1
         if eng is None or eng.max_batch < need_b or (chunk_samples and eng.chunk_samples != chunk_samples):
@@ -45,7 +48,7 @@ class EngineModelMixin:
             if eng is not None:
                 eng.close()
                 eng.workspace = None
-            eng = MCDEngine(self, device, max_batch=grown, chunk_samples=chunk_samples)
+            eng = MCDEngine(self, device, max_batch=grown, chunk_samples=chunk_samples, dtype=dtype)
             self._engines[key] = eng
         return eng
 

@@ -36,7 +36,8 @@
  *
  * Data layout in HBM: activations are NHWC fp16 ([image][y][x][channel]); conv weights
  * fp16 [Cout][ky][kx][Cin]; folded-BN scale/bias fp32 [Cout]; classifier weights fp32
- * [ceil32(C)][K] (rows >= C zero); the network input is fp32 NCHW exactly as the reference
+ * [ceil32(C)][K] (rows >= C zero); with bmi_model_desc.dtype = BMI_DTYPE_BF16 "fp16" reads
+ * bfloat16 throughout; the network input is fp32 NCHW exactly as the reference
  * receives it; moment accumulators are float64 [E][B][C].
  */
 #ifndef BAYESNN_FPGA_AMD_H
@@ -119,6 +120,10 @@ typedef struct bmi_op_desc {
     int32_t site_pos;       /* BMI_SITE_POS_*                                                      */
 } bmi_op_desc;
 
+/* element type of the 16-bit activations and conv weights of an engine */
+#define BMI_DTYPE_F16 0  /* IEEE half: v_mfma_f32_*_f16 (default; meets the 1e-3 parity bar)            */
+#define BMI_DTYPE_BF16 1 /* bfloat16:  v_mfma_f32_16x16x32_bf16 (8 mantissa bits: measured error in DESIGN.md) */
+
 typedef struct bmi_model_desc {
     int32_t n_tensors;
     const bmi_tensor_desc* tensors;
@@ -126,6 +131,7 @@ typedef struct bmi_model_desc {
     const bmi_op_desc* ops;
     int32_t n_exits;
     int32_t out_dim;
+    int32_t dtype; /* BMI_DTYPE_*: conv weights (`weight`, `weight2`) must be in this type */
 } bmi_model_desc;
 
 /* per-op-kind device time, filled by bmi_profile_read */
@@ -136,13 +142,15 @@ typedef struct bmi_model_desc {
 int bmi_version(void);
 const char* bmi_error_string(int code);
 
-/* Process-wide kernel-selection switches (speed only, never results beyond fp32 summation order inside one MFMA tile;
- * used for same-process A/B measurement and by the tests to cover both code paths).  Returns BMI_ERR_INVALID for an
+/* Process-wide switches: kernel selection (speed only, never results; used for same-process A/B measurement and by the
+ * tests to cover both code paths) and the element type of the unit-test entry points.  Returns BMI_ERR_INVALID for an
  * unknown name / value.  Names:
  *   "mfma_shape_patch", "mfma_shape_wide"   16 | 32: MFMA instruction shape of conv3x3_patch / conv_igemm_wide
  *                                           (v_mfma_f32_16x16x32_f16 | v_mfma_f32_32x32x16_f16); 0 = built-in default
  *   "xcd_split"                             0 | 1 | 2 | 4: channel-tile classes of the XCD-aware tile order (0 = chosen from
  *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
+ *   "unit_entry_dtype"                      BMI_DTYPE_*: how the single-kernel entry points below (unit tests) interpret
+ *                                           their 16-bit buffers; engines carry their own dtype in bmi_model_desc
  * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT). */
 int bmi_set_option(const char* name, int32_t value);
 
@@ -244,7 +252,7 @@ int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const fl
  * [batch, cout] tensor, sample index n / batch + t0).  `in` is fp16 (in_is_f32 = 0) or fp32 [.][k]; weight fp32 [cout][k];
  * k % 16 == 0, cout % 64 == 0.  Replaces the Dense 512 layers of the VGG-11 classifier stack
  * (Hardware_Artifact/bayes_hw/models/models.py:262-281) with their dropout (:268-281). */
-int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const float* bias, float* out, int32_t n,
+int bmi_dense_f32(const void* in, int32_t in_is_f32 /* 0: 16-bit (unit_entry_dtype), 1: fp32 */, const float* weight, const float* bias, float* out, int32_t n,
                   int32_t in_mod, int32_t k, int32_t cout, int32_t relu, const bmi_site* site, int32_t batch, int32_t t0,
                   uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
 

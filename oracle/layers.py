@@ -47,11 +47,20 @@ def philox_dropout(ctx, x, p, channelwise=False):
 
 
 class MCDropout(nn.Dropout):
-    """SA/models/resnet18/resnet18.py:207-210.  ``ctx`` is attached by the owning model."""
+    """SA/models/resnet18/resnet18.py:207-210.  ``ctx`` is attached by the owning model.
+
+    ``native_rng`` (class switch, bench.py's CPU-baseline TIMING leg only): draw the mask with ATen's own
+    ``F.dropout(x, p, True)`` exactly as the reference does, instead of the numpy Philox restatement — the Philox masks
+    exist to make GPU and CPU agree bit for bit, but generating them in numpy costs more than the convolutions and would
+    make the reference's CPU path look several times slower than it is."""
 
     ctx = None
+    native_rng = False
 
     def forward(self, x):
+        if MCDropout.native_rng:
+            self.ctx.next_site()
+            return torch.nn.functional.dropout(x, self.p, True)
         return philox_dropout(self.ctx, x, self.p)
 
 

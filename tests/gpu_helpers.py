@@ -66,12 +66,12 @@ def conv_ref(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod):
 
 
 def run_conv(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod, site=None, batch=None, t0=0, seed=0, cnt0=0,
-             in_bits=None, out_mul=1.0):
+             in_bits=None, out_mul=1.0, out_dtype=torch.float16):
     lib = _lib.lib()
     n_in, H, W, cin = x.shape
     cout, k = w.shape[0], w.shape[1]
     ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    out = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.float16, device=DEV)
+    out = torch.full((n, ho, wo, cout), float("nan"), dtype=out_dtype, device=DEV)
     keep = []
     s = site_struct(site, keep)
     rc = lib.bmi_conv_igemm_fwd(ptr(x), ptr(in_bits), float(out_mul), ptr(w), ptr(scale), ptr(bias), ptr(res), ptr(out), n, in_mod, res_mod, H, W, cin,

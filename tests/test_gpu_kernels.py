@@ -500,3 +500,72 @@ def test_dense_f32(in_f32, kind, relu):
     torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-5)
     assert lib.bmi_dense_f32(gh.ptr(xd), in_f32, gh.ptr(wd), gh.ptr(bd), gh.ptr(out), N, in_mod, K, 200, relu, None, B, t0,
                              seed, cnt0, gh.stream()) == -95
+
+
+@pytest.fixture
+def bf16_entries():
+    _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    yield
+    _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+
+
+@pytest.mark.parametrize("name", ["S1", "S2", "S3", "S4", "D3", "D4", "P4"])
+def test_bf16_conv_shape_classes(name, bf16_entries):
+    """The bf16 instantiations (v_mfma_f32_16x16x32_bf16 in conv3x3_patch / conv_igemm_wide, 32x32x16_bf16 in conv_igemm) on
+    bf16-rounded operands against the fp32 reference: only the output rounding (2^-9 relative) separates them.  With
+    residual + ReLU + a fused elementwise site (general epilogue) for the S classes, plain epilogue for the others."""
+    cin, cout, H, k, s, p = SHAPES[name]
+    B, tc, t0, seed = 3, 2, 1, 77
+    n = B * tc
+    g = _gen(13)
+    x = torch.randn(n, H, H, cin, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(torch.bfloat16).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    ho = (H + 2 * p - k) // s + 1
+    general = name.startswith("S")
+    res = torch.randn(n, ho, ho, cout, generator=g).to(torch.bfloat16).to(DEV) if general else None
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=3, p=0.25) if general else None
+    out = gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=B, t0=t0, seed=seed, out_dtype=torch.bfloat16)
+    ref = gh.conv_ref(x, w, scale, bias, res, True, s, p, n, n, n)
+    if site is not None:
+        mult = gh.folded_site_mask(site, B, cout, ho, ho, tc, t0, seed)
+        ref = ref * mult
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2)
+    if site is not None:
+        assert torch.equal(got[mult == 0], torch.zeros_like(got[mult == 0])) and (mult == 0).any()
+
+
+def test_bf16_elementwise_kernels(bf16_entries):
+    """mask_apply (lane-shared Philox path), maxpool2, pool_mask and dense_f32 reading / writing bfloat16 bits."""
+    lib = _lib.lib()
+    B, tc, H, Cc, t0, seed = 2, 3, 16, 64, 0, 5
+    N = B * tc
+    g = _gen(4)
+    x = torch.randn(B, H, H, Cc, generator=g).to(torch.bfloat16).to(DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=0, p=0.25)
+    keep = []
+    s = gh.site_struct(site, keep)
+    out = torch.empty(N, H, H, Cc, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.bmi_mask_apply(gh.ptr(x), gh.ptr(out), N, B, H * H, Cc, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_mask_apply")
+    mult = gh.folded_site_mask(site, B, Cc, H, H, tc, t0, seed).permute(0, 2, 3, 1)
+    want = (x.float().cpu()[torch.arange(N) % B] * mult).to(torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), want)
+    mp = torch.empty(N, H // 2, H // 2, Cc, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.bmi_maxpool2(gh.ptr(out), gh.ptr(mp), N, H, H, Cc, gh.stream()), "bmi_maxpool2")
+    torch.cuda.synchronize()
+    assert torch.equal(mp.cpu().float(), torch.nn.functional.max_pool2d(out.cpu().float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+    feat = torch.empty(N, Cc, device=DEV)
+    _lib.check(lib.bmi_pool_mask(gh.ptr(out), gh.ptr(feat), N, N, H * H, Cc, None, B, t0, seed, 0, gh.stream()), "bmi_pool_mask")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(feat.cpu(), torch.relu(out.cpu().float()).mean((1, 2)), rtol=1e-5, atol=1e-6)
+    flat = out.reshape(N, -1)[:, :512].contiguous()
+    w = 0.05 * torch.randn(128, 512, generator=g)
+    wd, bd = w.to(DEV), torch.zeros(128, device=DEV)        # (named: a temporary's memory is recycled by the next allocation)
+    d = torch.empty(N, 128, device=DEV)
+    _lib.check(lib.bmi_dense_f32(gh.ptr(flat), 0, gh.ptr(wd), gh.ptr(bd), gh.ptr(d), N, N, 512, 128, 0, None, B, 0, 0, 0,
+                                 gh.stream()), "bmi_dense_f32")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(d.cpu().double(), flat.cpu().double() @ w.double().T, rtol=1e-5, atol=2e-5)
