@@ -10,9 +10,11 @@ What is mirrored (same method names, argument meaning and return shapes):
   * ``all_experiments`` + ``saver`` :288-337, :508-541 — per-exit and per-ensemble accuracy, cumulative /
                                       unique correct, destructive overthinking, ECE, NLL, MSE; the
                                       ``test_evaluation_log_*.txt`` CSV rows and the 3-array ``.npy`` file.
-Differences, on purpose: ECE is the 15-bin equal-mass histogram ECE (``ece_hist_binary`` :446-495) because
-the reference's KDE-ECE needs KDEpy (parity unpinned); trackers are vectorised instead of the
-per-instance Python loop (:272-286); the extra output ``var`` (T-sample variance) is kept in ``self.var``.
+ECE is the reference's KDE-ECE (``ece_eval_binary`` :497-505 -> ``ece_kde_binary`` :351-443) with KDEpy's FFTKDE restated
+in ``metrics.py`` (parity unpinned: KDEpy is absent); ``ece="hist"`` selects the 15-bin equal-mass histogram ECE
+(``ece_hist_binary`` :446-495, pinned to the reference, but never called by it).  Differences, on purpose: trackers are
+vectorised instead of the per-instance Python loop (:272-286); the extra output ``var`` (T-sample variance) is kept in
+``self.var``.
   * ``save_validation``             :217-222 — the same 3-array ``.npy`` for a validation loader.
   * ``get_confidence_exiting_values`` :543-566 with ``get_model_type`` :598-604, ``get_dropout_type`` :582-595,
                                       ``get_flops_per_module`` :568-580 — the threshold sweep over the saved test
@@ -38,9 +40,9 @@ def exit_ensembles(per_exit):
 
 
 class FullAnalysis:
-    def __init__(self, model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="", seed=0, ece="hist"):
-        self.ece_kind = ece          # "hist" (pinned to the reference's ece_hist_binary) | "kde" (reference's headline
-                                     # estimator, direct evaluation, parity unpinned)
+    def __init__(self, model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="", seed=0, ece="kde"):
+        self.ece_kind = ece          # "kde": what the reference's ece_eval_binary returns (:503; FFTKDE restated, parity
+                                     # unpinned) | "hist": ece_hist_binary (pinned to the reference, unused by it)
         self.model = model
         self.loader = test_loader
         self.gpu = gpu
@@ -137,9 +139,9 @@ class FullAnalysis:
         return preds, ens, labels
 
     def ece_eval_binary(self, p, label):
-        """(ECE, NLL, MSE, accuracy) — :497-505 with the histogram ECE in place of the KDE ECE."""
+        """(ECE, NLL, MSE, accuracy) — :497-505; the ECE is the KDE-ECE like the reference's unless ``ece="hist"``."""
         nll, mse, acc = nll_mse_acc(p, label)
-        ece = ece_kde_binary(p, label) if getattr(self, "ece_kind", "hist") == "kde" else ece_hist_binary(p, label)
+        ece = ece_hist_binary(p, label) if getattr(self, "ece_kind", "kde") == "hist" else ece_kde_binary(p, label)
         return ece, nll, mse, acc
 
     def all_experiments(self, experiment_id, write=True):

@@ -112,6 +112,28 @@ def test_confidence_exiting_matches_reference():
     assert len(rows) == 11 and rows[0]["flops"] <= rows[-1]["flops"]
 
 
+def test_fftkde_restatement_matches_the_exact_kde():
+    """KDEpy.FFTKDE restated (linear binning on the caller's grid + convolution with the kernel sampled at grid spacing):
+    within the binning error of the exact triweight KDE, integrates to 1, zero beyond the support, raises KDEpy's
+    ValueError for data outside the grid, and the ECE built on it equals the exactly evaluated one to ~1e-6."""
+    from bayesnn_fpga_amd.train.metrics import _triweight_kde, ece_kde_binary, fftkde_triweight
+    rng = np.random.RandomState(0)
+    d = rng.beta(5, 2, 4000)
+    x = np.linspace(-0.6, 1.6, 2 ** 14)
+    f, e = fftkde_triweight(d, 0.02, x), _triweight_kde(d, 0.02, x)
+    assert np.abs(f - e).max() < 1e-5 * e.max()
+    assert abs(np.sum((f[1:] + f[:-1]) / 2 * np.diff(x)) - 1.0) < 1e-9
+    assert np.abs(f[x < d.min() - 0.0601]).max() < 1e-12 and (f > -1e-12).all()       # (scipy picks the FFT route: +-1e-16)
+    with pytest.raises(ValueError, match="inside of the grid"):
+        fftkde_triweight(np.array([0.5, 1.7]), 0.02, x)
+    # a bandwidth below the grid spacing degenerates to the binned histogram (L = 0), like KDEpy
+    h = fftkde_triweight(np.array([0.25]), 1e-9, x)
+    assert np.count_nonzero(np.abs(h) > 1e-6 * h.max()) == 2
+    g = load_golden("metrics.npz")
+    a, b = ece_kde_binary(g["p"], g["onehot"]), ece_kde_binary(g["p"], g["onehot"], method="direct")
+    assert abs(a - b) < 1e-6
+
+
 def test_kde_ece_properties_unpinned():
     """KDE-ECE is NOT pinned to the reference (KDEpy absent): only estimator properties are checked."""
     from bayesnn_fpga_amd.train.metrics import ece_kde_binary
