@@ -14,9 +14,9 @@ SITE_NONE, SITE_ELEMENTWISE, SITE_CHANNEL, SITE_MASKSEMBLE = 0, 1, 2, 3
 SITE_POS_OUTER, SITE_POS_INNER = 0, 1
 DTYPE_F16, DTYPE_BF16 = 0, 1
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
-PROFILE_SLOTS = 10
+PROFILE_SLOTS = 8
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
-                 OP_DENSE: "dense", 8: "moments", 9: "finalize"}
+                 OP_DENSE: "dense"}
 
 
 class Site(C.Structure):
@@ -75,13 +75,11 @@ _PROTOS = {
     "bmi_mask_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
                                  C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
     "bmi_maxpool2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
-    "bmi_pool_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
-                                C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
-    "bmi_linear_softmax": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
-    "bmi_linear_softmax_site": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.POINTER(Site), C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
+    "bmi_head_fused": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.POINTER(Site), C.POINTER(Site), C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bmi_dense_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 5 +
                       [C.POINTER(Site), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),
-    "bmi_moments_accumulate": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
 }
 
 EXPORTS = tuple(_PROTOS.keys())

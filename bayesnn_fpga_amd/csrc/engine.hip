@@ -63,8 +63,7 @@ struct bmi_engine_s {
     int64_t prefix_macs = 0, suffix_macs = 0;
     // plan
     int max_batch = 0, chunk = 0;
-    size_t ws_bytes = 0, feat_off = 0, probs_off = 0, logits_off = 0;
-    int max_head_k = 0;
+    size_t ws_bytes = 0;
     // profiling
     bool profiling = false;
     double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0};
@@ -340,7 +339,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 if (d.in == 0 || d.out < 0 || d.out >= desc->n_exits || exit_seen[d.out] || !d.weight || !d.bias) {
                     rc = BMI_ERR_INVALID; break;
                 }
-                if (tin.c % 8 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                if (tin.c % 32 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }   // head_fused splits K over 4 waves x 2 lane halves x float4
                 if (d.site_pos == BMI_SITE_POS_INNER && d.site.kind != BMI_SITE_NONE && d.site.kind != BMI_SITE_ELEMENTWISE) {
                     rc = BMI_ERR_UNSUPPORTED; break;   // dropout on the logits is elementwise (F.dropout after nn.Linear)
                 }
@@ -349,7 +348,6 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 op.cout = desc->out_dim;
                 e->suffix.push_back(op);
                 e->suffix_macs += (int64_t)tin.c * desc->out_dim;
-                e->max_head_k = std::max(e->max_head_k, tin.c);
                 break;
             }
             default: rc = BMI_ERR_INVALID;
@@ -493,12 +491,6 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
         st_peak = std::max(st_peak, pos + size);
     }
     off = st_base + st_peak;
-    h->feat_off = off;
-    off += align_up(NS * (size_t)std::max(h->max_head_k, 8) * 4, 256);
-    h->probs_off = off;
-    off += align_up((size_t)h->n_exits * NS * h->out_dim * 4, 256);
-    h->logits_off = off;
-    off += align_up((size_t)h->n_exits * NS * h->out_dim * 4, 256);
     h->ws_bytes = off;
     h->max_batch = max_batch;
     h->chunk = chunk_samples;
@@ -544,7 +536,7 @@ struct ProfScope {
 };
 
 int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, int B, int t0, uint64_t seed, int cnt0,
-           float* feat, float* probs, float* logits, hipStream_t s) {
+           double* S1, double* S2, double* SL, hipStream_t s) {
     const bmi_op_desc& d = op.d;
     const TensorInfo& tin = e->tensors[d.in];
     ProfScope prof(e, d.kind == OP_MASKBITS ? BMI_OP_MASK : d.kind, s);
@@ -628,20 +620,20 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                                     (float*)(ws + e->tensors[d.out].offset), N, tin.stoch ? N : B, tin.c, op.cout, d.relu,
                                     resolve_site(&d.site, seed, cnt0), B, t0, s);
         case BMI_OP_HEAD: {
-            EltArgs a;
+            // pool + site + Linear + softmax + the chunk's moment sums in one launch (head_fused.hip)
+            HeadArgs a;
             std::memset(&a, 0, sizeof(a));
-            a.in = (const _Float16*)(ws + tin.offset);
-            a.bf16 = e->bf16;
-            a.in_f32 = tin.f32 ? 1 : 0;
-            a.out = feat;
-            a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
+            a.in = ws + tin.offset;
+            a.in_kind = tin.f32 ? 1 : (e->bf16 ? 2 : 0);
+            a.in_mod = tin.stoch ? N : B;
+            a.HW = tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = N / B;
+            a.w = (const float*)d.weight; a.bias = d.bias; a.C = e->out_dim;
             const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
             a.site = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0);
-            int rc = launch_pool_mask(a, s);
-            if (rc != BMI_OK) return rc;
-            const size_t eo = (size_t)d.out * N * e->out_dim;
-            return launch_linear_softmax(feat, (const float*)d.weight, d.bias, logits + eo, probs + eo, N, tin.c, e->out_dim,
-                                         resolve_site(on_logits ? &d.site : nullptr, seed, cnt0), B, t0, s);
+            a.site_logits = resolve_site(on_logits ? &d.site : nullptr, seed, cnt0);
+            const size_t eo = (size_t)d.out * B * e->out_dim;
+            a.S1 = S1 + eo; a.S2 = S2 + eo; a.SL = SL + eo;
+            return launch_head_fused(a, s);
         }
     }
     return BMI_ERR_INVALID;
@@ -660,24 +652,17 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
     if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    float* feat = (float*)(ws + h->feat_off);
-    float* probs = (float*)(ws + h->probs_off);
-    float* logits = (float*)(ws + h->logits_off);
     for (const OpInfo& op : h->prefix) {
-        const int rc = run_op(h, op, x_nchw, ws, batch, batch, 0, seed, mask_cnt0, feat, probs, logits, s);
+        const int rc = run_op(h, op, x_nchw, ws, batch, batch, 0, seed, mask_cnt0, S1, S2, SL, s);
         if (rc != BMI_OK) return rc;
     }
     for (int t0 = t_begin; t0 < t_begin + t_count; t0 += h->chunk) {
         const int tc = std::min(h->chunk, t_begin + t_count - t0);
         const int N = tc * batch;
         for (const OpInfo& op : h->suffix) {
-            const int rc = run_op(h, op, x_nchw, ws, N, batch, t0, seed, mask_cnt0, feat, probs, logits, s);
+            const int rc = run_op(h, op, x_nchw, ws, N, batch, t0, seed, mask_cnt0, S1, S2, SL, s);
             if (rc != BMI_OK) return rc;
         }
-        ProfScope prof(h, BMI_PROFILE_SLOT_MOMENTS, s);
-        const int rc = launch_moments(probs, logits, S1, S2, SL, tc, batch, h->out_dim, h->n_exits,
-                                      (size_t)N * h->out_dim, (size_t)batch * h->out_dim, s);
-        if (rc != BMI_OK) return rc;
     }
     return BMI_OK;
 }
@@ -826,29 +811,6 @@ int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int
     return launch_maxpool2((const _Float16*)in, (_Float16*)out, n, h, w, c, opt_unit_dtype() == BMI_DTYPE_BF16, (hipStream_t)stream);
 }
 
-int bmi_pool_mask(const void* in, float* feat, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
-                  int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
-    EltArgs a;
-    const int rc = elt_args(a, in, feat, n, in_mod, hw, c, site, batch, t0, seed, mask_cnt0);
-    return rc != BMI_OK ? rc : launch_pool_mask(a, (hipStream_t)stream);
-}
-
-int bmi_linear_softmax(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
-                       int32_t n, int32_t k, int32_t out_dim, bmi_stream stream) {
-    if (!feat || !weight_pad || !bias || !logits || !probs) return BMI_ERR_INVALID;
-    return launch_linear_softmax(feat, weight_pad, bias, logits, probs, n, k, out_dim, resolve_site(nullptr, 0, 0), n, 0,
-                                 (hipStream_t)stream);
-}
-
-int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
-                            int32_t n, int32_t k, int32_t out_dim, const bmi_site* site, int32_t batch, int32_t t0,
-                            uint64_t seed, bmi_stream stream) {
-    if (!feat || !weight_pad || !bias || !logits || !probs || batch < 1) return BMI_ERR_INVALID;
-    if (site && !site_ok(*site)) return BMI_ERR_INVALID;
-    return launch_linear_softmax(feat, weight_pad, bias, logits, probs, n, k, out_dim, resolve_site(site, seed, 0), batch, t0,
-                                 (hipStream_t)stream);
-}
-
 int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const float* bias, float* out, int32_t n,
                   int32_t in_mod, int32_t k, int32_t cout, int32_t relu, const bmi_site* site, int32_t batch, int32_t t0,
                   uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
@@ -858,10 +820,20 @@ int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const 
                             t0, (hipStream_t)stream);
 }
 
-int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,
-                           int32_t batch, int32_t out_dim, bmi_stream stream) {
-    if (!probs || !logits || !S1 || !S2 || !SL) return BMI_ERR_INVALID;
-    return launch_moments(probs, logits, S1, S2, SL, tc, batch, out_dim, 1, 0, 0, (hipStream_t)stream);
+int bmi_head_fused(const void* in, int32_t in_is_f32, int32_t in_mod, int32_t hw, int32_t k, const float* weight_pad,
+                   const float* bias, int32_t out_dim, const bmi_site* site, const bmi_site* site_logits, int32_t batch, int32_t t0,
+                   int32_t tc, uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL, bmi_stream stream) {
+    if ((site && !site_ok(*site)) || (site_logits && !site_ok(*site_logits))) return BMI_ERR_INVALID;
+    HeadArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.in_kind = in_is_f32 ? 1 : (opt_unit_dtype() == BMI_DTYPE_BF16 ? 2 : 0);
+    a.in_mod = in_mod; a.HW = hw; a.K = k; a.B = batch; a.t0 = t0; a.tc = tc;
+    a.w = weight_pad; a.bias = bias; a.C = out_dim;
+    a.site = resolve_site(site, seed, mask_cnt0);
+    a.site_logits = resolve_site(site_logits, seed, mask_cnt0);
+    a.S1 = S1; a.S2 = S2; a.SL = SL;
+    return launch_head_fused(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

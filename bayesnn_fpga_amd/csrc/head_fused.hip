@@ -1,0 +1,246 @@
+// Exit head, fused: relu -> global average pool -> [site] -> Linear -> [site on the logits] -> softmax -> T-sample moments
+// in ONE kernel per exit (ex{1,2,3}linear / linear with their avg_pool2d / exit dropout, SA/models/resnet18/resnet18.py:
+// 309-314, :320-325, :331-335, :338-344; the softmax and the np.average over the passes of FullAnalysis._get_output,
+// SA/train/results_analyzer.py:242-248).  Round 1 ran this as pool_mask + linear_softmax + a per-sample [E][N][C]
+// probability / logit scratch + a moments kernel (9 launches per chunk); here nothing per-sample is materialised.
+//
+//   workgroup   = one image b of the batch x one group of 32 of the launch's samples, 256 threads (one workgroup per image
+//                 walking all groups left 250 workgroups of latency-bound work on 256 CUs: 2x slower than the three kernels
+//                 it replaced); the groups of an image meet in S1/S2/SL[b][:] by hardware float64 atomic adds (<= 4 per
+//                 address and launch at T = 100).
+//   phase A     = pooling, coalesced: wave w pools columns (samples) 8w..8w+7 of the group, lane = one 8-channel group
+//                 (16 B per pixel row: 64 lanes cover a 512-channel row = 1 KB contiguous), ReLU + mean in fp32, the
+//                 feature-side site (MC dropout / Masksembles1D on the [B, K] tensor), then fp32 into LDS
+//                 feat[32 samples][KC] with the 16-byte chunks XOR-swizzled by the sample index.
+//   phase B     = logits[class][sample] on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), classes on the row axis, the 32
+//                 samples on the column axis; the 4 waves split K, partial sums meet in LDS.
+//   finalize    = wave 0: bias, [dropout on the logits], softmax in registers (one cross-half shuffle) -> LDS [class][sample];
+//                 then all waves: the sums over the group's samples of p, p^2 and logit by WAVEFRONT SHUFFLE REDUCTION in
+//                 float64 (32 lanes = 32 samples of one class; the reference averages in float64; per-sample values are
+//                 bit-identical however the samples are chunked or sharded, so only the float64 summation order depends
+//                 on it: <= 1e-13 relative).
+#include "conv_epilogue.h"
+#include "kernels.h"
+
+typedef float f32x16_h __attribute__((ext_vector_type(16)));
+typedef float f32x4_h __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_h __attribute__((ext_vector_type(8)));
+
+#define HEAD_KC 512                       // K chunk held in LDS (floats per sample)
+#define HEAD_FEAT_BYTES (32 * HEAD_KC * 4)
+
+// KIND: 0 fp16, 1 fp32, 2 bf16 input tensor
+template <int RT, int KIND>
+__global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[HEAD_FEAT_BYTES + 4 * RT * 16 * 64 * 4];
+    float* const feat = (float*)smem;
+    float* const part = (float*)(smem + HEAD_FEAT_BYTES);     // [4 waves][RT][16 regs][64 lanes]
+
+    const int b = blockIdx.x;
+    const int g = blockIdx.y;                                  // this workgroup's group of 32 samples
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int K = a.K, C = a.C;
+    const float inv_hw = 1.0f / (float)a.HW;
+    {
+        f32x16_h acc[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+        for (int k0 = 0; k0 < K; k0 += HEAD_KC) {
+            const int kc = min(HEAD_KC, K - k0);               // multiple of 32
+            const int swz = (kc & 63) == 0 ? 15 : 7;          // the XOR must stay inside the row's kc / 4 chunks
+            // this wave's slice of the classifier weights is requested BEFORE the pooling pass (its L2 latency hides under
+            // phase A); RT <= 2 only: 16 float4 per class tile and lane
+            const int kq = kc >> 3;                            // k per (wave, half): multiple of 4, <= 64
+            const int koff = wave * (kc >> 2) + hh * kq;
+            const float* wp = a.w + (size_t)r * K + k0 + koff;
+            f32x4_h wpre[RT <= 2 ? RT : 1][16];
+            if constexpr (RT <= 2) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        wpre[i][q] = 4 * q < kq ? *(const f32x4_h*)(wp + (size_t)(32 * i) * K + 4 * q) : f32x4_h{0.f, 0.f, 0.f, 0.f};
+            }
+            // ---- phase A: pool 8 samples per wave into LDS ----
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = wave * 8 + jj;
+                const int tl = g * 32 + j;
+                const int c8 = lane;
+                if (c8 * 8 < kc) {
+                    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (tl < a.tc) {
+                        const int n = tl * a.B + b;
+                        const size_t row0 = (size_t)(n % a.in_mod) * a.HW * K + k0 + c8 * 8;
+#pragma unroll 8
+                        for (int p = 0; p < a.HW; ++p) {
+                            if constexpr (KIND == 1) {
+                                const float* src = (const float*)a.in + row0 + (size_t)p * K;
+                                const f32x4_h x0 = *(const f32x4_h*)src, x1 = *(const f32x4_h*)(src + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += fmaxf(x0[e], 0.f); v[4 + e] += fmaxf(x1[e], 0.f); }
+                            } else {
+                                const half8_h x = *(const half8_h*)((const _Float16*)a.in + row0 + (size_t)p * K);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += fmaxf(a16_to_f32<KIND == 2>(x[e]), 0.f);   // F.relu before the pool
+                            }
+                        }
+                        const int t = a.t0 + tl;
+                        const int kk = k0 + c8 * 8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= inv_hw;
+                        if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
+                            // [B, K] tensor: element = b*K + k (a per-(image, channel) draw is the same thing here)
+                            const uint32_t keep = site_keep8(a.site, (uint64_t)b * K + kk, (uint32_t)t);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * a.site.scale : 0.f;
+                        } else if (a.site.kind == BMI_SITE_MASKSEMBLE) {
+                            const float* mrow = a.site.masks + (size_t)((a.site.cnt0 + t) % a.site.num_masks) * K + kk;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= mrow[e];
+                        }
+                    }
+                    float* dst = feat + j * kc;
+                    *(f32x4_h*)(dst + (((2 * c8) ^ (j & swz)) << 2)) = f32x4_h{v[0], v[1], v[2], v[3]};
+                    *(f32x4_h*)(dst + (((2 * c8 + 1) ^ (j & swz)) << 2)) = f32x4_h{v[4], v[5], v[6], v[7]};
+                }
+            }
+            __syncthreads();
+            // ---- phase B: this wave's quarter of the chunk's K, lane half hh takes half of that ----
+            {
+                const float* fr = feat + r * kc;
+                if constexpr (RT <= 2) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if (4 * q < kq) {
+                            const f32x4_h b4 = *(const f32x4_h*)(fr + ((((koff + 4 * q) >> 2) ^ (r & swz)) << 2));
+#pragma unroll
+                            for (int i = 0; i < RT; ++i) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wpre[i][q][e], b4[e], acc[i], 0, 0, 0);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll 4
+                    for (int s = 0; s < kq; s += 4) {
+                        const f32x4_h b4 = *(const f32x4_h*)(fr + ((((koff + s) >> 2) ^ (r & swz)) << 2));
+#pragma unroll
+                        for (int i = 0; i < RT; ++i) {
+                            const f32x4_h a4 = *(const f32x4_h*)(wp + (size_t)(32 * i) * K + s);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                   // feat is free for the next chunk
+        }
+        // ---- the four K-quarters meet in LDS ----
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[((wave * RT + i) * 16 + e) * 64 + lane] = acc[i][e];
+        __syncthreads();
+        float* const pb_p = part;                              // [class][33]: softmax of the group's 32 samples (aliases `part`:
+        float* const pb_l = part + 32 * RT * 33;               //  wave 0 has read all of it before it writes) and their logits
+        if (wave == 0) {
+            const int tl = g * 32 + r;
+            const uint32_t t = (uint32_t)(a.t0 + tl);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    float v = acc[i][e];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) v += part[((w * RT + i) * 16 + e) * 64 + lane];
+                    if (c < C) {
+                        v += a.bias[c];
+                        if (a.site_logits.kind == BMI_SITE_ELEMENTWISE) {
+                            // dropout on the logits (converter/pytorch wraps the last Linear too, nn2bnn.py:33-45):
+                            // [B, C] tensor, element = b*C + c
+                            const uint64_t elem = (uint64_t)b * C + c;
+                            const uint32_t keep = site_keep8(a.site_logits, elem & ~(uint64_t)7, t);
+                            v = ((keep >> (elem & 7)) & 1u) ? v * a.site_logits.scale : 0.f;
+                        }
+                        mx = fmaxf(mx, v);
+                    }
+                    acc[i][e] = v;
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const float ex = c < C ? expf(acc[i][e] - mx) : 0.f;
+                    sum += ex;
+                    if (c < C) { pb_l[c * 33 + r] = acc[i][e]; pb_p[c * 33 + r] = ex; }
+                }
+            sum += __shfl_xor(sum, 32);
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (c < C) pb_p[c * 33 + r] = pb_p[c * 33 + r] / sum;      // same quotient the per-sample path stored
+                }
+        }
+        __syncthreads();
+        // ---- moments: 32 lanes = the group's 32 samples of one class; float64 wavefront-shuffle butterfly; two classes per
+        //      wave and step; one hardware f64 atomic add per (class, quantity) joins the image's groups ----
+        {
+            const int ts = lane & 31;
+            const bool live = g * 32 + ts < a.tc;
+            for (int c0 = 0; c0 < C; c0 += 8) {
+                const int c = c0 + wave * 2 + (lane >> 5);
+                const bool ok = live && c < C;
+                const double p = ok ? (double)pb_p[c * 33 + ts] : 0.0;
+                double s1 = p, s2 = p * p, sl = ok ? (double)pb_l[c * 33 + ts] : 0.0;
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) {
+                    s1 += __shfl_xor(s1, m);
+                    s2 += __shfl_xor(s2, m);
+                    sl += __shfl_xor(sl, m);
+                }
+                if (ts == 0 && c < C) {
+                    const size_t o = (size_t)b * C + c;
+                    unsafeAtomicAdd(a.S1 + o, s1);
+                    unsafeAtomicAdd(a.S2 + o, s2);
+                    unsafeAtomicAdd(a.SL + o, sl);
+                }
+            }
+        }
+    }
+}
+
+template <int RT>
+static void launch_rt(const HeadArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)a.B, (unsigned)((a.tc + 31) / 32)), block(256);
+    if (a.in_kind == 1) hipLaunchKernelGGL((head_fused_kernel<RT, 1>), grid, block, 0, s, a);
+    else if (a.in_kind == 2) hipLaunchKernelGGL((head_fused_kernel<RT, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((head_fused_kernel<RT, 0>), grid, block, 0, s, a);
+}
+
+int launch_head_fused(const HeadArgs& a, hipStream_t s) {
+    if (!a.in || !a.w || !a.bias || !a.S1 || !a.S2 || !a.SL) return BMI_ERR_INVALID;
+    if (a.B <= 0 || a.tc <= 0 || a.in_mod <= 0 || a.HW <= 0 || a.C <= 0 || a.in_kind < 0 || a.in_kind > 2) return BMI_ERR_INVALID;
+    if (a.in_mod != a.B && a.in_mod != a.B * a.tc) return BMI_ERR_INVALID;
+    if (a.K % 32 != 0 || a.C > 128) return BMI_ERR_UNSUPPORTED;
+    if (a.site_logits.kind != BMI_SITE_NONE && a.site_logits.kind != BMI_SITE_ELEMENTWISE) return BMI_ERR_UNSUPPORTED;
+    switch ((a.C + 31) / 32) {
+        case 1: launch_rt<1>(a, s); break;
+        case 2: launch_rt<2>(a, s); break;
+        case 3: launch_rt<3>(a, s); break;
+        default: launch_rt<4>(a, s); break;
+    }
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}

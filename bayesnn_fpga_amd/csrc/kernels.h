@@ -46,17 +46,31 @@ struct ConvArgs {
     SiteArgs site;
 };
 
-struct EltArgs {  // MASK / POOL ops
+struct EltArgs {  // MASK op
     int bf16;     // 16-bit tensors hold bfloat16 bits
     const _Float16* in;
-    int in_f32;   // POOL: `in` is an fp32 [N][HW][C] tensor (a dense layer's output)
-    void* out;    // MASK: fp16 [N][HW][C]; POOL: fp32 [N][C]
+    void* out;    // fp16 [N][HW][C]
     int N, in_mod, HW, C;
     int B, t0;
     SiteArgs site;
     const float* bias_post;  // MASK with an inner site: out = relu?(x * mask + bias_post[c]); or null
     int relu;
 };
+
+struct HeadArgs {   // fused exit head (head_fused.hip)
+    const void* in;      // [N or in_mod][HW][K]; in_kind 0: fp16, 1: fp32, 2: bf16
+    int in_kind;
+    int in_mod;          // B (deterministic input: every sample reads the same image) or B * tc
+    int HW, K;
+    int B, t0, tc;       // images per sample, first sample index, samples in this launch
+    const float* w;      // fp32 [ceil32(C)][K], rows >= C zero
+    const float* bias;   // fp32 [C]
+    int C;               // out_dim
+    SiteArgs site;        // on the pooled [B, K] features
+    SiteArgs site_logits; // ELEMENTWISE dropout on the [B, C] logits, or NONE
+    double *S1, *S2, *SL; // this exit's [B][C] moment accumulators
+};
+int launch_head_fused(const HeadArgs& a, hipStream_t s);
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s);  // 256x256 tiles; BMI_ERR_UNSUPPORTED -> conv_igemm
@@ -66,16 +80,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int* family = nullptr);   // p
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int bf16, hipStream_t s);
 int launch_mask_apply(const EltArgs& a, hipStream_t s);
-int launch_pool_mask(const EltArgs& a, hipStream_t s);
 int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, int bf16, hipStream_t s);
-// `site` (kind NONE to skip): dropout on the LOGITS ([B, out_dim] tensor: element = b*out_dim + c), sample n / batch
-int launch_linear_softmax(const float* feat, const float* w, const float* bias, float* logits, float* probs, int n,
-                          int k, int out_dim, const SiteArgs& site, int batch, int t0, hipStream_t s);
 // hidden dense layer, fp32 weights [cout][k] / accumulate / output; `in` 16-bit (in_kind 0: fp16, 2: bf16) or fp32 (1) [n or in_mod][k]
 int launch_dense_f32(const void* in, int in_kind, const float* w, const float* bias, float* out, int n, int in_mod, int k,
                      int cout, int relu, const SiteArgs& site, int batch, int t0, hipStream_t s);
-int launch_moments(const float* probs, const float* logits, double* S1, double* S2, double* SL, int tc, int batch,
-                   int out_dim, int n_exits, size_t exit_stride_scratch, size_t exit_stride_S, hipStream_t s);
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);

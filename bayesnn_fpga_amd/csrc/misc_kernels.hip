@@ -3,10 +3,7 @@
 //                  (ResNet stem, SA/models/resnet18/resnet18.py:303: no ReLU after bn1)
 //   mask_apply     stand-alone stochastic site; also expands a deterministic tensor [B,...] to
 //                  the folded [samples*B,...] batch (MCDropout :207-210 / Masksembles2D utils.py:165-169)
-//   pool_mask      F.avg_pool2d(F.relu(x), HxW) + flatten + exit dropout (:309-313) -> fp32 features
 //   maxpool2       VGG block-end MaxPool2d(2,2) (SA/models/vgg19/vgg19.py:127)
-//   moments        S1 += p, S2 += p^2, SL += logit over the samples of a chunk (float64;
-//                  results_analyzer.py:247-248 averages in float64)
 //   finalize       mean / variance / mean logit
 //   philox_mask    keep bits, for unit tests
 #include <cstdlib>
@@ -188,55 +185,6 @@ int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename TIN, bool BF>
-__global__ __launch_bounds__(256) void pool_mask_kernel(EltArgs a) {
-    const int cg = a.C >> 3;
-    const long total = (long)a.N * cg;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c8 = (int)(i % cg) * 8;
-    const int n = (int)(i / cg);
-    const int tl = n / a.B, b = n - tl * a.B;
-    const int t = a.t0 + tl;
-    const TIN* src = (const TIN*)a.in + (size_t)(n % a.in_mod) * a.HW * a.C + c8;
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = 0; p < a.HW; ++p) {
-        if constexpr (sizeof(TIN) == 2) {
-            const half8 x = *(const half8*)(src + (size_t)p * a.C);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += fmaxf(a16_to_f32<BF>(x[e]), 0.f);  // F.relu before the pool
-        } else {
-            const float4 x0 = *(const float4*)(src + (size_t)p * a.C), x1 = *(const float4*)(src + (size_t)p * a.C + 4);
-            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += fmaxf(x[e], 0.f);
-        }
-    }
-    const float inv = 1.0f / (float)a.HW;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= inv;
-    const float* mrow = a.site.kind == BMI_SITE_MASKSEMBLE
-                            ? a.site.masks + (size_t)((a.site.cnt0 + t) % a.site.num_masks) * a.C + c8
-                            : nullptr;
-    site_mask8(a.site, v, (uint64_t)b * a.C + c8, t, mrow);  // [B, C] tensor: element = b*C + c
-    float* o = (float*)a.out + (size_t)n * a.C + c8;
-    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-
-int launch_pool_mask(const EltArgs& a, hipStream_t s) {
-    if (a.C % 8 != 0) return BMI_ERR_UNSUPPORTED;
-    if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || a.HW <= 0) return BMI_ERR_INVALID;
-    const long total = (long)a.N * (a.C >> 3);
-    const dim3 g((unsigned)((total + 255) / 256)), b(256);
-    if (a.in_f32) hipLaunchKernelGGL((pool_mask_kernel<float, false>), g, b, 0, s, a);
-    else if (a.bf16) hipLaunchKernelGGL((pool_mask_kernel<_Float16, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((pool_mask_kernel<_Float16, false>), g, b, 0, s, a);
-    BMI_CHECK_LAUNCH();
-    return BMI_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
 template <bool BF>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C) {
     const int cg = C >> 3, Ho = H >> 1, Wo = W >> 1;
@@ -336,37 +284,6 @@ int launch_stem_conv(const float* x, const float* w, const float* scale, const f
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
-                                                      double* S1, double* S2, double* SL, int tc, int BC_,
-                                                      size_t exit_stride_scratch, size_t exit_stride_S) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // b*C + c
-    if (i >= BC_) return;
-    const int e = blockIdx.y;
-    const float* p = probs + e * exit_stride_scratch + i;
-    const float* l = logits + e * exit_stride_scratch + i;
-    double s1 = 0, s2 = 0, sl = 0;
-    for (int t = 0; t < tc; ++t) {
-        const double pv = (double)p[(size_t)t * BC_];
-        s1 += pv;
-        s2 += pv * pv;
-        sl += (double)l[(size_t)t * BC_];
-    }
-    const size_t o = e * exit_stride_S + i;
-    S1[o] += s1;
-    S2[o] += s2;
-    SL[o] += sl;
-}
-
-int launch_moments(const float* probs, const float* logits, double* S1, double* S2, double* SL, int tc, int batch,
-                   int out_dim, int n_exits, size_t exit_stride_scratch, size_t exit_stride_S, hipStream_t s) {
-    const int bc = batch * out_dim;
-    if (bc <= 0 || tc <= 0 || n_exits <= 0) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL(moments_kernel, dim3((bc + 255) / 256, n_exits), dim3(256), 0, s, probs, logits, S1, S2, SL, tc, bc,
-                       exit_stride_scratch, exit_stride_S);
-    BMI_CHECK_LAUNCH();
-    return BMI_OK;
-}
-
 __global__ void finalize_kernel(long n, double inv_t, const double* S1, const double* S2, const double* SL, double* mean,
                                 double* var, double* lm) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

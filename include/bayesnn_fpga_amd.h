@@ -23,10 +23,10 @@
  *   bmi_stem_conv_fwd, bmi_conv_igemm_fwd   conv+BN(+residual)(+ReLU) of BasicBlock.forward
  *                              (resnet18.py:32-48) and of the exit heads (:306-308,:318-319,:329)
  *   bmi_mask_apply, bmi_mask_bits   MCDropout / Masksembles2D on a stage output (:278-280)
- *   bmi_pool_mask              F.avg_pool2d(F.relu(.),4) + flatten + exit dropout (:309-313)
- *   bmi_linear_softmax         ex{1,2,3}linear / linear (:314,:325,:335,:344) + softmax
- *                              (results_analyzer.py:242)
- *   bmi_moments_accumulate     the accumulation behind np.average (:247-248)
+ *   bmi_head_fused             one exit head end to end: F.avg_pool2d(F.relu(.),4) + flatten + exit dropout (:309-313),
+ *                              ex{1,2,3}linear / linear (:314,:325,:335,:344), softmax (results_analyzer.py:242) and
+ *                              the accumulation behind np.average over the passes (:247-248)
+ *   bmi_dense_f32              hidden Dense layers of the VGG-11 classifier stack (Keras definition, see below)
  *
  * Conventions: plain pointers and sizes only; every function returns 0 or a negative
  * errno-style code (no exceptions cross the ABI); all device buffers are owned by the
@@ -82,7 +82,7 @@ typedef struct bmi_site {
 #define BMI_OP_STEM 1  /* direct conv on the fp32 NCHW network input (Cin <= 4)        */
 #define BMI_OP_CONV 2  /* implicit-GEMM conv (Cin % 64 == 0, Cout % 64 == 0)           */
 #define BMI_OP_MASK 3  /* stand-alone stochastic site on a tensor                      */
-#define BMI_OP_HEAD 4  /* global avg-pool + site + Linear + softmax -> exit `out`      */
+#define BMI_OP_HEAD 4  /* global avg-pool + site + Linear + softmax + moment sums -> exit `out` (Cin % 32 == 0) */
 #define BMI_OP_MAXPOOL 5 /* 2x2 stride-2 max-pool                                      */
 #define BMI_OP_DENSE 6 /* hidden fully-connected layer on a flattened [1][1][K] tensor, fp32 weights,
                           accumulation and OUTPUT (the tensor `out` is then fp32 in the workspace and may
@@ -135,9 +135,7 @@ typedef struct bmi_model_desc {
 } bmi_model_desc;
 
 /* per-op-kind device time, filled by bmi_profile_read */
-#define BMI_PROFILE_SLOTS 10 /* index = BMI_OP_*; slot 8 = moments, slot 9 = finalize */
-#define BMI_PROFILE_SLOT_MOMENTS 8
-#define BMI_PROFILE_SLOT_FINALIZE 9
+#define BMI_PROFILE_SLOTS 8 /* index = BMI_OP_* (the exit heads' slot includes the moment sums) */
 
 int bmi_version(void);
 const char* bmi_error_string(int code);
@@ -235,18 +233,16 @@ int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t
 
 int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c, bmi_stream stream);
 
-/* feat[n][c] = mean_hw(in[n % in_mod][hw][c]) (site)   -> fp32 [n][c] */
-int bmi_pool_mask(const void* in, float* feat, int32_t n, int32_t in_mod, int32_t hw, int32_t c, const bmi_site* site,
-                  int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
-
-/* logits[n][c] = feat[n] . weight[c] + bias[c];  probs = softmax(logits)   (fp32 [n][out_dim]) */
-int bmi_linear_softmax(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
-                       int32_t n, int32_t k, int32_t out_dim, bmi_stream stream);
-/* the same with dropout on the LOGITS (site on the [batch, out_dim] tensor, sample index n / batch + t0): the
- * converter/pytorch rule wraps the last Linear too (nn2bnn.py:33-45).  site NULL = none; ELEMENTWISE only. */
-int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const float* bias, float* logits, float* probs,
-                            int32_t n, int32_t k, int32_t out_dim, const bmi_site* site, int32_t batch, int32_t t0,
-                            uint64_t seed, bmi_stream stream);
+/* One exit head for samples t0 .. t0+tc-1 of `batch` images, fused (csrc/head_fused.hip):
+ *   feat[n][k]   = mean_hw(relu(in[n % in_mod][hw][k])) (site)          n = t_local*batch + b, in_mod = batch or batch*tc
+ *   logits[n][c] = feat[n] . weight_pad[c] + bias[c]  (site_logits: ELEMENTWISE dropout on the [batch, out_dim] logits, the
+ *                  converter/pytorch rule wraps the last Linear too, nn2bnn.py:33-45; NULL = none)
+ *   S1[b][c] += sum_t softmax(logits)[c], S2 += sum_t softmax^2, SL += sum_t logits        (float64 [batch][out_dim])
+ * `in` is fp16 / bf16 (in_is_f32 = 0, per unit_entry_dtype) or fp32; weight_pad fp32 [ceil32(out_dim)][k], rows >= out_dim
+ * zero; k % 32 == 0, out_dim <= 128.  No per-sample probabilities are materialised. */
+int bmi_head_fused(const void* in, int32_t in_is_f32, int32_t in_mod, int32_t hw, int32_t k, const float* weight_pad,
+                   const float* bias, int32_t out_dim, const bmi_site* site, const bmi_site* site_logits, int32_t batch, int32_t t0,
+                   int32_t tc, uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL, bmi_stream stream);
 
 /* Hidden dense layer in fp32 (BMI_OP_DENSE): out[n][c] = relu?(in[n % in_mod] . weight[c] + bias[c]) (site on the
  * [batch, cout] tensor, sample index n / batch + t0).  `in` is fp16 (in_is_f32 = 0) or fp32 [.][k]; weight fp32 [cout][k];
@@ -255,10 +251,6 @@ int bmi_linear_softmax_site(const float* feat, const float* weight_pad, const fl
 int bmi_dense_f32(const void* in, int32_t in_is_f32 /* 0: 16-bit (unit_entry_dtype), 1: fp32 */, const float* weight, const float* bias, float* out, int32_t n,
                   int32_t in_mod, int32_t k, int32_t cout, int32_t relu, const bmi_site* site, int32_t batch, int32_t t0,
                   uint64_t seed, int32_t mask_cnt0, bmi_stream stream);
-
-/* S1/S2/SL [batch][out_dim] += sum over the tc samples of probs / probs^2 / logits ([tc][batch][out_dim]) */
-int bmi_moments_accumulate(const float* probs, const float* logits, double* S1, double* S2, double* SL, int32_t tc,
-                           int32_t batch, int32_t out_dim, bmi_stream stream);
 
 #ifdef __cplusplus
 }

@@ -171,55 +171,113 @@ def test_mask_apply_expands_and_masks(kind):
     assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)        # one rounding, bit-exact
 
 
-def test_pool_mask_and_linear_softmax_and_moments():
-    lib = _lib.lib()
-    B, tc, Cc, K, t0, seed = 5, 3, 10, 512, 4, 1234
+def _head_ref(x_nhwk, in_mod, B, tc, t0, seed, w, b, out_dim, site, site_logits, cnt0=0):
+    """float64 reference of one exit head over tc samples: returns (S1, S2, SL) [B, out_dim] and per-sample logits."""
     N = B * tc
+    K = x_nhwk.shape[-1]
+    pooled = torch.relu(x_nhwk.float().cpu()).mean(dim=(1, 2))[torch.arange(N) % in_mod]
+    if site is not None:
+        pooled = pooled * gh.folded_site_mask(site, B, K, 1, 1, tc, t0, seed, cnt0).reshape(N, K)
+    logits = pooled.double() @ w[:out_dim].double().T + b.double()
+    lmult = None
+    if site_logits is not None:
+        lmult = gh.folded_site_mask(site_logits, B, out_dim, 1, 1, tc, t0, seed).reshape(N, out_dim).double()
+        logits = logits * lmult
+    p = torch.softmax(logits, 1).reshape(tc, B, out_dim)
+    l = logits.reshape(tc, B, out_dim)
+    return p.sum(0), (p * p).sum(0), l.sum(0), lmult
+
+
+@pytest.mark.parametrize("out_dim,K,HW,tc,site_kind,in_kind,det", [
+    (10, 512, 16, 3, "elementwise", "f16", False),       # the ResNet-18 exit heads (4x4 maps, exit dropout)
+    (100, 512, 16, 37, "masksemble", "f16", False),      # C = 100 (4 class tiles), two sample groups (32 + 5), Masksembles1D
+    (10, 512, 1, 70, "elementwise", "f32", False),       # VGG-11: fp32 input from a dense layer, HW = 1, three groups
+    (10, 2048, 16, 5, None, "f16", True),                # ResNet-50 final head: K in four LDS chunks; deterministic input (in_mod = B)
+    (100, 256, 4, 33, "channel", "bf16", False),         # bf16 bits, 2x2 maps, K < one chunk
+    (10, 96, 1, 2, "logits", "f16", False),              # dropout on the LOGITS (converter/pytorch rule); K = 96: 7-chunk swizzle
+])
+def test_head_fused(out_dim, K, HW, tc, site_kind, in_kind, det):
+    """bmi_head_fused = pool + site + Linear + softmax + float64 moment sums in one launch, against a float64 reference;
+    the site masks are bit-exact (a dropped logit is exactly 0), the call accumulates (+=)."""
+    lib = _lib.lib()
+    B, t0, seed, cnt0 = 5, 4, (3 << 32) + 1234, 2
+    N = B * tc
+    in_mod = B if det else N
     g = _gen(8)
-    x = torch.randn(N, 4, 4, K, generator=g).to(torch.float16).to(DEV)
-    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=6, p=0.25)
+    h = int(HW ** 0.5)
+    x = torch.randn(in_mod, h, h, K, generator=g)
+    tdt = dict(f16=torch.float16, bf16=torch.bfloat16, f32=torch.float32)[in_kind]
+    xd = x.to(tdt).to(DEV)
+    w = torch.zeros((out_dim + 31) // 32 * 32, K)
+    w[:out_dim] = (2.0 / K ** 0.5) * torch.randn(out_dim, K, generator=g)
+    b = 0.2 * torch.randn(out_dim, generator=g)
+    wd, bd = w.to(DEV), b.to(DEV)
+    site = site_logits = None
+    if site_kind == "elementwise":
+        site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=6, p=0.25)
+    elif site_kind == "channel":
+        site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=3, p=0.5)            # on a [B, K] tensor channel-wise IS elementwise
+    elif site_kind == "masksemble":
+        site = dict(kind=_lib.SITE_MASKSEMBLE, site_id=1, masks=(torch.rand(4, K, generator=g) < 0.5).float().numpy())
+    elif site_kind == "logits":
+        site_logits = dict(kind=_lib.SITE_ELEMENTWISE, site_id=7, p=0.25)
     keep = []
-    s = gh.site_struct(site, keep)
-    feat = torch.empty(N, K, dtype=torch.float32, device=DEV)
-    _lib.check(lib.bmi_pool_mask(gh.ptr(x), gh.ptr(feat), N, N, 16, K, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_pool_mask")
-    mult = gh.folded_site_mask(site, B, K, 1, 1, tc, t0, seed).reshape(N, K)
-    pooled = torch.relu(x.float().cpu()).mean(dim=(1, 2))
-    torch.cuda.synchronize()
-    torch.testing.assert_close(feat.cpu(), pooled * mult, rtol=1e-6, atol=1e-6)
-    assert torch.equal(feat.cpu()[mult == 0], torch.zeros(int((mult == 0).sum())))
-
-    for out_dim in (10, 100):
-        w = torch.zeros((out_dim + 31) // 32 * 32, K)
-        w[:out_dim] = 0.4 * torch.randn(out_dim, K, generator=g)
-        b = 0.2 * torch.randn(out_dim, generator=g)
-        logits = torch.empty(N, out_dim, device=DEV)
-        probs = torch.empty(N, out_dim, device=DEV)
-        wd, bd = w.to(DEV), b.to(DEV)
-        _lib.check(lib.bmi_linear_softmax(gh.ptr(feat), gh.ptr(wd), gh.ptr(bd), gh.ptr(logits), gh.ptr(probs), N, K,
-                                          out_dim, gh.stream()), "bmi_linear_softmax")
-        torch.cuda.synchronize()
-        ref_l = feat.cpu().double() @ w[:out_dim].double().T + b.double()
-        torch.testing.assert_close(logits.cpu().double(), ref_l, rtol=1e-5, atol=2e-5)
-        torch.testing.assert_close(probs.cpu().double(), torch.softmax(ref_l, 1), rtol=1e-4, atol=1e-6)
-        assert torch.allclose(probs.sum(1).cpu(), torch.ones(N), atol=1e-5)
-
-        S = torch.zeros(3, B, out_dim, dtype=torch.float64, device=DEV)
+    s1 = gh.site_struct(dict(site, kind=_lib.SITE_CHANNEL) if site_kind == "channel" else site, keep)
+    s2 = gh.site_struct(site_logits, keep)
+    S = torch.zeros(3, B, out_dim, dtype=torch.float64, device=DEV)
+    if in_kind == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    try:
         for _ in range(2):   # accumulates (+=)
-            _lib.check(lib.bmi_moments_accumulate(gh.ptr(probs), gh.ptr(logits), gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), tc, B,
-                                                  out_dim, gh.stream()), "bmi_moments_accumulate")
+            _lib.check(lib.bmi_head_fused(gh.ptr(xd), int(in_kind == "f32"), in_mod, HW, K, gh.ptr(wd), gh.ptr(bd), out_dim,
+                                          C.byref(s1) if s1 is not None else None, C.byref(s2) if s2 is not None else None, B, t0, tc,
+                                          seed, cnt0, gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), gh.stream()), "bmi_head_fused")
         torch.cuda.synchronize()
-        p = probs.cpu().double().reshape(tc, B, out_dim)
-        l = logits.cpu().double().reshape(tc, B, out_dim)
-        torch.testing.assert_close(S[0].cpu(), 2 * p.sum(0), rtol=1e-13, atol=1e-13)
-        torch.testing.assert_close(S[1].cpu(), 2 * (p * p).sum(0), rtol=1e-13, atol=1e-13)
-        torch.testing.assert_close(S[2].cpu(), 2 * l.sum(0), rtol=1e-13, atol=1e-13)
-        out = torch.empty(3, B, out_dim, dtype=torch.float64, device=DEV)
-        _lib.check(lib.bmi_finalize(B * out_dim, 2 * tc, gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), gh.ptr(out[0]), gh.ptr(out[1]),
-                                    gh.ptr(out[2]), gh.stream()), "bmi_finalize")
+    finally:
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+    r1, r2, rl, lmult = _head_ref(xd, in_mod, B, tc, t0, seed, w, b, out_dim, site, site_logits, cnt0)
+    torch.testing.assert_close(S[0].cpu(), 2 * r1, rtol=2e-5, atol=2e-6 * tc)      # fp32 pool / Linear / softmax vs float64
+    torch.testing.assert_close(S[1].cpu(), 2 * r2, rtol=2e-5, atol=2e-6 * tc)
+    torch.testing.assert_close(S[2].cpu(), 2 * rl, rtol=2e-5, atol=2e-5 * tc)
+    torch.testing.assert_close(S[0].sum(-1).cpu(), torch.full((B,), 2.0 * tc, dtype=torch.float64), rtol=0, atol=1e-5 * tc)
+    if tc == 2 and lmult is not None:      # every sample of an image dropped the logit -> its sum is exactly 0
+        dead = (lmult.reshape(tc, B, out_dim) == 0).all(0)
+        assert dead.any() and torch.equal(S[2].cpu()[dead], torch.zeros(int(dead.sum()), dtype=torch.float64))
+    assert lib.bmi_head_fused(gh.ptr(xd), int(in_kind == "f32"), in_mod, HW, 100, gh.ptr(wd), gh.ptr(bd), out_dim, None, None, B, t0, tc,
+                              seed, cnt0, gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), gh.stream()) == -95       # K % 32 != 0
+
+
+def test_head_fused_is_chunking_invariant_and_finalize():
+    """Per-sample values do not depend on how the samples are grouped: one call over 40 samples equals 3 + 32 + 5 to the
+    float64 summation order; bmi_finalize turns the sums into mean / variance (ddof = 0) / mean logit."""
+    lib = _lib.lib()
+    B, K, out_dim, tc, seed = 3, 512, 10, 40, 9
+    g = _gen(5)
+    x = torch.randn(B * tc, 4, 4, K, generator=g).half().to(DEV)
+    w = torch.zeros(32, K)
+    w[:out_dim] = 0.1 * torch.randn(out_dim, K, generator=g)
+    wd, bd = w.to(DEV), (0.1 * torch.randn(out_dim, generator=g)).to(DEV)
+    keep = []
+    s = gh.site_struct(dict(kind=_lib.SITE_ELEMENTWISE, site_id=2, p=0.25), keep)
+
+    def run(spans):
+        S = torch.zeros(3, B, out_dim, dtype=torch.float64, device=DEV)
+        for lo, n in spans:
+            xs = x[lo * B:(lo + n) * B]
+            _lib.check(lib.bmi_head_fused(gh.ptr(xs), 0, B * n, 16, K, gh.ptr(wd), gh.ptr(bd), out_dim, C.byref(s), None, B, lo, n, seed, 0,
+                                          gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), gh.stream()), "bmi_head_fused")
         torch.cuda.synchronize()
-        torch.testing.assert_close(out[0].cpu(), p.mean(0), rtol=1e-12, atol=1e-14)
-        torch.testing.assert_close(out[1].cpu(), p.var(0, unbiased=False), rtol=1e-9, atol=1e-14)
-        torch.testing.assert_close(out[2].cpu(), l.mean(0), rtol=1e-12, atol=1e-14)
+        return S
+    Sa, Sb = run([(0, 40)]), run([(0, 3), (3, 32), (35, 5)])
+    torch.testing.assert_close(Sa.cpu(), Sb.cpu(), rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(run([(0, 40)]).cpu(), Sa.cpu(), rtol=1e-14, atol=1e-14)   # (f64 atomics: order of <= 2 adds varies)
+    out = torch.empty(3, B, out_dim, dtype=torch.float64, device=DEV)
+    _lib.check(lib.bmi_finalize(B * out_dim, tc, gh.ptr(Sa[0]), gh.ptr(Sa[1]), gh.ptr(Sa[2]), gh.ptr(out[0]), gh.ptr(out[1]),
+                                gh.ptr(out[2]), gh.stream()), "bmi_finalize")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out[0].cpu(), Sa[0].cpu() / tc, rtol=1e-14, atol=0)
+    torch.testing.assert_close(out[1].cpu(), (Sa[1].cpu() / tc - (Sa[0].cpu() / tc) ** 2).clamp(min=0), rtol=1e-9, atol=1e-15)
+    torch.testing.assert_close(out[2].cpu(), Sa[2].cpu() / tc, rtol=1e-14, atol=0)
 
 
 def test_maxpool2():
@@ -347,33 +405,6 @@ def test_conv_pair_rejects_bad_splits():
                            ca, cb, 3, 1, 1, 1, gh.stream())
     assert lib.bmi_conv_pair_fwd(*args(64, 192)) == -22        # first half must be a multiple of 128 channels
     assert lib.bmi_conv_pair_fwd(*args(128, 64)) == -95        # total not a multiple of the 256-channel tile
-
-
-@pytest.mark.parametrize("out_dim", [10, 100])
-def test_linear_softmax_with_dropout_on_the_logits(out_dim):
-    """converter/pytorch wraps the last Linear too: logits * mask / (1-p), then softmax; bit-exact mask."""
-    lib = _lib.lib()
-    B, tc, K, t0, seed = 7, 3, 256, 2, 99
-    N = B * tc
-    g = _gen(3)
-    feat = torch.randn(N, K, generator=g).to(DEV)
-    w = torch.zeros((out_dim + 31) // 32 * 32, K)
-    w[:out_dim] = 0.1 * torch.randn(out_dim, K, generator=g)
-    b = 0.2 * torch.randn(out_dim, generator=g)
-    wd, bd = w.to(DEV), b.to(DEV)
-    logits = torch.empty(N, out_dim, device=DEV)
-    probs = torch.empty(N, out_dim, device=DEV)
-    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=7, p=0.25)
-    keep = []
-    s = gh.site_struct(site, keep)
-    _lib.check(lib.bmi_linear_softmax_site(gh.ptr(feat), gh.ptr(wd), gh.ptr(bd), gh.ptr(logits), gh.ptr(probs), N, K, out_dim,
-                                           C.byref(s), B, t0, seed, gh.stream()), "bmi_linear_softmax_site")
-    torch.cuda.synchronize()
-    mult = gh.folded_site_mask(site, B, out_dim, 1, 1, tc, t0, seed).reshape(N, out_dim).double()
-    ref_l = (feat.cpu().double() @ w[:out_dim].double().T + b.double()) * mult
-    torch.testing.assert_close(logits.cpu().double(), ref_l, rtol=1e-5, atol=2e-5)
-    assert torch.equal(logits.cpu() == 0, mult == 0) and (mult == 0).any()
-    torch.testing.assert_close(probs.cpu().double(), torch.softmax(ref_l, 1), rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("name,kwargs", [("S2", dict(with_res=True, with_site=True)), ("S2", dict(with_res=False, with_site=False)),
@@ -538,7 +569,7 @@ def test_bf16_conv_shape_classes(name, bf16_entries):
 
 
 def test_bf16_elementwise_kernels(bf16_entries):
-    """mask_apply (lane-shared Philox path), maxpool2, pool_mask and dense_f32 reading / writing bfloat16 bits."""
+    """mask_apply (lane-shared Philox path), maxpool2 and dense_f32 reading / writing bfloat16 bits (the head: test_head_fused)."""
     lib = _lib.lib()
     B, tc, H, Cc, t0, seed = 2, 3, 16, 64, 0, 5
     N = B * tc
@@ -557,10 +588,6 @@ def test_bf16_elementwise_kernels(bf16_entries):
     _lib.check(lib.bmi_maxpool2(gh.ptr(out), gh.ptr(mp), N, H, H, Cc, gh.stream()), "bmi_maxpool2")
     torch.cuda.synchronize()
     assert torch.equal(mp.cpu().float(), torch.nn.functional.max_pool2d(out.cpu().float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
-    feat = torch.empty(N, Cc, device=DEV)
-    _lib.check(lib.bmi_pool_mask(gh.ptr(out), gh.ptr(feat), N, N, H * H, Cc, None, B, t0, seed, 0, gh.stream()), "bmi_pool_mask")
-    torch.cuda.synchronize()
-    torch.testing.assert_close(feat.cpu(), torch.relu(out.cpu().float()).mean((1, 2)), rtol=1e-5, atol=1e-6)
     flat = out.reshape(N, -1)[:, :512].contiguous()
     w = 0.05 * torch.randn(128, 512, generator=g)
     wd, bd = w.to(DEV), torch.zeros(128, device=DEV)        # (named: a temporary's memory is recycled by the next allocation)

@@ -1,3 +1,5 @@
-python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -s 2>&1 | grep -v "^B+E\|^Ensemble" | tail -12
-python bench.py --workload vgg11 --steps 5 --warmup 2 --dtype bf16 2>&1 | grep -v amdgpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['dtype'], d['cpu_baseline'])"
-python bench.py --steps 5 --warmup 2 --dtype bf16 --cpu-T 4 2>&1 | grep -v amdgpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['dtype'], d['roofline']['frac'], d['cpu_baseline'])"
+python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "head or dense" 2>&1 | tail -4
+python -m pytest tests/test_gpu_model.py tests/test_converter.py tests/test_vgg.py -m gpu -x -q 2>&1 | tail -3
+python tools/step_ab.py --rounds 5 --steps 3 --ab "xcd_split=0" 2>&1 | grep -v amdgpu
+python tools/step_ab.py --T 13 --rounds 5 --steps 5 --ab "xcd_split=0" 2>&1 | grep -v amdgpu
+python tools/step_ab.py --workload resnet18_masksembles --rounds 3 --steps 3 --ab "xcd_split=0" 2>&1 | grep -v amdgpu

@@ -18,7 +18,7 @@ if r.returncode:
     sys.exit(r.stderr[-3000:])
 pat = (r"Function Name: (\S+).*?SGPRs: (\d+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
        r"Occupancy \[waves/SIMD\]: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+).*?LDS Size \[bytes/block\]: (\d+)")
-print(f"{'kernel':90s} sgpr vgpr agpr scratch occ spill  lds")
+print(f"{'kernel':90s} sgpr vgpr agpr scratch occ s-spill v-spill  lds")
 for m in re.findall(pat, r.stderr, flags=re.S):
     name = subprocess.run(["c++filt", m[0]], capture_output=True, text=True).stdout.strip().replace("(ConvArgs)", "")
-    print(f"{name[:90]:90s} {m[1]:>4s} {m[2]:>4s} {m[3]:>4s} {m[4]:>7s} {m[5]:>3s} {int(m[6]) + int(m[7]):>5d} {m[8]:>6s}")
+    print(f"{name[:90]:90s} {m[1]:>4s} {m[2]:>4s} {m[3]:>4s} {m[4]:>7s} {m[5]:>3s} {m[6]:>7s} {m[7]:>7s} {m[8]:>6s}")
