@@ -49,6 +49,7 @@ struct ProfRec {
     hipEvent_t a, b;
     int family = -1;     // BMI_CONV_FAMILY_* of a conv launch
     double flops = 0;    // its algorithmic FLOPs
+    double bytes = 0;    // its algorithmic HBM bytes (inputs + residual + weights once, output once)
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -66,7 +67,7 @@ struct bmi_engine_s {
     size_t ws_bytes = 0;
     // profiling
     bool profiling = false;
-    double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0};
+    double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0}, fam_bytes[BMI_CONV_FAMILIES] = {0};
     int64_t fam_launches[BMI_CONV_FAMILIES] = {0};
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
@@ -527,7 +528,7 @@ struct ProfScope {
         r.slot = slot; r.a = get(); r.b = get();
         (void)hipEventRecord(r.a, s);
     }
-    void tag(int family, double flops) { r.family = family; r.flops = flops; }
+    void tag(int family, double flops, double bytes) { r.family = family; r.flops = flops; r.bytes = bytes; }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(r.b, s);
@@ -576,6 +577,12 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             if (op.bits_tensor >= 0) a.in_bits = (const uint8_t*)(ws + e->tensors[op.bits_tensor].offset);
             double flops = 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
             if (d.in2 >= 0) flops += 2.0 * N * op.ho * op.wo * (double)op.cout * e->tensors[d.in2].c;
+            // algorithmic bytes: every operand tensor once (a deterministic operand counts its B images), weights once
+            auto tbytes = [&](int id) { const TensorInfo& t = e->tensors[id]; return 2.0 * (t.stoch ? N : B) * t.h * t.w * t.c; };
+            double bytes = tbytes(d.in) + 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) +
+                           2.0 * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
+            if (d.residual >= 0) bytes += tbytes(d.residual);
+            if (d.in2 >= 0) bytes += tbytes(d.in2) + 2.0 * op.cout * e->tensors[d.in2].c;
             if (op.has_pair) {
                 ConvArgs p = a;
                 p.wgt_b = (const _Float16*)op.pair_d.weight;
@@ -584,18 +591,18 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 p.split = op.cout;
                 p.Cout = op.cout + op.pair_cout;
                 const int rc = launch_conv_igemm_wide(p, s);
-                prof.tag(BMI_CONV_FAMILY_WIDE, flops);
+                prof.tag(BMI_CONV_FAMILY_WIDE, flops, bytes);
                 if (rc != BMI_ERR_UNSUPPORTED) return rc;
                 ConvArgs q = a;          // not taken after all: two plain launches
                 q.wgt = p.wgt_b; q.scale = p.scale_b; q.bias = p.bias_b; q.out = p.out_b; q.Cout = op.pair_cout;
                 int fam = -1;
                 const int rc2 = launch_conv(a, s, &fam);
-                prof.tag(fam, flops);
+                prof.tag(fam, flops, bytes);
                 return rc2 != BMI_OK ? rc2 : launch_conv(q, s);
             }
             int fam = -1;
             const int rcc = launch_conv(a, s, &fam);
-            prof.tag(fam, flops);
+            prof.tag(fam, flops, bytes);
             return rcc;
         }
         case OP_MASKBITS:
@@ -682,14 +689,14 @@ int bmi_profile_enable(bmi_handle h, int32_t enable) {
 int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launches[BMI_PROFILE_SLOTS]) {
     if (!h || !ms || !launches) return BMI_ERR_INVALID;
     for (int i = 0; i < BMI_PROFILE_SLOTS; ++i) { ms[i] = 0; launches[i] = 0; }
-    for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { h->fam_ms[i] = 0; h->fam_flops[i] = 0; h->fam_launches[i] = 0; }
+    for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { h->fam_ms[i] = 0; h->fam_flops[i] = 0; h->fam_bytes[i] = 0; h->fam_launches[i] = 0; }
     int rc = BMI_OK;
     for (auto& r : h->recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = BMI_ERR_HIP;
         if (r.slot >= 0 && r.slot < BMI_PROFILE_SLOTS) { ms[r.slot] += t; launches[r.slot] += 1; }
         if (r.slot == BMI_OP_CONV && r.family >= 0 && r.family < BMI_CONV_FAMILIES) {
-            h->fam_ms[r.family] += t; h->fam_flops[r.family] += r.flops; h->fam_launches[r.family] += 1;
+            h->fam_ms[r.family] += t; h->fam_flops[r.family] += r.flops; h->fam_bytes[r.family] += r.bytes; h->fam_launches[r.family] += 1;
         }
         h->pool.push_back(r.a);
         h->pool.push_back(r.b);
@@ -699,9 +706,9 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
 }
 
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
-                              double flops[BMI_CONV_FAMILIES]) {
-    if (!h || !ms || !launches || !flops) return BMI_ERR_INVALID;
-    for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { ms[i] = h->fam_ms[i]; launches[i] = h->fam_launches[i]; flops[i] = h->fam_flops[i]; }
+                              double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]) {
+    if (!h || !ms || !launches || !flops || !bytes) return BMI_ERR_INVALID;
+    for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { ms[i] = h->fam_ms[i]; launches[i] = h->fam_launches[i]; flops[i] = h->fam_flops[i]; bytes[i] = h->fam_bytes[i]; }
     return BMI_OK;
 }
 

@@ -36,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16, MI355X_MICROARCH.md §Chip-level parameters
+HBM_PEAK_GBS = 8000.0           # HBM3E, same table
 MODEL_KW = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
 
 # name -> (package class, oracle class, kwargs, batch, T, description).  The default is the configuration BASELINE.json's
@@ -295,9 +296,15 @@ def main():
                          "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_launches, 1)),
                          "algorithmic_flops_per_launch": round(conv_flops / max(conv_launches, 1)),
                          "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                         # per kernel family both rooflines: MFMA (algorithmic FLOP/s over 2.5 PF) and HBM (algorithmic bytes/s
+                         # over 8 TB/s); `bound` names the tighter one for that family's launches
                          "by_kernel": {k: {"launches": int(v["launches"]), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
                                            "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
                                            "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                           "hbm_gbs_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                           "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "flop_per_byte": round(v["flops"] / max(v["bytes"], 1.0), 1),
+                                           "bound": "mfma" if v["flops"] / MFMA_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_GBS / 1e9 else "hbm",
                                            **(pmc_sq(a.workload, k) if traffic is not None else {})}
                                        for k, v in eng.conv_families.items()},
                          "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},

@@ -181,13 +181,14 @@ int bmi_finalize(int64_t n, int32_t t_total, const double* S1, const double* S2,
 int bmi_profile_enable(bmi_handle h, int32_t enable);
 int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launches[BMI_PROFILE_SLOTS]);
 /* The BMI_OP_CONV slot of the LAST bmi_profile_read, split by the kernel that took each launch, with the
- * algorithmic FLOPs (2 * MACs) of those launches: what bench.py prices against the MFMA roofline. */
+ * algorithmic FLOPs (2 * MACs) and algorithmic HBM bytes (every operand tensor and the weights read once, the output
+ * written once) of those launches: what bench.py prices against the MFMA and the HBM roofline. */
 #define BMI_CONV_FAMILY_PATCH 0 /* conv3x3_patch_kernel  */
 #define BMI_CONV_FAMILY_WIDE 1  /* conv_igemm_wide_kernel */
 #define BMI_CONV_FAMILY_IGEMM 2 /* conv_igemm_kernel */
 #define BMI_CONV_FAMILIES 3
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
-                              double flops[BMI_CONV_FAMILIES]);
+                              double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]);
 
 /* ---- single-kernel entry points (unit parity tests) -------------------------------------- */
 
