@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         const int n = n0 + img;
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = cell < G::CELLS && px < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        psrc[i] = ok ? (int)((((size_t)(n % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + c * 8) : -1;
+        psrc[i] = ok ? (int)((((size_t)(map_image(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + c * 8) : -1;
     }
     // Weight tile: LDS-DMA one K-step ahead, double buffered, issued as one burst behind the barrier.  Recorded
     // negatives (round 1, same-box A/B on S2/S3/S4): register staging -10 %, hand-pipelined fragment reads -3 %, a third
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 const int oy = rem / TW, ox = rem - oy * TW;
                 const int c = cp ^ (((ox + KA * oy) >> 1) & 7);
                 const int n = n0 + img;
-                const int nm = n < a.in2_mod ? n : n % a.in2_mod;
+                const int nm = map_image(a, n) % a.in2_mod;
                 const _Float16* src = n < a.N ? a.in2 + (((size_t)nm * a.H2 + (size_t)(y0 + oy) * a.stride2) * a.W2 +
                                                         (size_t)(x0 + ox) * a.stride2) * a.Cin2 + c2 * 64 + c * 8
                                               : (const _Float16*)g_zero_page;
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         const int oy = q / TW, ox = q - oy * TW;
         n = n0 + img;
         rem = (y0 + oy) * a.Wo + x0 + ox;
-        return n < a.N;
+        const bool ok = n < a.N;
+        n = map_image(a, n);
+        return ok;
     };
     auto offmap = [&](int p, size_t& off) -> bool {
         int n, rem;

@@ -67,6 +67,13 @@ __device__ __forceinline__ void xcd_tile_map(int bid, int n_pt, int n_ct, int& p
     }
 }
 
+// Dynamic early exit: compact image index of this launch -> row of the tensors / Philox image index (see ConvArgs::imap).
+__device__ __forceinline__ int map_image(const ConvArgs& a, int n) {
+    if (!a.imap || n >= a.N) return n;
+    const int tl = n / a.Bc;
+    return tl * a.B + a.imap[n - tl * a.Bc];
+}
+
 struct PixelCtx {
     size_t out_off;        // element offset of this pixel's channel 0 in the output tensor
     const _Float16* resp;  // residual row or nullptr

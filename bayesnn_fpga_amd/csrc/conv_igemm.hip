@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int m = pix0 + r0 + 32 * j;
         vm[j] = m < a.M;
         const int mm = vm[j] ? m : 0;
-        const int n = mm / HoWo;
-        const int rem = mm - n * HoWo;
+        const int nc = mm / HoWo;
+        const int rem = mm - nc * HoWo;
+        const int n = map_image(a, nc);
         const int oy = rem / a.Wo;
         const int ox = rem - oy * a.Wo;
         iy0[j] = oy * a.stride - a.pad;
@@ -185,10 +186,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             const int m = pix0 + p;
             n = m / HoWo;
             rem = m - n * HoWo;
+            n = map_image(a, n);
             return m < a.M;
         };
         auto offmap = [&](int p, size_t& off) -> bool {
-            off = (size_t)(pix0 + p) * a.Cout;
+            if (a.imap) {
+                const int m = pix0 + p, n = m / HoWo;
+                off = ((size_t)map_image(a, n) * HoWo + (m - n * HoWo)) * a.Cout;
+            } else {
+                off = (size_t)(pix0 + p) * a.Cout;
+            }
             return pix0 + p < a.M;
         };
         epilogue_coalesced<TJ, PLAIN, 32, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             const int m = pix0 + wp * (BP / WP) + 32 * j + r;
             if (m >= a.M) continue;
             const int n = m / HoWo;
-            const PixelCtx px = make_pixel_ctx(a, n, m - n * HoWo);
+            const PixelCtx px = make_pixel_ctx(a, map_image(a, n), m - n * HoWo);
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
 #pragma unroll

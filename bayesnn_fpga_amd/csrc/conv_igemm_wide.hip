@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         const int ox = rem - oy * a.Wo;
         iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;       // a row beyond M never passes the bounds test
         ix0[i] = ox * a.stride - a.pad;
-        xsrc[i] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + srcchunk;
+        xsrc[i] = a.in + (size_t)(map_image(a, n) % a.in_mod) * a.H * a.W * a.Cin + srcchunk;
     }
     // One row block (64 rows = 8 KB) of the weight / activation tile per call: the fills of the NEXT K-step are
     // spread over the MFMAs of the current one (2 DMA instructions per 8 MFMAs per wave).  Issued as one burst
@@ -275,10 +275,16 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         const int m = pix0 + p;
         n = m / HoWo;
         rem = m - n * HoWo;
+        n = map_image(a, n);
         return m < a.M;
     };
     auto offmap = [&](int p, size_t& off) -> bool {
-        off = (size_t)(pix0 + p) * b.Cout;
+        if (a.imap) {
+            const int m = pix0 + p, n = m / HoWo;
+            off = ((size_t)map_image(a, n) * HoWo + (m - n * HoWo)) * b.Cout;
+        } else {
+            off = (size_t)(pix0 + p) * b.Cout;
+        }
         return pix0 + p < a.M;
     };
     epilogue_coalesced<TJ, PLAIN, MS, BF>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
             const int ox = rem - oy * a.Wo;                                                            \
             iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;                                            \
             ix0[i] = ox * a.stride - a.pad;                                                            \
-            xsrc[i] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + srcchunk;                    \
+            xsrc[i] = a.in + (size_t)(map_image(a, n) % a.in_mod) * a.H * a.W * a.Cin + srcchunk;                    \
         }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) ISSUE_X(i, 0, 0, 0, smem);                       \
     }
@@ -550,7 +556,7 @@ int launch_conv_igemm_wide(const ConvArgs& a_in, hipStream_t s) {
         return cu;
     }();
     const int shape = opt_mfma_shape_wide();
-    if (persist && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks > 2L * n_cu) {
+    if (persist && !a.imap && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks > 2L * n_cu) {
         if (a.bf16) hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<16, true>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
         else if (shape == 16) hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<16, false>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
         else hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<32, false>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);

@@ -64,7 +64,7 @@ struct bmi_engine_s {
     int64_t prefix_macs = 0, suffix_macs = 0;
     // plan
     int max_batch = 0, chunk = 0;
-    size_t ws_bytes = 0;
+    size_t ws_bytes = 0, exit_off = 0;   // exit_off: 2 active-image lists + a counter (dynamic early exit)
     // profiling
     bool profiling = false;
     double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0}, fam_bytes[BMI_CONV_FAMILIES] = {0};
@@ -492,6 +492,8 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
         st_peak = std::max(st_peak, pos + size);
     }
     off = st_base + st_peak;
+    h->exit_off = off;
+    off += align_up((2 * (size_t)max_batch + 64) * sizeof(int), 256);
     h->ws_bytes = off;
     h->max_batch = max_batch;
     h->chunk = chunk_samples;
@@ -536,10 +538,13 @@ struct ProfScope {
     }
 };
 
+// imap / Bc: dynamic early exit (ConvArgs::imap): N = samples * Bc compact images of the B-image batch; null = all images
 int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, int B, int t0, uint64_t seed, int cnt0,
-           double* S1, double* S2, double* SL, hipStream_t s) {
+           double* S1, double* S2, double* SL, hipStream_t s, const int* imap = nullptr, int Bc = 0) {
     const bmi_op_desc& d = op.d;
     const TensorInfo& tin = e->tensors[d.in];
+    const int n_rows = imap ? (N / Bc) * B : N;     // rows of a stochastic tensor (original folded layout)
+    if (imap && d.kind != BMI_OP_CONV && d.kind != BMI_OP_HEAD) return BMI_ERR_UNSUPPORTED;
     ProfScope prof(e, d.kind == OP_MASKBITS ? BMI_OP_MASK : d.kind, s);
     switch (d.kind) {
         case BMI_OP_STEM:
@@ -554,10 +559,11 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.scale = d.scale; a.bias = d.bias;
             a.out = (_Float16*)(ws + e->tensors[d.out].offset);
             a.N = N;
-            a.in_mod = tin.stoch ? N : B;
+            a.imap = imap; a.Bc = Bc;
+            a.in_mod = tin.stoch ? n_rows : B;
             if (d.residual >= 0) {
                 a.res = (const _Float16*)(ws + e->tensors[d.residual].offset);
-                a.res_mod = e->tensors[d.residual].stoch ? N : B;
+                a.res_mod = e->tensors[d.residual].stoch ? n_rows : B;
             }
             a.H = tin.h; a.W = tin.w; a.Cin = tin.c;
             a.Ho = op.ho; a.Wo = op.wo; a.Cout = op.cout;
@@ -571,7 +577,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 const TensorInfo& t2 = e->tensors[d.in2];
                 a.in2 = (const _Float16*)(ws + t2.offset);
                 a.wgt2 = (const _Float16*)d.weight2;
-                a.in2_mod = t2.stoch ? N : B;
+                a.in2_mod = t2.stoch ? n_rows : B;
                 a.H2 = t2.h; a.W2 = t2.w; a.Cin2 = t2.c; a.stride2 = t2.h / op.ho;
             }
             if (op.bits_tensor >= 0) a.in_bits = (const uint8_t*)(ws + e->tensors[op.bits_tensor].offset);
@@ -632,8 +638,9 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             std::memset(&a, 0, sizeof(a));
             a.in = ws + tin.offset;
             a.in_kind = tin.f32 ? 1 : (e->bf16 ? 2 : 0);
-            a.in_mod = tin.stoch ? N : B;
-            a.HW = tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = N / B;
+            a.in_mod = tin.stoch ? n_rows : B;
+            a.imap = imap; a.Bc = Bc;
+            a.HW = tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = imap ? N / Bc : N / B;
             a.w = (const float*)d.weight; a.bias = d.bias; a.C = e->out_dim;
             const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
             a.site = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0);
@@ -670,6 +677,51 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
             const int rc = run_op(h, op, x_nchw, ws, N, batch, t0, seed, mask_cnt0, S1, S2, SL, s);
             if (rc != BMI_OK) return rc;
         }
+    }
+    return BMI_OK;
+}
+
+int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_count, uint64_t seed, int32_t mask_cnt0,
+                         double threshold, int32_t first_exit, double* S1, double* S2, double* SL, int32_t* exit_of_image,
+                         int32_t* active_after, void* workspace, size_t workspace_bytes, bmi_stream stream) {
+    if (!h || !x_nchw || !S1 || !S2 || !SL || !workspace || !exit_of_image || !active_after) return BMI_ERR_INVALID;
+    if (batch < 1 || t_count < 1 || mask_cnt0 < 0 || first_exit < 0) return BMI_ERR_INVALID;
+    if (h->max_batch == 0 || batch > h->max_batch) return BMI_ERR_INVALID;
+    if (t_count > h->chunk) return BMI_ERR_UNSUPPORTED;     // an exit's decision needs ALL samples of the stage in the workspace
+    if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int* lists[2] = {(int*)(ws + h->exit_off), (int*)(ws + h->exit_off) + h->max_batch};
+    int* count_dev = (int*)(ws + h->exit_off) + 2 * h->max_batch;
+    const int last = h->n_exits - 1;
+    int rc = launch_fill_int(exit_of_image, batch, last, s);
+    if (rc != BMI_OK) return rc;
+    for (int x = 0; x < h->n_exits; ++x) active_after[x] = 0;
+    for (const OpInfo& op : h->prefix) {
+        rc = run_op(h, op, x_nchw, ws, batch, batch, 0, seed, mask_cnt0, S1, S2, SL, s);
+        if (rc != BMI_OK) return rc;
+    }
+    const int* imap = nullptr;     // null: every image is still active
+    int bc = batch, cur = 0;
+    for (const OpInfo& op : h->suffix) {
+        rc = run_op(h, op, x_nchw, ws, t_count * bc, batch, 0, seed, mask_cnt0, S1, S2, SL, s, imap, bc);
+        if (rc != BMI_OK) return rc;
+        if (op.d.kind != BMI_OP_HEAD) continue;
+        const int e = op.d.out;
+        if (e < first_exit || e >= last) { active_after[e] = bc; continue; }
+        // confidence test of exit e over the still-active images, on the device; the host only learns how many go on
+        rc = launch_exit_decide(S1 + (size_t)e * batch * h->out_dim, h->out_dim, t_count, threshold, imap, bc, lists[cur], count_dev,
+                                exit_of_image, e, s);
+        if (rc != BMI_OK) return rc;
+        int n_active = 0;
+        if (hipMemcpyAsync(&n_active, count_dev, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            return BMI_ERR_HIP;
+        active_after[e] = n_active;
+        if (n_active == 0) return BMI_OK;                    // every image has left: the later stages do not run at all
+        imap = lists[cur];
+        bc = n_active;
+        cur ^= 1;
     }
     return BMI_OK;
 }

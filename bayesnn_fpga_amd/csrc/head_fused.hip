@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
     float* const feat = (float*)smem;
     float* const part = (float*)(smem + HEAD_FEAT_BYTES);     // [4 waves][RT][16 regs][64 lanes]
 
-    const int b = blockIdx.x;
+    const int b = a.imap ? a.imap[blockIdx.x] : (int)blockIdx.x;    // dynamic early exit: only the still-active images
     const int g = blockIdx.y;                                  // this workgroup's group of 32 samples
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
 
 template <int RT>
 static void launch_rt(const HeadArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)a.B, (unsigned)((a.tc + 31) / 32)), block(256);
+    const dim3 grid((unsigned)(a.imap ? a.Bc : a.B), (unsigned)((a.tc + 31) / 32)), block(256);
     if (a.in_kind == 1) hipLaunchKernelGGL((head_fused_kernel<RT, 1>), grid, block, 0, s, a);
     else if (a.in_kind == 2) hipLaunchKernelGGL((head_fused_kernel<RT, 2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((head_fused_kernel<RT, 0>), grid, block, 0, s, a);
@@ -233,6 +233,7 @@ int launch_head_fused(const HeadArgs& a, hipStream_t s) {
     if (!a.in || !a.w || !a.bias || !a.S1 || !a.S2 || !a.SL) return BMI_ERR_INVALID;
     if (a.B <= 0 || a.tc <= 0 || a.in_mod <= 0 || a.HW <= 0 || a.C <= 0 || a.in_kind < 0 || a.in_kind > 2) return BMI_ERR_INVALID;
     if (a.in_mod != a.B && a.in_mod != a.B * a.tc) return BMI_ERR_INVALID;
+    if (a.imap && (a.Bc <= 0 || a.Bc > a.B)) return BMI_ERR_INVALID;
     if (a.K % 32 != 0 || a.C > 128) return BMI_ERR_UNSUPPORTED;
     if (a.site_logits.kind != BMI_SITE_NONE && a.site_logits.kind != BMI_SITE_ELEMENTWISE) return BMI_ERR_UNSUPPORTED;
     switch ((a.C + 31) / 32) {

@@ -42,6 +42,10 @@ struct ConvArgs {
     int B;         // images per Monte-Carlo sample
     int t0;        // first sample index of this launch
     int bf16;      // 1: activations / weights are bfloat16 bits (v_mfma_*_bf16), 0: fp16
+    // dynamic early exit (bmi_forward_mcd_exit): the launch covers N = samples * Bc COMPACT images; compact image n is row
+    // (n / Bc) * B + imap[n % Bc] of every tensor (which keep their original folded layout) and of the Philox index
+    const int* imap;   // device [Bc] original image indices of the still-active images, or null (identity, Bc unused)
+    int Bc;
     int xcd_split; // channel-tile classes of the XCD-aware tile order (xcd_tile_map's cs); set by the launcher
     SiteArgs site;
 };
@@ -66,6 +70,8 @@ struct HeadArgs {   // fused exit head (head_fused.hip)
     const float* w;      // fp32 [ceil32(C)][K], rows >= C zero
     const float* bias;   // fp32 [C]
     int C;               // out_dim
+    const int* imap;      // dynamic early exit: grid.x = Bc workgroups, image = imap[blockIdx.x]; or null
+    int Bc;
     SiteArgs site;        // on the pooled [B, K] features
     SiteArgs site_logits; // ELEMENTWISE dropout on the [B, C] logits, or NONE
     double *S1, *S2, *SL; // this exit's [B][C] moment accumulators
@@ -84,6 +90,9 @@ int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int 
 // hidden dense layer, fp32 weights [cout][k] / accumulate / output; `in` 16-bit (in_kind 0: fp16, 2: bf16) or fp32 (1) [n or in_mod][k]
 int launch_dense_f32(const void* in, int in_kind, const float* w, const float* bias, float* out, int n, int in_mod, int k,
                      int cout, int relu, const SiteArgs& site, int batch, int t0, hipStream_t s);
+int launch_exit_decide(const double* S1e, int C, int t_total, double thr, const int* in, int bc, int* out, int* count,
+                       int* exit_of, int e, hipStream_t s);
+int launch_fill_int(int* p, int n, int v, hipStream_t s);
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);

@@ -284,6 +284,64 @@ int launch_stem_conv(const float* x, const float* w, const float* scale, const f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dynamic early exit, the per-stage confidence test + compaction of the still-active images (what the reference models post
+// hoc: FullAnalysis.confidence_exiting / is_confident, SA/train/results_analyzer.py:606-630, :725-733): among the `bc`
+// active images (list `in`, identity when null) those whose exit-e confidence max_c mean_t p[e][b][c] exceeds the
+// threshold get exit_of[b] = e and leave; the others are written, order preserved, to `out` (`in` != `out`) and counted.
+__global__ __launch_bounds__(256) void exit_decide_kernel(const double* __restrict__ S1e, int C, double inv_t, double thr,
+                                                          const int* __restrict__ in, int bc, int* __restrict__ out,
+                                                          int* __restrict__ count, int* __restrict__ exit_of, int e) {
+    __shared__ int scan[256];
+    __shared__ int base_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int base = 0; base < bc; base += 256) {
+        const int i = base + tid;
+        int keep = 0, b = -1;
+        if (i < bc) {
+            b = in ? in[i] : i;
+            double mx = 0.0;
+            for (int c = 0; c < C; ++c) mx = fmax(mx, S1e[(size_t)b * C + c]);
+            if (mx * inv_t > thr) exit_of[b] = e;
+            else keep = 1;
+        }
+        scan[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        if (keep) out[base_s + scan[tid] - 1] = b;
+        __syncthreads();
+        if (tid == 255) base_s += scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+}
+
+int launch_exit_decide(const double* S1e, int C, int t_total, double thr, const int* in, int bc, int* out, int* count,
+                       int* exit_of, int e, hipStream_t s) {
+    if (!S1e || !out || !count || !exit_of || bc <= 0 || C <= 0 || t_total <= 0 || in == out) return BMI_ERR_INVALID;
+    hipLaunchKernelGGL(exit_decide_kernel, dim3(1), dim3(256), 0, s, S1e, C, 1.0 / t_total, thr, in, bc, out, count, exit_of, e);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+__global__ void fill_int_kernel(int* p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int launch_fill_int(int* p, int n, int v, hipStream_t s) {
+    if (!p || n <= 0) return BMI_ERR_INVALID;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
 __global__ void finalize_kernel(long n, double inv_t, const double* S1, const double* S2, const double* SL, double* mean,
                                 double* var, double* lm) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -381,6 +381,31 @@ class MCDEngine(CompiledGraph):
         self.accumulate(x, S, t_begin, T, seed, cnt0)
         return self.finalize(S, T)
 
+    def predict_with_exit(self, x, T, threshold, seed=0, cnt0=0, first_exit=1):
+        """Confidence-threshold early exiting on the device (bmi_forward_mcd_exit): an image leaves after the first exit
+        e >= ``first_exit`` whose T-mean confidence exceeds ``threshold`` (the reference's ``confidence_exiting`` rule,
+        SA/train/results_analyzer.py:606-630; its loop starts at exit 1) and the later stages only run for the images
+        that are still active.  Returns dict(mean/var/logit_mean [E,B,C] — rows of exits an image never reached are
+        meaningless —, exit_layer int32 [B], active_after [E] (host ints), best_preds [B,C] = mean[exit_layer[b], b])."""
+        x = self._check_x(x)
+        B = x.shape[0]
+        if T > self.chunk_samples:
+            raise ValueError(f"dynamic exiting needs all T={T} samples in one chunk (engine planned for {self.chunk_samples})")
+        S = self.new_moments(B)
+        exit_layer = torch.empty(B, dtype=torch.int32, device=self.device)
+        active = (C.c_int32 * self.n_exits)()
+        with torch.cuda.device(self.device):
+            rc = self.lib.bmi_forward_mcd_exit(self.handle, x.data_ptr(), B, int(T), int(seed) & 0xFFFFFFFFFFFFFFFF, int(cnt0),
+                                               float(threshold), int(first_exit), S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
+                                               exit_layer.data_ptr(), active, self.workspace.data_ptr(), self.workspace_bytes,
+                                               self._stream())
+        _lib.check(rc, "bmi_forward_mcd_exit")
+        r = self.finalize(S, T)
+        r["exit_layer"] = exit_layer
+        r["active_after"] = [int(v) for v in active]
+        r["best_preds"] = r["mean"][exit_layer.long(), torch.arange(B, device=self.device)]
+        return r
+
     def forward_once(self, x, seed=0, t=0, cnt0=0):
         """One stochastic pass -> list of fp32 logits [B, C] per exit (the reference forward's return)."""
         S = self.new_moments(x.shape[0])

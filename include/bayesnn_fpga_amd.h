@@ -172,6 +172,21 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
                     uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL, void* workspace,
                     size_t workspace_bytes, bmi_stream stream);
 
+/* Confidence-threshold early exiting ON the device — what the reference only models after the fact
+ * (FullAnalysis.confidence_exiting / is_confident / flop_saver, SA/train/results_analyzer.py:606-630, :638-677, :725-733):
+ * runs samples 0 .. t_count-1 of the batch stage by stage; after the head of exit e (first_exit <= e < n_exits-1; the
+ * reference's loop starts at exit 1) an image whose confidence max_c mean_t softmax[e][b][c] exceeds `threshold` is
+ * assigned exit_of_image[b] = e and takes no part in the later stages: the following launches cover only the still-active
+ * images (compact tile grid, tensors keep their original rows, masks keep their original element indices, so every value
+ * that IS computed equals the full run's bit for bit).  Images that never pass get n_exits-1.
+ * S1/S2/SL [E][batch][C] must be ZERO on entry; on return the rows of exits an image did not reach hold no samples.
+ * active_after[e] (host, [n_exits]) = images still active after exit e's test.  Needs t_count <= the planned chunk;
+ * synchronises the stream once per tested exit (the host sizes the next stage's grids), so it cannot be graph-captured.
+ * Graphs with MASK / MAXPOOL / DENSE ops behind the first tested exit are BMI_ERR_UNSUPPORTED. */
+int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_count, uint64_t seed, int32_t mask_cnt0,
+                         double threshold, int32_t first_exit, double* S1, double* S2, double* SL, int32_t* exit_of_image,
+                         int32_t* active_after, void* workspace, size_t workspace_bytes, bmi_stream stream);
+
 /* mean = S1/T, var = S2/T - mean^2 (clamped at 0), logit_mean = SL/T; n = E*B*C. */
 int bmi_finalize(int64_t n, int32_t t_total, const double* S1, const double* S2, const double* SL, double* mean,
                  double* var, double* logit_mean, bmi_stream stream);

@@ -1,0 +1,91 @@
+"""-m gpu: confidence-threshold early exiting ON the device (bmi_forward_mcd_exit / MCDEngine.predict_with_exit) against
+the reference's post-hoc rule applied to a FULL run (train/confidence_exiting.py, itself pinned to
+FullAnalysis.confidence_exiting / is_confident by tests/golden/confidence_exiting.npz): same exit per image, and the
+prediction of every image at its exit equals the full run's — the compacted stages compute the same values bit for bit
+(same masks: the Philox element index keeps the ORIGINAL image index; tile composition does not enter an MFMA result)."""
+import numpy as np
+import pytest
+import torch
+
+from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
+from bayesnn_fpga_amd.train import confidence_exiting as cex
+from tests.helpers import build_seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+KWS = {
+    "mc_block_exit": dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10),
+    "mc_layer_exit": dict(dropout_exit=True, dropout="layer", dropout_p=0.25, out_dim=10),
+    "masksembles": dict(dropout_exit=True, dropout="block", mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=10),
+}
+
+
+@pytest.mark.parametrize("name", sorted(KWS))
+def test_device_exit_equals_posthoc_rule_on_the_full_run(name):
+    B, T, seed = 45, 6, 11
+    m = build_seeded(ResNet18MCEarlyExit, KWS[name])
+    synthetic_weights_(m, 0)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    x = synthetic_images(B, seed=21).to(DEV)
+    full = eng.predict(x, T, seed=seed)
+    p_full = full["mean"].cpu().numpy()
+    conf = p_full.max(-1)                                        # [E, B]
+    for thr in (float(np.median(conf[1])), float(np.quantile(conf[2], 0.3)), 0.0, 1.0):
+        want = cex.exit_layer(p_full.copy(), thr)
+        r = eng.predict_with_exit(x, T, thr, seed=seed)
+        got = r["exit_layer"].cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        best = r["best_preds"].cpu().numpy()
+        np.testing.assert_allclose(best, p_full[want, np.arange(B)], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(best.sum(-1), 1.0, atol=1e-6)
+        # the stages really ran on fewer images: an image that left at exit e has no samples in the later exits
+        mean = r["mean"].cpu().numpy()
+        for e in range(1, 4):
+            gone = got < e
+            assert np.all(mean[e][gone] == 0.0)
+            np.testing.assert_allclose(mean[e][~gone], p_full[e][~gone], rtol=0, atol=1e-13)
+        act = r["active_after"]
+        assert act[0] == B and act[1] == int((got > 1).sum()) and (act[1] == 0 or act[2] == int((got > 2).sum()))
+        if thr == 0.0:
+            assert (got == 1).all() and act[1] == 0 and act[3] == 0          # everybody left at the first tested exit
+        if thr == 1.0:
+            assert (got == 3).all() and act[2] == B
+
+
+def test_dynamic_exit_needs_all_samples_in_one_chunk():
+    m = build_seeded(ResNet18MCEarlyExit, KWS["mc_block_exit"])
+    synthetic_weights_(m, 0)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=4, chunk_samples=2)
+    x = synthetic_images(4, seed=1).to(DEV)
+    with pytest.raises(ValueError, match="one chunk"):
+        eng.predict_with_exit(x, 3, 0.5)
+
+
+def test_dynamic_exit_saves_time_at_full_size():
+    """B = 250, T = 20: with a threshold that lets ~half the images leave at exit 1 the step is measurably shorter than the
+    full run (the compacted stages launch proportionally smaller grids)."""
+    import time
+    B, T = 250, 20
+    m = build_seeded(ResNet18MCEarlyExit, KWS["mc_block_exit"])
+    synthetic_weights_(m, 0)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    x = synthetic_images(B, seed=1234).to(DEV)
+    conf = eng.predict(x, T, seed=3)["mean"].max(-1).values
+    thr = float(conf[1].median())
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3
+    t_full = timed(lambda: eng.predict(x, T, seed=3))
+    t_exit = timed(lambda: eng.predict_with_exit(x, T, thr, seed=3))
+    r = eng.predict_with_exit(x, T, thr, seed=3)
+    print(f"full {t_full * 1e3:.2f} ms, dynamic exit {t_exit * 1e3:.2f} ms, active after exits {r['active_after']}")
+    assert 0.3 * B < r["active_after"][1] < 0.7 * B
+    assert t_exit < 0.9 * t_full
