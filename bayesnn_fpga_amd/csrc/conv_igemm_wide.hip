@@ -545,18 +545,18 @@ int launch_conv_igemm_wide(const ConvArgs& a_in, hipStream_t s) {
     }
     const long blocks = (((long)a.M + WBP - 1) / WBP) * (a.Cout / WBC);
     if (blocks > 0x7fffffffL) return BMI_ERR_INVALID;
-    // a grid that cannot fill the chip (small deterministic-prefix launches: B images, not samples x B) is better
-    // served by conv_igemm's 128 x 128 tiles (4x as many workgroups)
-    static const int min_blocks = [] { const char* v = std::getenv("BMI_WIDE_MIN_BLOCKS"); return v ? std::atoi(v) : 192; }();
-    if (!a.wgt_b && blocks < min_blocks) return BMI_ERR_UNSUPPORTED;
-    static const int persist = [] { const char* v = std::getenv("BMI_WIDE_PERSIST"); return v ? std::atoi(v) : 1; }();
     static const int n_cu = [] {
         int dev = 0, cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
         return cu;
     }();
+    // a grid that cannot fill the chip (small deterministic-prefix launches: B images, not samples x B) is better served by
+    // conv_igemm's 128 x 128 tiles (4x as many workgroups): below 3/4 of a workgroup per CU (BMI_WIDE_MIN_BLOCKS overrides)
+    static const int min_blocks = [] { const char* v = std::getenv("BMI_WIDE_MIN_BLOCKS"); return v ? std::atoi(v) : (n_cu > 0 ? 3 * n_cu / 4 : 192); }();
+    if (!a.wgt_b && blocks < min_blocks) return BMI_ERR_UNSUPPORTED;
+    static const int persist = [] { const char* v = std::getenv("BMI_WIDE_PERSIST"); return v ? std::atoi(v) : 1; }();
     const int shape = opt_mfma_shape_wide();
-    if (persist && !a.imap && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks > 2L * n_cu) {
+    if (persist && !a.imap && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks * 10 > (long)opt_wide_persist_min() * n_cu) {
         if (a.bf16) hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<16, true>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
         else if (shape == 16) hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<16, false>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);
         else hipLaunchKernelGGL((conv_igemm_wide_persist_kernel<32, false>), dim3((unsigned)n_cu), dim3(512), 0, s, a, (int)blocks);

@@ -135,6 +135,7 @@ static int shape_from_env(const char* primary, const char* fallback) {
     return x == 16 || x == 32 ? x : BMI_DEFAULT_MFMA_SHAPE;
 }
 int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nullptr); return v; }
+int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
@@ -158,6 +159,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "unit_entry_dtype") == 0) {
         if (value != BMI_DTYPE_F16 && value != BMI_DTYPE_BF16) return BMI_ERR_INVALID;
         opt_unit_dtype() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "wide_persist_min_x10") == 0) {
+        if (value < 10 || value > 1000) return BMI_ERR_INVALID;
+        opt_wide_persist_min() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "xcd_split") == 0) {

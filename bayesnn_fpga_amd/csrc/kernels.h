@@ -103,6 +103,7 @@ bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, 
 int& opt_mfma_shape_patch();
 int& opt_mfma_shape_wide();
 int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
+int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);
 

@@ -157,9 +157,33 @@ def cpu_baseline_1thread(wl, images, T, seed):
         torch.set_num_threads(n)
 
 
+def best_thread_count(m, x, seed, candidates):
+    """ATen's CPU convolutions do not scale to every core of a 2-socket host at batch 250 (measured: 128 threads are
+    SLOWER than one).  The baseline should be the reference's loop at its best, so a short sweep (2 passes each) picks the
+    intra-op thread count; the all-cores figure is reported next to it."""
+    import copy
+    from oracle import mcd
+    from oracle.layers import MCDropout
+    n0 = torch.get_num_threads()
+    rates = {}
+    MCDropout.native_rng = True
+    try:
+        for n in candidates:
+            torch.set_num_threads(n)
+            mm = copy.deepcopy(m)
+            mcd.mcd_predict(mm, x[:8], 1, seed)
+            t0 = time.perf_counter()
+            mcd.mcd_predict(mm, x, 2, seed)
+            rates[n] = x.shape[0] * 2 / (time.perf_counter() - t0)
+    finally:
+        MCDropout.native_rng = False
+        torch.set_num_threads(n0)
+    return max(rates, key=rates.get), rates
+
+
 def cpu_baseline(wl, batch, T, seed):
     """The oracle (port of FullAnalysis._get_output, T sequential full forwards per batch, fp32) on
-    the host cores.  Returns (MCD-samples/s, threads, mean probs)."""
+    the host cores.  Returns (MCD-samples/s, threads, mean probs, {threads: rate} of the sweep)."""
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
     from oracle import mcd
     torch.manual_seed(0)
@@ -173,14 +197,19 @@ def cpu_baseline(wl, batch, T, seed):
     # timing leg: the reference's own loop — T sequential full forwards with ATen's F.dropout as the RNG
     # (results_analyzer.py:236-248); the numpy Philox restatement above costs more than the convolutions themselves
     from oracle.layers import MCDropout
+    n_all = torch.get_num_threads()
+    cand = sorted({n for n in (n_all, n_all // 2, n_all // 4, n_all // 8, 16, 8) if 1 <= n <= n_all}, reverse=True)
+    best, sweep = best_thread_count(m, x, seed, cand)
     MCDropout.native_rng = True
+    torch.set_num_threads(best)
     try:
         t0 = time.perf_counter()
         mcd.mcd_predict(copy.deepcopy(m), x, T, seed)
         dt = time.perf_counter() - t0
     finally:
         MCDropout.native_rng = False
-    return batch * T / dt, torch.get_num_threads(), r["mean"]
+        torch.set_num_threads(n_all)
+    return batch * T / dt, best, r["mean"], sweep
 
 
 def main():
@@ -310,7 +339,7 @@ def main():
                          "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
         }
         if not a.no_cpu_baseline and world == 1:        # the CPU baseline is reported at N=1 only
-            cpu_val, threads, cpu_mean = cpu_baseline(wl, B, a.cpu_T, a.seed)
+            cpu_val, threads, cpu_mean, sweep = cpu_baseline(wl, B, a.cpu_T, a.seed)
             gpu_same = eng.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()
             other = "bf16" if a.dtype == "f16" else "f16"          # the other 16-bit instantiation on the same inputs / masks
             eng_o = model.engine(dev, max_batch=B, chunk_samples=a.chunk or None, dtype=other)
@@ -319,10 +348,12 @@ def main():
             line["cpu_baseline"] = {
                 "value": round(cpu_val, 1), "unit": "MCD-samples/s", "cores": threads, "kind": "port",
                 "threads": threads, "cores_physical": physical_cores(), "logical_cpus": os.cpu_count(),
+                "thread_sweep": {str(k): round(v, 1) for k, v in sweep.items()},
                 "value_1thread": None if one is None else round(one, 2),
                 "sample_1thread": f"same oracle loop, torch.set_num_threads(1), {a.cpu_1t_images} images x T=2",
                 "sample": f"oracle (port of FullAnalysis._get_output loop, ATen F.dropout as the RNG like the reference), 1 batch of {B} images x T={a.cpu_T}, fp32, "
-                          f"torch {torch.__version__} CPU, {os.cpu_count()} logical CPUs",
+                          f"torch {torch.__version__} CPU at its best intra-op thread count ({threads} of {os.cpu_count()} logical CPUs; "
+                          f"thread_sweep = MCD-samples/s of 2 passes per candidate)",
                 "ece_hist_final_exit_cpu": round(ece_hist_binary(cpu_mean[-1], onehot), 6),
                 "ece_hist_final_exit_gpu_same_T": round(ece_hist_binary(gpu_same[-1], onehot), 6),
                 "max_abs_mean_diff_gpu_vs_cpu": float(np.abs(gpu_same - cpu_mean).max()),

@@ -147,6 +147,8 @@ const char* bmi_error_string(int code);
  *                                           (v_mfma_f32_16x16x32_f16 | v_mfma_f32_32x32x16_f16); 0 = built-in default
  *   "xcd_split"                             0 | 1 | 2 | 4: channel-tile classes of the XCD-aware tile order (0 = chosen from
  *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
+ *   "wide_persist_min_x10"                  10..1000: conv_igemm_wide runs persistent (one workgroup per CU walking the tiles)
+ *                                           when tiles * 10 > value * CUs
  *   "unit_entry_dtype"                      BMI_DTYPE_*: how the single-kernel entry points below (unit tests) interpret
  *                                           their 16-bit buffers; engines carry their own dtype in bmi_model_desc
  * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT). */

@@ -22,17 +22,15 @@ SHAPES = [  # cin, cout, H, k, s, p, images
 ]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rounds", type=int, default=300)
-    ap.add_argument("--scale", type=int, default=1, help="multiplies the image count of every shape")
-    a = ap.parse_args()
+def screen(shapes, rounds, scale=1, verbose=True):
+    """Runs every shape `rounds` times beside concurrent HBM traffic; returns the number of launches whose output differs
+    in any bit from the first launch of the same inputs."""
     lib, dev = _lib.lib(), "cuda:0"
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator().manual_seed(7)
     cases = []
-    for cin, cout, H, k, s, p, n in SHAPES:
-        n = n * a.scale
+    for cin, cout, H, k, s, p, n in shapes:
+        n = n * scale
         x = torch.randn(n, H, H, cin, generator=g).half().to(dev)
         w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).half().to(dev)
         sc, bi = (0.5 + torch.rand(cout, generator=g)).to(dev), (0.1 * torch.randn(cout, generator=g)).to(dev)
@@ -52,7 +50,7 @@ def main():
     noise_stream = torch.cuda.Stream()
     junk = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     bad = 0
-    for r in range(a.rounds):
+    for r in range(rounds):
         with torch.cuda.stream(noise_stream):
             junk.add_(1)                                   # 0.5 GB of HBM traffic beside the convs
         for i, c in enumerate(cases):
@@ -63,8 +61,18 @@ def main():
             if not torch.equal(c[4], first[i]):
                 bad += 1
                 d = (c[4].float() - first[i].float()).abs()
-                print(f"round {r} shape {SHAPES[i]}: {int((d > 0).sum())} elements differ, max {float(d.max()):.4g}", flush=True)
-    print(f"{a.rounds} rounds x {len(cases)} shapes: {bad} mismatching launches")
+                if verbose:
+                    print(f"round {r} shape {shapes[i]}: {int((d > 0).sum())} elements differ, max {float(d.max()):.4g}", flush=True)
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=300)
+    ap.add_argument("--scale", type=int, default=1, help="multiplies the image count of every shape")
+    a = ap.parse_args()
+    bad = screen(SHAPES, a.rounds, a.scale)
+    print(f"{a.rounds} rounds x {len(SHAPES)} shapes: {bad} mismatching launches")
     sys.exit(1 if bad else 0)
 
 
