@@ -1,0 +1,324 @@
+// 3x3 / stride-1 / pad-1 convolution on small maps (8x8, 4x4) with Cout % 256 == 0: the "patch-wide" kernel — the input
+// patch resident in LDS like conv3x3_patch, the 256 x 256 tile, 8 waves and ping-pong main loop of conv_igemm_wide.
+//
+// Why a third 3x3 kernel.  On the 8x8 / 4x4 maps conv3x3_patch's workgroup is 128 channels x 128 pixels, wave tile
+// 64 x 64: 8 fragment reads (ds_read_b128) per 16 MFMAs.  Two such workgroups per CU read 128 KB of LDS per 64-deep K-step
+// against 1024 cycles of MFMA issue per SIMD, i.e. the LDS pipe (128 B/clk) is as busy as the matrix pipe.  A build that
+// skipped half of the pixel-fragment reads (wrong results, timing probe) ran the 8x8 and 4x4 classes 5-6 % faster, the
+// 16x16 class (wave tile 64 x 128 already) not at all.  Here every wave owns 64 channels x 128 pixels (12 reads per 32 MFMAs),
+// the weight tile is shared by 256 pixels instead of 128 and the patch by 256 channels instead of 128: half the L2 -> LDS
+// bytes per FLOP.  That tile needs one 512-thread workgroup per CU, so nothing else covers a refill of the patch: it is
+// double buffered in 32-channel sub-patches (K-step = one tap x 32 channels = one 16x16x32 MFMA per tile), and the next
+// sub-patch streams in piece by piece behind the MFMAs of the current one.
+//
+//   tile       = IMGS whole images (256 pixels: 4 maps of 8x8 or 16 maps of 4x4) x 256 output channels
+//   waves      = 2 channel halves (g) x [2 (channels) x 2 (pixels)], wave tile 64 ch x 128 px = 4 x 8 tiles of
+//                v_mfma_f32_16x16x32 — accumulator layout and epilogue identical to conv_igemm_wide
+//   LDS        = 3 weight stages [256 ch][32 k] (64-byte rows) + 2 sub-patches [cells][32 ch] (64-byte cells)
+//   64-B rows  = four rows share a 256-byte bank window, so the 16-byte chunk c of row r is stored at position
+//                (c + rot(r)) & 3 with rot distinct for the four rows of a window that one ds_read_b128 lane group
+//                touches: weights rot = row >> 2; patch cells (pitch % 4 == 0, so the window is x & 3) rot = y, with the 16
+//                pixels of an MFMA tile a 4 x 4 block (4 windows x 4 rows) — conflict-free for every tap shift, and a tap
+//                only adds its ky to the position.  LDS-DMA writes lane-linearly, so the rotation is applied to the
+//                per-lane SOURCE address.
+//   main loop  = conv_igemm_wide's ping-pong (two wave groups one barrier apart, raw s_barrier, LOAD part / MFMA part),
+//                two phases per K-step: phase 0 reads the 4 channel fragments + pixel tiles 0-3 and issues the weight DMA
+//                of the step AFTER NEXT (a 32-deep K-step is too short to hide an L2 round trip: with 2 stages the
+//                kernel ran 845-1030 TF/s) + one piece of the next sub-patch, phase 1 reads pixel tiles 4-7.  The 9 taps of a
+//                chunk are unrolled: stage index, tap shift and vmcnt immediates are compile-time.
+//                Intervals between barriers, K-step T: group 0 LOAD 4T+2k, MFMA 4T+2k+1; group 1 one later.
+//                WAR  weight stage (T+2)%3 was last read in 4T-3 (group 1, phase 0 of T-1; retired by its lgkmcnt(0) in 4T-2):
+//                     refilled from 4T on.  Sub-patch (c+1)&1 was last read in step 9c-1; its refill starts in step 9c+1.
+//                RAW  in interval 4T+3 every wave waits (counted vmcnt) until only the DMA issued in step T and the patch
+//                     piece of step T-1 are in flight, i.e. until the weights of step T+1 have landed, before the barrier that
+//                     ends 4T+3; first reads of step T+1 in 4T+4.  At tap 8 the count (2) also retires the whole next sub-patch.
+// Reference semantics: BasicBlock.forward SA/models/resnet18/resnet18.py:32-48 (conv2 of every block, conv1 of the
+// stride-1 blocks).
+#include <cstdlib>
+
+#include "conv_epilogue.h"
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+static __device__ unsigned int g_zero_page_pw[64];
+
+#define GLDS16(SRC, LDSPTR)                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),       \
+                                     (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
+
+template <int TW>
+struct PwGeom {
+    static constexpr int TH = TW, IMGS = 256 / (TH * TW);
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int PWP = TW == 8 ? 12 : 8;                 // cell pitch, % 4 == 0: bank window of a cell = x & 3
+    static constexpr int CELLS = IMGS * PH * PWP;                 // 480 | 768
+    static constexpr int ITER_P = (CELLS * 4 + 511) / 512;        // 16-byte pieces per thread and sub-patch: 4 | 6
+    static constexpr int PBUF = ITER_P * 512 * 16;                // 32 KB | 48 KB
+    static constexpr int WST = 256 * 64;                          // one weight stage
+    static constexpr int NST = 3;                                 // weight stages: the tile of K-step T+2 is in flight during T
+    static constexpr int MAIN = NST * WST + 2 * PBUF;             // 112 KB | 144 KB
+    static constexpr int LDS_BYTES = MAIN > 2 * BMI_EPILOGUE_LDS_BYTES ? MAIN : 2 * BMI_EPILOGUE_LDS_BYTES;
+    // tile pixel p (0..255) -> image of the tile and output coordinates: the 16 pixels of one MFMA tile are a 4 x 4 block
+    __host__ __device__ static constexpr int p_img(int p) { return p / (TH * TW); }
+    __host__ __device__ static constexpr int p_ox(int p) { return TW == 8 ? 4 * ((p >> 4) & 1) + (p & 3) : p & 3; }
+    __host__ __device__ static constexpr int p_oy(int p) { return TW == 8 ? 4 * ((p >> 5) & 1) + ((p >> 2) & 3) : (p >> 2) & 3; }
+};
+
+template <int TW, bool PLAIN, bool BF>
+__global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
+    using G = PwGeom<TW>;
+    constexpr int TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
+    constexpr int TJ = 4, TI = 4, TP = 8;
+    typedef float accv __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
+    char* const wst = smem;
+    char* const pbuf = smem + G::NST * G::WST;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
+
+    const int n_ctiles = a.Cout / 256;
+    const int n_ptiles = (a.N + IMGS - 1) / IMGS;
+    int ptile, ctile;
+    xcd_tile_map(blockIdx.x, n_ptiles, n_ctiles, ptile, ctile, a.xcd_split);
+    const int ch0 = ctile * 256;
+    const int n0 = ptile * IMGS;
+    const int Ktot = 9 * a.Cin;
+    const int nC = a.Cin / 32;
+
+    // ---- per-thread DMA sources ----
+    // weights: piece q = tid + 512 i -> row (tid >> 2) + 128 i, position tid & 3 holds chunk (pos - (row >> 2)) & 3
+    const _Float16* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 128 * i;
+        wsrc[i] = a.wgt + (size_t)(ch0 + row) * Ktot + (((tid & 3) - (row >> 2)) & 3) * 8;
+    }
+#define ISSUE_W(KOFF, ST)                                                                        \
+    {                                                                                            \
+        GLDS16(wsrc[0] + (KOFF), wst + (ST) * G::WST + (wave * 64) * 16);                        \
+        GLDS16(wsrc[1] + (KOFF), wst + (ST) * G::WST + (512 + wave * 64) * 16);                  \
+    }
+    ISSUE_W(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // sub-patch: piece q = tid + 512 i -> cell q >> 2, position q & 3 holds chunk (pos - y) & 3; element offset of its
+    // source at channel chunk 0, or -1 (padding / halo beyond the map / cells of the pitch / images beyond N -> zero page)
+    int psrc[G::ITER_P];
+#pragma unroll
+    for (int i = 0; i < G::ITER_P; ++i) {
+        const int q = tid + 512 * i;
+        const int cell = q >> 2, pos = q & 3;
+        const int rowc = cell / PWP, x = cell - rowc * PWP;
+        const int img = rowc / PH, y = rowc - img * PH;
+        const int n = n0 + img;
+        const int iy = y - 1, ix = x - 1;
+        const bool ok = cell < G::CELLS && x < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        psrc[i] = ok ? (int)((((size_t)(map_image(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + ((pos - y) & 3) * 8) : -1;
+    }
+#define ISSUE_P(I, C0, PB)                                                                                   \
+    GLDS16(psrc[I] >= 0 ? a.in + (size_t)(unsigned)psrc[I] + (C0) : (const _Float16*)g_zero_page_pw,       \
+           pbuf + (PB) * G::PBUF + ((I) * 512 + wave * 64) * 16)
+#pragma unroll
+    for (int i = 0; i < G::ITER_P; ++i) ISSUE_P(i, 0, 0);
+    if (9 * nC > 1) ISSUE_W(a.Cin, 1);                         // K-step 1 = tap 1 of chunk 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- per-lane fragment geometry ----
+    const int a_off = (g * 128 + wc * 64 + l16) * 64;
+    const int a_byte = ((kq + (l16 >> 2)) & 3) << 4;              // position of chunk kq in this lane's rows ((row >> 2) & 3 == l16 >> 2)
+    int bbyte[TP], bpos[TP];                                      // byte offset of the pixel's cell at tap (0,0); kq + y of that cell
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int p = wp * 128 + 16 * j + l16;
+        const int ox = G::p_ox(p), oy = G::p_oy(p);
+        bbyte[j] = ((G::p_img(p) * PH + oy) * PWP + ox) * 64;
+        bpos[j] = kq + oy;
+    }
+
+    accv acc[TI][TP];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+#define RAW_BARRIER()                                  \
+    {                                                  \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_sched_barrier(0);             \
+    }
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+    // What may still be in flight when K-step `TAP` of a chunk ends: the weight tile of the step after next (2 DMA
+    // instructions, issued this step) and the sub-patch pieces issued this step and the step before (one each at taps
+    // 1..ITER_P when another chunk follows); everything older — in particular the next step's weights — has landed.
+#define END_OF_STEP_WAIT(TAP)                                                                                  \
+    {                                                                                                          \
+        constexpr int pieces_ = ((TAP) >= 1 && (TAP) <= G::ITER_P ? 1 : 0) + ((TAP) >= 2 && (TAP) <= G::ITER_P + 1 ? 1 : 0); \
+        if (!last) { WAIT_VM(2 + pieces_); }                                                                   \
+        else if ((TAP) >= 7) { WAIT_VM(0); }                                                                   \
+        else { WAIT_VM(2); }                                                                                   \
+    }
+    // One K-step = tap TAP x this chunk's 32 channels.  Two phases (LOAD part, barrier, MFMA part, barrier); the two wave
+    // groups run one barrier apart.  Weight stage = TAP % 3 (9 taps per chunk: the stage index repeats per chunk).
+#define PW_STEP(TAP)                                                                                           \
+    {                                                                                                          \
+        constexpr int ky_ = (TAP) / 3, kx_ = (TAP) - 3 * ky_;                                                  \
+        const char* ws_ = wst + ((TAP) % 3) * G::WST + a_off + a_byte;                                         \
+        const char* pb_ = pb + (ky_ * PWP + kx_) * 64;                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+            if (kk == 0) {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+                bf[j] = *(const half8*)(pb_ + bbyte[4 * kk + j] + (((bpos[4 * kk + j] + ky_) & 3) << 4));      \
+            if (kk == 0) {                                                                                     \
+                /* weights of the step after next: (tap + 2) of this chunk, or taps 0 / 1 of the next one */   \
+                if ((TAP) < 7) { ISSUE_W(((TAP) + 2) * a.Cin + c32, ((TAP) + 2) % 3); }                        \
+                else if (!last) { ISSUE_W(((TAP) - 7) * a.Cin + c32 + 32, ((TAP) + 2) % 3); }                  \
+                if ((TAP) >= 1 && (TAP) <= G::ITER_P && !last) { ISSUE_P((TAP) - 1, c32 + 32, nb); }           \
+            }                                                                                                  \
+            if (kk == 1 && g == 1) END_OF_STEP_WAIT(TAP);      /* interval 4T+3, group 1: LOAD part */         \
+            RAW_BARRIER();                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+            __builtin_amdgcn_s_setprio(1);                                                                     \
+            _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+                    acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);                  \
+            __builtin_amdgcn_s_setprio(0);                                                                     \
+            if (kk == 1 && g == 0) END_OF_STEP_WAIT(TAP);      /* interval 4T+3, group 0: MFMA part */         \
+            RAW_BARRIER();                                                                                     \
+        }                                                                                                      \
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RAW_BARRIER();                      // weight stages 0, 1 and sub-patch 0 have landed
+    if (g == 1) RAW_BARRIER();          // stagger
+    half8 af[TI], bf[4];
+    for (int chunk = 0; chunk < nC; ++chunk) {
+        const bool last = chunk + 1 == nC;
+        const int c32 = chunk * 32;
+        const int nb = (chunk + 1) & 1;
+        const char* pb = pbuf + (chunk & 1) * G::PBUF;
+        PW_STEP(0) PW_STEP(1) PW_STEP(2) PW_STEP(3) PW_STEP(4) PW_STEP(5) PW_STEP(6) PW_STEP(7) PW_STEP(8)
+    }
+    if (g == 0) RAW_BARRIER();          // re-align the two groups before the epilogue reuses the LDS
+#undef PW_STEP
+#undef END_OF_STEP_WAIT
+#undef WAIT_VM
+#undef ISSUE_W
+#undef ISSUE_P
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- fused 1x1 strided shortcut (BasicBlock downsample path, resnet18.py:42-45): Cin2 / 32 more K-steps on the block
+    //      input sampled at the output pixels' positions.  All eight waves in lockstep, two [weights | pixels] stages of
+    //      32 KB in the LDS the main loop has left (every DMA is drained, every fragment read retired), one barrier per
+    //      step: the next step's tiles fly while this one computes.  4-8 steps against 72-144 of the main loop. ----
+    if (a.in2) {
+        const int nC2 = a.Cin2 / 32;
+        const _Float16* w2src[2];
+        const _Float16* x2src[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 2) + 128 * i;               // weight row / tile pixel of this thread's piece
+            const int lg = (((tid & 3) - (row >> 2)) & 3) * 8;   // logical chunk held at position tid & 3
+            w2src[i] = a.wgt2 + (size_t)(ch0 + row) * a.Cin2 + lg;
+            const int n = n0 + G::p_img(row);
+            x2src[i] = n < a.N ? a.in2 + (((size_t)(map_image(a, n) % a.in2_mod) * a.H2 + (size_t)G::p_oy(row) * a.stride2) * a.W2 +
+                                          (size_t)G::p_ox(row) * a.stride2) * a.Cin2 + lg
+                               : nullptr;
+        }
+#define ISSUE_S(C2, ST)                                                                                        \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+            GLDS16(w2src[i] + (C2) * 32, smem + (ST) * 32768 + (i * 512 + wave * 64) * 16);                    \
+            GLDS16(x2src[i] ? x2src[i] + (C2) * 32 : (const _Float16*)g_zero_page_pw,                          \
+                   smem + (ST) * 32768 + 16384 + (i * 512 + wave * 64) * 16);                                  \
+        }                                                                                                      \
+    }
+        RAW_BARRIER();                   // both groups are past their last fragment reads
+        ISSUE_S(0, 0);
+        for (int c2 = 0; c2 < nC2; ++c2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RAW_BARRIER();               // stage c2 & 1 has landed for every wave; everyone is done with the other stage
+            if (c2 + 1 < nC2) ISSUE_S(c2 + 1, (c2 + 1) & 1);
+            const char* ss = smem + (c2 & 1) * 32768;
+            half8 sa[TI], sb[TP];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) sa[i] = *(const half8*)(ss + a_off + i * 16 * 64 + a_byte);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) sb[j] = *(const half8*)(ss + 16384 + (wp * 128 + 16 * j + l16) * 64 + a_byte);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) acc[i][j] = mfma_16x16x32<BF>(sa[i], sb[j], acc[i][j]);
+        }
+#undef ISSUE_S
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RAW_BARRIER();                   // the epilogue reuses the stages
+    }
+#undef RAW_BARRIER
+
+    // ---- epilogue: each channel half (4 waves) in its own 64 KB (conv_epilogue.h) ----
+    const int chg = ch0 + 128 * g;
+    auto pixmap = [&](int p, int& n, int& rem) -> bool {
+        n = n0 + G::p_img(p);
+        rem = G::p_oy(p) * TW + G::p_ox(p);
+        const bool ok = n < a.N;
+        n = map_image(a, n);
+        return ok;
+    };
+    auto offmap = [&](int p, size_t& off) -> bool {
+        int n, rem;
+        const bool ok = pixmap(p, n, rem);
+        off = ((size_t)n * (TH * TW) + rem) * a.Cout;
+        return ok;
+    };
+    epilogue_coalesced<TJ, PLAIN, 16, BF>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+}
+
+// Shapes this kernel takes (3x3 / stride 1 / pad 1 on 8x8 or 4x4 maps, Cout % 256 == 0).
+bool conv_takes_pw_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo) {
+    static const int on = [] { const char* v = std::getenv("BMI_CONV_PW"); return v ? std::atoi(v) : 1; }();
+    return on && ksize == 3 && stride == 1 && pad == 1 && cin % 64 == 0 && cout % 256 == 0 && ((ho == 8 && wo == 8) || (ho == 4 && wo == 4));
+}
+
+template <int TW>
+static int launch_pw(const ConvArgs& a, hipStream_t s) {
+    const long tiles = (long)((a.N + PwGeom<TW>::IMGS - 1) / PwGeom<TW>::IMGS) * (a.Cout / 256);
+    if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
+    const dim3 grid((unsigned)tiles), block(512);
+    const bool plain = conv_epilogue_is_plain(a);
+    if (a.bf16) {
+        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, true>), grid, block, 0, s, a);
+    } else {
+        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, false>), grid, block, 0, s, a);
+    }
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// BMI_ERR_UNSUPPORTED -> the caller falls back to conv3x3_patch.
+int launch_conv3x3_pw(const ConvArgs& a_in, hipStream_t s) {
+    if (!opt_conv_pw() || a_in.in_bits || a_in.wgt_b) return BMI_ERR_UNSUPPORTED;
+    if (a_in.in2 && (!a_in.wgt2 || a_in.Cin2 % 64 != 0 || a_in.in2_mod <= 0 || a_in.stride2 < 1)) return BMI_ERR_INVALID;
+    if (!conv_takes_pw_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout, a_in.Ho, a_in.Wo)) return BMI_ERR_UNSUPPORTED;
+    if (a_in.N <= 0 || a_in.in_mod <= 0 || a_in.B <= 0 || (a_in.res && a_in.res_mod <= 0)) return BMI_ERR_INVALID;
+    if ((size_t)a_in.in_mod * a_in.H * a_in.W * a_in.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets
+    // No minimum-grid rule: which kernel runs depends on the conv's SHAPE only, never on the batch or on how many samples a
+    // launch carries, so a result does not depend on batch size, chunking or sharding (conv3x3_patch sums the channels in
+    // 64-wide chunks, this kernel in 32-wide ones: equal to fp32 rounding, not bit for bit).  An under-filled grid (B * T <
+    // ~200 images) runs at most one tile time per launch either way.
+    ConvArgs a = a_in;
+    a.xcd_split = xcd_split_for(a.Cout / 256, (size_t)a.Cout * 9 * a.Cin * 2);
+    return a.Ho == 8 ? launch_pw<8>(a, s) : launch_pw<4>(a, s);
+}

@@ -251,7 +251,8 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     }
     if (a.Cout % 128 == 0) {
         // 256-pixel tiles (single LDS buffer, 2 barriers per K-step) halve the weight-tile traffic per FLOP
-        if (big && (long)(a.M / 256) * (a.Cout / 128) >= 400 && a.ksize == 3) return launch_cfg<128, 256, 2, 2, false>(a, s);
+        const long m_sel = a.n_ref > 0 ? (long)a.n_ref * a.Ho * a.Wo : a.M;
+        if (big && (m_sel / 256) * (a.Cout / 128) >= 400 && a.ksize == 3) return launch_cfg<128, 256, 2, 2, false>(a, s);
         return launch_cfg<128, 128, 2, 2, true>(a, s);
     }
     return launch_cfg<64, 128, 1, 4, true>(a, s);

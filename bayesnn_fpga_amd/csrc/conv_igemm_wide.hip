@@ -553,7 +553,8 @@ int launch_conv_igemm_wide(const ConvArgs& a_in, hipStream_t s) {
     // a grid that cannot fill the chip (small deterministic-prefix launches: B images, not samples x B) is better served by
     // conv_igemm's 128 x 128 tiles (4x as many workgroups): below 3/4 of a workgroup per CU (BMI_WIDE_MIN_BLOCKS overrides)
     static const int min_blocks = [] { const char* v = std::getenv("BMI_WIDE_MIN_BLOCKS"); return v ? std::atoi(v) : (n_cu > 0 ? 3 * n_cu / 4 : 192); }();
-    if (!a.wgt_b && blocks < min_blocks) return BMI_ERR_UNSUPPORTED;
+    const long blocks_sel = a.n_ref > 0 ? (((long)a.n_ref * a.Ho * a.Wo + WBP - 1) / WBP) * (a.Cout / WBC) : blocks;
+    if (!a.wgt_b && blocks_sel < min_blocks) return BMI_ERR_UNSUPPORTED;
     static const int persist = [] { const char* v = std::getenv("BMI_WIDE_PERSIST"); return v ? std::atoi(v) : 1; }();
     const int shape = opt_mfma_shape_wide();
     if (persist && !a.imap && n_cu > 0 && conv_epilogue_is_plain(a) && a.Cout <= WBN_MAX && blocks * 10 > (long)opt_wide_persist_min() * n_cu) {

@@ -105,6 +105,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int* family) {
         return (v && std::strcmp(v, "igemm") == 0) ? 2 : 1;
     }();
     if (mode <= 1) {
+        *family = BMI_CONV_FAMILY_PW;
+        const int rcw = launch_conv3x3_pw(a, s);
+        if (rcw != BMI_ERR_UNSUPPORTED) return rcw;
         *family = BMI_CONV_FAMILY_PATCH;
         const int rc = launch_conv3x3_patch(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
@@ -136,6 +139,7 @@ static int shape_from_env(const char* primary, const char* fallback) {
 }
 int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nullptr); return v; }
 int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
+int& opt_conv_pw() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
@@ -164,6 +168,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "wide_persist_min_x10") == 0) {
         if (value < 10 || value > 1000) return BMI_ERR_INVALID;
         opt_wide_persist_min() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "conv_pw") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_conv_pw() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "xcd_split") == 0) {
@@ -565,6 +574,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.scale = d.scale; a.bias = d.bias;
             a.out = (_Float16*)(ws + e->tensors[d.out].offset);
             a.N = N;
+            a.n_ref = (tin.stoch || (d.residual >= 0 && e->tensors[d.residual].stoch) || op.stoch) ? B * e->chunk : B;
             a.imap = imap; a.Bc = Bc;
             a.in_mod = tin.stoch ? n_rows : B;
             if (d.residual >= 0) {
@@ -850,7 +860,7 @@ int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2
     a.in2 = (const _Float16*)in2; a.wgt2 = (const _Float16*)weight2; a.in2_mod = n; a.H2 = 2 * h; a.W2 = 2 * w;
     a.Cin2 = cin2; a.stride2 = 2;
     a.site = resolve_site(nullptr, 0, 0);
-    return launch_conv3x3_patch(a, (hipStream_t)stream);
+    return launch_conv(a, (hipStream_t)stream);     // conv3x3_pw where it applies, else conv3x3_patch
 }
 
 static int elt_args(EltArgs& a, const void* in, void* out, int n, int in_mod, int hw, int c, const bmi_site* site, int batch,

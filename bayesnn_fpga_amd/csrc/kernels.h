@@ -32,6 +32,9 @@ struct ConvArgs {
     int site_inner;          // 1: a.site multiplies before bias_post / residual / ReLU
     _Float16* out;
     int N;        // output images in this launch (= samples_in_chunk * B in the suffix)
+    int n_ref;    // images of a FULL chunk of this engine (B x planned chunk; 0 = N): kernel SELECTION looks at this, not at N,
+                  // so a t-shard (fewer samples per launch, e.g. one rank of eight) runs the same kernels — and gets the
+                  // same bits — as the single-rank run
     int in_mod;   // input image = n % in_mod  (B when the input is deterministic)
     int res_mod;
     int H, W, Cin;
@@ -82,6 +85,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s);  // 256x256 tiles; BMI_ERR_UNSUPPORTED -> conv_igemm
 bool conv_takes_wide_kernel(int cin, int cout);
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
+int launch_conv3x3_pw(const ConvArgs& a, hipStream_t s);      // 8x8 / 4x4 maps, Cout % 256 == 0; BMI_ERR_UNSUPPORTED -> conv3x3_patch
 int launch_conv(const ConvArgs& a, hipStream_t s, int* family = nullptr);   // picks the kernel; *family = BMI_CONV_FAMILY_*
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int bf16, hipStream_t s);
@@ -104,6 +108,7 @@ int& opt_mfma_shape_patch();
 int& opt_mfma_shape_wide();
 int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
 int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
+int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);
 

@@ -221,52 +221,69 @@ int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Direct convolution for the 3-channel network input.  One thread = one output pixel x 8 output
-// channels; weights [Cout][k][k][Cin] fp32 staged in LDS.  fp32 math, fp16 NHWC store.
+// Direct convolution for the 3-channel network input; weights [Cout][k][k][Cin] fp32 staged (transposed) in LDS.
+// fp32 math (same fmaf order over the taps as before: identical results), fp16 NHWC store.
 #define STEM_MAX_W 4096  // floats of weight in LDS (64 x 3x3x3 = 1728)
+// One thread = one output pixel x 32 output channels (lane = consecutive pixels: the fp32 NCHW reads and the 64-byte NHWC
+// stores are coalesced; a tap's 32 weights are an LDS broadcast of 8 x ds_read_b128).  The first version mapped 8 lanes to
+// one pixel (8 channels each): every wave-load fetched 8 distinct words and the kernel sat at 80 us for 0.9 GFLOP.
 template <bool BF>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         _Float16* __restrict__ out, int N, int Cin, int H, int W, int Cout,
                                                         int ks, int stride, int pad, int Ho, int Wo, int relu) {
-    __shared__ float wl[STEM_MAX_W];
+    __shared__ __attribute__((aligned(16))) float wl[STEM_MAX_W];      // transposed: [tap][Cout]
     const int kvol = ks * ks * Cin;
-    for (int i = threadIdx.x; i < Cout * kvol; i += blockDim.x) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cout * kvol; i += blockDim.x) { const int c = i / kvol, t = i - c * kvol; wl[t * Cout + c] = w[i]; }
     __syncthreads();
-    const int cg = Cout >> 3;
-    const long total = (long)N * Ho * Wo * cg;
+    const int c0 = blockIdx.y * 32;                                    // this block's 32 output channels (uniform: LDS broadcast)
+    const int nc = min(32, Cout - c0);                                 // multiple of 8
+    const long total = (long)N * Ho * Wo;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int c8 = (int)(i % cg) * 8;
-    long q = i / cg;
+    long q = i;
     const int ox = (int)(q % Wo); q /= Wo;
     const int oy = (int)(q % Ho);
     const int n = (int)(q / Ho);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[e] = 0.f;
     for (int ky = 0; ky < ks; ++ky) {
         const int iy = oy * stride - pad + ky;
-        if ((unsigned)iy >= (unsigned)H) continue;
+        const bool oky = (unsigned)iy < (unsigned)H;
         for (int kx = 0; kx < ks; ++kx) {
             const int ix = ox * stride - pad + kx;
-            if ((unsigned)ix >= (unsigned)W) continue;
+            const bool ok = oky && (unsigned)ix < (unsigned)W;
             for (int ci = 0; ci < Cin; ++ci) {
-                const float xv = x[(((size_t)n * Cin + ci) * H + iy) * W + ix];
-                const int wk = (ky * ks + kx) * Cin + ci;
+                const float xv = ok ? x[(((size_t)n * Cin + ci) * H + iy) * W + ix] : 0.f;
+                const float* wr = wl + ((ky * ks + kx) * Cin + ci) * Cout + c0;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(xv, wl[(c8 + e) * kvol + wk], acc[e]);
+                for (int e4 = 0; e4 < 8; ++e4) {
+                    if (4 * e4 < nc) {
+                        const float4 w4 = *(const float4*)(wr + 4 * e4);
+                        acc[4 * e4] = fmaf(xv, w4.x, acc[4 * e4]); acc[4 * e4 + 1] = fmaf(xv, w4.y, acc[4 * e4 + 1]);
+                        acc[4 * e4 + 2] = fmaf(xv, w4.z, acc[4 * e4 + 2]); acc[4 * e4 + 3] = fmaf(xv, w4.w, acc[4 * e4 + 3]);
+                    }
+                }
             }
         }
     }
-    half8 o;
+    _Float16* op = out + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = acc[e];
-        if (scale) v *= scale[c8 + e];
-        if (bias) v += bias[c8 + e];
-        if (relu) v = fmaxf(v, 0.f);
-        o[e] = a16_from_f32<BF>(v);
+    for (int g8 = 0; g8 < 4; ++g8) {
+        if (8 * g8 < nc) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = acc[8 * g8 + e];
+                if (scale) v *= scale[c0 + 8 * g8 + e];
+                if (bias) v += bias[c0 + 8 * g8 + e];
+                if (relu) v = fmaxf(v, 0.f);
+                o[e] = a16_from_f32<BF>(v);
+            }
+            *(half8*)(op + 8 * g8) = o;
+        }
     }
-    *(half8*)(out + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c8) = o;
 }
 
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
@@ -274,11 +291,10 @@ int launch_stem_conv(const float* x, const float* w, const float* scale, const f
     if (cout % 8 != 0 || cout * ksize * ksize * cin > STEM_MAX_W) return BMI_ERR_UNSUPPORTED;
     if (n <= 0) return BMI_ERR_INVALID;
     const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wdt + 2 * pad - ksize) / stride + 1;
-    const long total = (long)n * ho * wo * (cout / 8);
-    if (bf16) hipLaunchKernelGGL(stem_conv_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, bias, out,
-                                 n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
-    else hipLaunchKernelGGL(stem_conv_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, bias, out,
-                            n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+    const long total = (long)n * ho * wo;
+    const dim3 grid((unsigned)((total + 255) / 256), (unsigned)((cout + 31) / 32)), block(256);
+    if (bf16) hipLaunchKernelGGL(stem_conv_kernel<true>, grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+    else hipLaunchKernelGGL(stem_conv_kernel<false>, grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

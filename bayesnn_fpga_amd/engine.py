@@ -421,8 +421,8 @@ class MCDEngine(CompiledGraph):
         n = (C.c_int64 * _lib.PROFILE_SLOTS)()
         _lib.check(self.lib.bmi_profile_read(self.handle, ms, n), "bmi_profile_read")
         out = {_lib.PROFILE_NAMES.get(i, str(i)): (ms[i], n[i]) for i in range(_lib.PROFILE_SLOTS) if n[i]}
-        fms, fn, ffl, fby = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)(), (C.c_double * 3)()
+        fms, fn, ffl, fby = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)(), (C.c_double * 4)()
         _lib.check(self.lib.bmi_profile_conv_families(self.handle, fms, fn, ffl, fby), "bmi_profile_conv_families")
-        names = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel")
-        self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i], bytes=fby[i]) for i in range(3) if fn[i]}
+        names = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel")
+        self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i], bytes=fby[i]) for i in range(4) if fn[i]}
         return out

@@ -97,7 +97,7 @@ def hbm_traffic(workload, launches_per_step):
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     if not os.path.exists(path):
         return None, None
-    ks = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch"))}
+    ks = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw"))}
     n = sum(v["launches"] for v in ks.values())
     if n == 0 or n % launches_per_step:
         return None, None                   # collected for another batch / T / chunking: do not quote it

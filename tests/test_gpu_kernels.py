@@ -323,12 +323,20 @@ def test_mask_bits_and_masked_input_conv():
     torch.testing.assert_close(out1.float().cpu().permute(0, 3, 1, 2), ref1, rtol=2e-3, atol=2e-3)
 
 
+@pytest.fixture(params=[0, 1], ids=["patch", "pw"])
+def pw_mode(request):
+    _lib.set_option("conv_pw", request.param)
+    yield request.param
+    _lib.set_option("conv_pw", 1)
+
+
 @pytest.mark.parametrize("name,cin2", [("S2", 64), ("S3", 128), ("S4", 256)])
-def test_conv3x3_with_fused_shortcut(name, cin2):
-    """BasicBlock tail with downsample in ONE launch: relu(conv3x3(a) + conv1x1_s2(x) + bias)."""
+def test_conv3x3_with_fused_shortcut(name, cin2, pw_mode):
+    """BasicBlock tail with downsample in ONE launch: relu(conv3x3(a) + conv1x1_s2(x) + bias); in conv3x3_patch and (8x8 /
+    4x4 maps, Cout % 256 == 0) in conv3x3_pw."""
     lib = _lib.lib()
     cin, cout, H, _, _, _ = SHAPES[name]
-    n = 5
+    n = 5 if pw_mode == 0 else 21
     g = _gen(77)
     a_in = torch.randn(n, H, H, cin, generator=g).to(torch.float16).to(DEV)
     x_in = torch.randn(n, 2 * H, 2 * H, cin2, generator=g).to(torch.float16).to(DEV)
@@ -596,3 +604,41 @@ def test_bf16_elementwise_kernels(bf16_entries):
                                  gh.stream()), "bmi_dense_f32")
     torch.cuda.synchronize()
     torch.testing.assert_close(d.cpu().double(), flat.cpu().double() @ w.double().T, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,n,general,dt", [("S3", 5, False, "f16"), ("S3", 37, True, "f16"), ("S4", 3, False, "f16"), ("S4", 50, True, "f16"),
+                                              ("S3", 9, True, "bf16"), ("S4", 17, False, "bf16")])
+def test_conv3x3_pw_kernel(name, n, general, dt):
+    """conv3x3_pw (256 x 256 tile, 32-channel double-buffered sub-patches, rotated 64-byte LDS rows) on the 8x8 and 4x4 map
+    classes: ragged image counts (tiles with missing images), plain and general epilogue (residual + ReLU + fused
+    elementwise site with bit-exact mask), fp16 and bf16 — against the fp32 reference on the rounded operands."""
+    cin, cout, H, k, s, p = SHAPES[name]
+    B, seed, t0 = n, 5, 2
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = _gen(31)
+    x = torch.randn(n, H, H, cin, generator=g).to(tdt).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(tdt).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    res = torch.randn(n, H, H, cout, generator=g).to(tdt).to(DEV) if general else None
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=3, p=0.25) if general else None
+    if dt == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    try:
+        out = gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=B, t0=t0, seed=seed, out_dtype=tdt)
+        _lib.set_option("conv_pw", 0)
+        out_patch = gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=B, t0=t0, seed=seed, out_dtype=tdt)
+    finally:
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+        _lib.set_option("conv_pw", 1)
+    ref = gh.conv_ref(x, w, scale, bias, res, True, s, p, n, n, n)
+    if site is not None:
+        mult = gh.folded_site_mask(site, B, cout, H, H, 1, t0, seed)
+        ref = ref * mult
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    tol = 2e-3 if dt == "f16" else 1e-2
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
+    # same values as the patch kernel up to the fp32 summation order over K (different chunking of the channels)
+    torch.testing.assert_close(got, out_patch.float().cpu().permute(0, 3, 1, 2), rtol=tol, atol=tol)
+    if site is not None:
+        assert torch.equal(got[mult == 0], torch.zeros_like(got[mult == 0])) and (mult == 0).any()

@@ -22,6 +22,7 @@ SHAPES = [  # cin, cout, H, k, s, p, images
     (256, 512, 8, 3, 2, 1, 5000),    # D4: 626 tiles  -> persistent
     (256, 512, 8, 1, 2, 0, 5000),    # P4: 1x1 taps (4 K-steps per tile), persistent
     (128, 128, 16, 3, 1, 1, 257), (256, 256, 8, 3, 1, 1, 515), (512, 512, 4, 3, 1, 1, 1031),   # patch kernel S2 / S3 / S4
+    (256, 256, 8, 3, 1, 1, 1030), (512, 512, 4, 3, 1, 1, 4100),                                # conv3x3_pw (>= 3/4 tile per CU)
 ]
 
 
