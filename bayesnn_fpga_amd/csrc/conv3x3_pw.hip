@@ -47,28 +47,37 @@ static __device__ unsigned int g_zero_page_pw[64];
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),       \
                                      (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
 
+// TW = map size (TW x TW): 8 or 4.  (A 128-channel x 512-pixel variant of this kernel for the 16x16 / Cout = 128 class was built
+// and measured: 1061 vs 1094 TFLOP/s for conv3x3_patch, whose wave tile is 64 x 128 there already — not kept.)
 template <int TW>
 struct PwGeom {
-    static constexpr int TH = TW, IMGS = 256 / (TH * TW);
+    static constexpr int CT = 256, TH = TW, PX = 65536 / CT, IMGS = PX / (TH * TW);
+    static_assert(IMGS >= 1 && IMGS * TH * TW == PX, "whole images per tile");
     static constexpr int PH = TH + 2, PW = TW + 2;
-    static constexpr int PWP = TW == 8 ? 12 : 8;                 // cell pitch, % 4 == 0: bank window of a cell = x & 3
-    static constexpr int CELLS = IMGS * PH * PWP;                 // 480 | 768
-    static constexpr int ITER_P = (CELLS * 4 + 511) / 512;        // 16-byte pieces per thread and sub-patch: 4 | 6
-    static constexpr int PBUF = ITER_P * 512 * 16;                // 32 KB | 48 KB
-    static constexpr int WST = 256 * 64;                          // one weight stage
+    static constexpr int PWP = (PW + 3) & ~3;                     // cell pitch, % 4 == 0: bank window of a cell = x & 3
+    static constexpr int CELLS = IMGS * PH * PWP;                 // 8x8: 480, 4x4: 768, 16x16 (2 images): 720
+    static constexpr int ITER_P = (CELLS * 4 + 511) / 512;        // 16-byte pieces per thread and sub-patch: 4 | 6 | 6
+    static constexpr int PBUF = ITER_P * 512 * 16;                // 32 KB | 48 KB | 48 KB
+    static constexpr int WROWS = CT / 128;                        // weight pieces per thread and stage
+    static constexpr int WST = CT * 64;                           // one weight stage
     static constexpr int NST = 3;                                 // weight stages: the tile of K-step T+2 is in flight during T
-    static constexpr int MAIN = NST * WST + 2 * PBUF;             // 112 KB | 144 KB
-    static constexpr int LDS_BYTES = MAIN > 2 * BMI_EPILOGUE_LDS_BYTES ? MAIN : 2 * BMI_EPILOGUE_LDS_BYTES;
-    // tile pixel p (0..255) -> image of the tile and output coordinates: the 16 pixels of one MFMA tile are a 4 x 4 block
+    static constexpr int MAIN = NST * WST + 2 * PBUF;             // 112 KB | 144 KB | 120 KB
+    static constexpr int SHORT = 2 * (WST + PX * 64);             // shortcut steps: two [weights | pixels] stages
+    static constexpr int NEED = MAIN > SHORT ? MAIN : SHORT;
+    static constexpr int LDS_BYTES = NEED > 2 * BMI_EPILOGUE_LDS_BYTES ? NEED : 2 * BMI_EPILOGUE_LDS_BYTES;
+    // tile pixel p -> image of the tile and output coordinates: the 16 pixels of one MFMA tile are a 4 x 4 block
     __host__ __device__ static constexpr int p_img(int p) { return p / (TH * TW); }
-    __host__ __device__ static constexpr int p_ox(int p) { return TW == 8 ? 4 * ((p >> 4) & 1) + (p & 3) : p & 3; }
-    __host__ __device__ static constexpr int p_oy(int p) { return TW == 8 ? 4 * ((p >> 5) & 1) + ((p >> 2) & 3) : (p >> 2) & 3; }
+    __host__ __device__ static constexpr int p_ox(int p) { return 4 * ((p >> 4) % (TW / 4)) + (p & 3); }
+    __host__ __device__ static constexpr int p_oy(int p) { return 4 * (((p >> 4) / (TW / 4)) % (TH / 4)) + ((p >> 2) & 3); }
+    // patch cell of the j-th 4 x 4 block of a wave (its 8 blocks start at a multiple of 8) relative to the wave's first one
+    static constexpr int BR = TW / 4, BI = BR * BR;
+    __host__ __device__ static constexpr int cell_delta(int j) { return (j / BI) * PH * PWP + 4 * ((j % BI) / BR) * PWP + 4 * ((j % BI) % BR); }
 };
 
 template <int TW, bool PLAIN, bool BF>
 __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
     using G = PwGeom<TW>;
-    constexpr int TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
+    constexpr int CT = G::CT, TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
     constexpr int TJ = 4, TI = 4, TP = 8;
     typedef float accv __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
@@ -81,27 +90,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
     const int l16 = lane & 15, kq = lane >> 4;
     const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
 
-    const int n_ctiles = a.Cout / 256;
+    const int n_ctiles = a.Cout / CT;
     const int n_ptiles = (a.N + IMGS - 1) / IMGS;
     int ptile, ctile;
     xcd_tile_map(blockIdx.x, n_ptiles, n_ctiles, ptile, ctile, a.xcd_split);
-    const int ch0 = ctile * 256;
+    const int ch0 = ctile * CT;
     const int n0 = ptile * IMGS;
     const int Ktot = 9 * a.Cin;
     const int nC = a.Cin / 32;
 
     // ---- per-thread DMA sources ----
     // weights: piece q = tid + 512 i -> row (tid >> 2) + 128 i, position tid & 3 holds chunk (pos - (row >> 2)) & 3
-    const _Float16* wsrc[2];
+    const _Float16* wsrc[G::WROWS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < G::WROWS; ++i) {
         const int row = (tid >> 2) + 128 * i;
         wsrc[i] = a.wgt + (size_t)(ch0 + row) * Ktot + (((tid & 3) - (row >> 2)) & 3) * 8;
     }
 #define ISSUE_W(KOFF, ST)                                                                        \
     {                                                                                            \
-        GLDS16(wsrc[0] + (KOFF), wst + (ST) * G::WST + (wave * 64) * 16);                        \
-        GLDS16(wsrc[1] + (KOFF), wst + (ST) * G::WST + (512 + wave * 64) * 16);                  \
+        _Pragma("unroll") for (int i = 0; i < G::WROWS; ++i)                                     \
+            GLDS16(wsrc[i] + (KOFF), wst + (ST) * G::WST + (i * 512 + wave * 64) * 16);          \
     }
     ISSUE_W(0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -129,15 +138,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
 
     // ---- per-lane fragment geometry ----
     const int a_off = (g * 128 + wc * 64 + l16) * 64;
+    const int pbase = wp * 128;                                   // first tile pixel of this wave
     const int a_byte = ((kq + (l16 >> 2)) & 3) << 4;              // position of chunk kq in this lane's rows ((row >> 2) & 3 == l16 >> 2)
-    int bbyte[TP], bpos[TP];                                      // byte offset of the pixel's cell at tap (0,0); kq + y of that cell
+    // Pixel fragments: cell of (wave's first block) + compile-time cell_delta(j) + this lane's cell inside the 4 x 4 block; the
+    // chunk position (kq + y) & 3 depends on the lane's row in the block and on the tap's ky only (block origins are multiples
+    // of 4) — so a fragment read is ONE ds_read_b128 with an immediate offset from one of three per-lane addresses.
+    const int wave_cell = (G::p_img(pbase) * PH + G::p_oy(pbase)) * PWP + G::p_ox(pbase);
+    int boff[3];
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const int p = wp * 128 + 16 * j + l16;
-        const int ox = G::p_ox(p), oy = G::p_oy(p);
-        bbyte[j] = ((G::p_img(p) * PH + oy) * PWP + ox) * 64;
-        bpos[j] = kq + oy;
-    }
+    for (int ky = 0; ky < 3; ++ky)
+        boff[ky] = (wave_cell + (l16 >> 2) * PWP + (l16 & 3)) * 64 + (((kq + (l16 >> 2) + ky) & 3) << 4);
 
     accv acc[TI][TP];
 #pragma unroll
@@ -156,15 +166,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);             \
     }
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-    // What may still be in flight when K-step `TAP` of a chunk ends: the weight tile of the step after next (2 DMA
+    // What may still be in flight when K-step `TAP` of a chunk ends: the weight tile of the step after next (WROWS DMA
     // instructions, issued this step) and the sub-patch pieces issued this step and the step before (one each at taps
     // 1..ITER_P when another chunk follows); everything older — in particular the next step's weights — has landed.
 #define END_OF_STEP_WAIT(TAP)                                                                                  \
     {                                                                                                          \
         constexpr int pieces_ = ((TAP) >= 1 && (TAP) <= G::ITER_P ? 1 : 0) + ((TAP) >= 2 && (TAP) <= G::ITER_P + 1 ? 1 : 0); \
-        if (!last) { WAIT_VM(2 + pieces_); }                                                                   \
+        if (!last) { WAIT_VM(G::WROWS + pieces_); }                                                            \
         else if ((TAP) >= 7) { WAIT_VM(0); }                                                                   \
-        else { WAIT_VM(2); }                                                                                   \
+        else { WAIT_VM(G::WROWS); }                                                                            \
     }
     // One K-step = tap TAP x this chunk's 32 channels.  Two phases (LOAD part, barrier, MFMA part, barrier); the two wave
     // groups run one barrier apart.  Weight stage = TAP % 3 (9 taps per chunk: the stage index repeats per chunk).
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
                 _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
-                bf[j] = *(const half8*)(pb_ + bbyte[4 * kk + j] + (((bpos[4 * kk + j] + ky_) & 3) << 4));      \
+                bf[j] = *(const half8*)(pb_ + boff[ky_] + G::cell_delta(4 * kk + j) * 64);                     \
             if (kk == 0) {                                                                                     \
                 /* weights of the step after next: (tap + 2) of this chunk, or taps 0 / 1 of the next one */   \
                 if ((TAP) < 7) { ISSUE_W(((TAP) + 2) * a.Cin + c32, ((TAP) + 2) % 3); }                        \
@@ -218,30 +228,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- fused 1x1 strided shortcut (BasicBlock downsample path, resnet18.py:42-45): Cin2 / 32 more K-steps on the block
-    //      input sampled at the output pixels' positions.  All eight waves in lockstep, two [weights | pixels] stages of
-    //      32 KB in the LDS the main loop has left (every DMA is drained, every fragment read retired), one barrier per
+    //      input sampled at the output pixels' positions.  All eight waves in lockstep, two [weights | pixels] stages
+    //      (32 or 40 KB) in the LDS the main loop has left (every DMA is drained, every fragment read retired), one barrier per
     //      step: the next step's tiles fly while this one computes.  4-8 steps against 72-144 of the main loop. ----
     if (a.in2) {
         const int nC2 = a.Cin2 / 32;
-        const _Float16* w2src[2];
-        const _Float16* x2src[2];
+        constexpr int XROWS = G::PX / 128, SST = G::WST + G::PX * 64;   // pixel pieces per thread; bytes of one stage
+        const _Float16* w2src[G::WROWS];
+        int x2off[XROWS];                                       // 31-bit element offsets (checked by the launcher), -1: zero page
+        const int lg = (((tid & 3) - (tid >> 4)) & 3) * 8;       // logical chunk held at position tid & 3 (row >> 2 == (tid >> 4) mod 4)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (tid >> 2) + 128 * i;               // weight row / tile pixel of this thread's piece
-            const int lg = (((tid & 3) - (row >> 2)) & 3) * 8;   // logical chunk held at position tid & 3
-            w2src[i] = a.wgt2 + (size_t)(ch0 + row) * a.Cin2 + lg;
+        for (int i = 0; i < G::WROWS; ++i) w2src[i] = a.wgt2 + (size_t)(ch0 + (tid >> 2) + 128 * i) * a.Cin2 + lg;
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            const int row = (tid >> 2) + 128 * i;               // tile pixel of this thread's piece
             const int n = n0 + G::p_img(row);
-            x2src[i] = n < a.N ? a.in2 + (((size_t)(map_image(a, n) % a.in2_mod) * a.H2 + (size_t)G::p_oy(row) * a.stride2) * a.W2 +
-                                          (size_t)G::p_ox(row) * a.stride2) * a.Cin2 + lg
-                               : nullptr;
+            x2off[i] = n < a.N ? (int)((((size_t)(map_image(a, n) % a.in2_mod) * a.H2 + (size_t)G::p_oy(row) * a.stride2) * a.W2 +
+                                        (size_t)G::p_ox(row) * a.stride2) * a.Cin2 + lg)
+                               : -1;
         }
 #define ISSUE_S(C2, ST)                                                                                        \
     {                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
-            GLDS16(w2src[i] + (C2) * 32, smem + (ST) * 32768 + (i * 512 + wave * 64) * 16);                    \
-            GLDS16(x2src[i] ? x2src[i] + (C2) * 32 : (const _Float16*)g_zero_page_pw,                          \
-                   smem + (ST) * 32768 + 16384 + (i * 512 + wave * 64) * 16);                                  \
-        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < G::WROWS; ++i)                                                   \
+            GLDS16(w2src[i] + (C2) * 32, smem + (ST) * SST + (i * 512 + wave * 64) * 16);                      \
+        _Pragma("unroll") for (int i = 0; i < XROWS; ++i)                                                      \
+            GLDS16(x2off[i] >= 0 ? a.in2 + (size_t)(unsigned)x2off[i] + (C2) * 32 : (const _Float16*)g_zero_page_pw, \
+                   smem + (ST) * SST + G::WST + (i * 512 + wave * 64) * 16);                                   \
     }
         RAW_BARRIER();                   // both groups are past their last fragment reads
         ISSUE_S(0, 0);
@@ -249,12 +261,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RAW_BARRIER();               // stage c2 & 1 has landed for every wave; everyone is done with the other stage
             if (c2 + 1 < nC2) ISSUE_S(c2 + 1, (c2 + 1) & 1);
-            const char* ss = smem + (c2 & 1) * 32768;
+            const char* ss = smem + (c2 & 1) * SST;
             half8 sa[TI], sb[TP];
 #pragma unroll
             for (int i = 0; i < TI; ++i) sa[i] = *(const half8*)(ss + a_off + i * 16 * 64 + a_byte);
 #pragma unroll
-            for (int j = 0; j < TP; ++j) sb[j] = *(const half8*)(ss + 16384 + (wp * 128 + 16 * j + l16) * 64 + a_byte);
+            for (int j = 0; j < TP; ++j) sb[j] = *(const half8*)(ss + G::WST + (pbase + 16 * j + l16) * 64 + a_byte);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -284,14 +296,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
     epilogue_coalesced<TJ, PLAIN, 16, BF>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
 }
 
-// Shapes this kernel takes (3x3 / stride 1 / pad 1 on 8x8 or 4x4 maps, Cout % 256 == 0).
+// Shapes this kernel takes: 3x3 / stride 1 / pad 1 on 8x8 or 4x4 maps with Cout % 256 == 0.
 bool conv_takes_pw_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo) {
-    static const int on = [] { const char* v = std::getenv("BMI_CONV_PW"); return v ? std::atoi(v) : 1; }();
-    return on && ksize == 3 && stride == 1 && pad == 1 && cin % 64 == 0 && cout % 256 == 0 && ((ho == 8 && wo == 8) || (ho == 4 && wo == 4));
+    return ksize == 3 && stride == 1 && pad == 1 && cin % 64 == 0 && cout % 256 == 0 && ho == wo && (ho == 8 || ho == 4);
 }
 
 template <int TW>
-static int launch_pw(const ConvArgs& a, hipStream_t s) {
+static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    a.xcd_split = xcd_split_for(a.Cout / 256, (size_t)a.Cout * 9 * a.Cin * 2);
     const long tiles = (long)((a.N + PwGeom<TW>::IMGS - 1) / PwGeom<TW>::IMGS) * (a.Cout / 256);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)tiles), block(512);
@@ -308,17 +321,16 @@ static int launch_pw(const ConvArgs& a, hipStream_t s) {
 }
 
 // BMI_ERR_UNSUPPORTED -> the caller falls back to conv3x3_patch.
-int launch_conv3x3_pw(const ConvArgs& a_in, hipStream_t s) {
-    if (!opt_conv_pw() || a_in.in_bits || a_in.wgt_b) return BMI_ERR_UNSUPPORTED;
-    if (a_in.in2 && (!a_in.wgt2 || a_in.Cin2 % 64 != 0 || a_in.in2_mod <= 0 || a_in.stride2 < 1)) return BMI_ERR_INVALID;
-    if (!conv_takes_pw_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout, a_in.Ho, a_in.Wo)) return BMI_ERR_UNSUPPORTED;
-    if (a_in.N <= 0 || a_in.in_mod <= 0 || a_in.B <= 0 || (a_in.res && a_in.res_mod <= 0)) return BMI_ERR_INVALID;
-    if ((size_t)a_in.in_mod * a_in.H * a_in.W * a_in.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets
-    // No minimum-grid rule: which kernel runs depends on the conv's SHAPE only, never on the batch or on how many samples a
-    // launch carries, so a result does not depend on batch size, chunking or sharding (conv3x3_patch sums the channels in
-    // 64-wide chunks, this kernel in 32-wide ones: equal to fp32 rounding, not bit for bit).  An under-filled grid (B * T <
-    // ~200 images) runs at most one tile time per launch either way.
-    ConvArgs a = a_in;
-    a.xcd_split = xcd_split_for(a.Cout / 256, (size_t)a.Cout * 9 * a.Cin * 2);
+// No minimum-grid rule: which kernel runs depends on the conv's SHAPE only, never on the batch or on how many samples a launch
+// carries, so a result does not depend on batch size, chunking or sharding (conv3x3_patch sums the channels in 64-wide
+// chunks, this kernel in 32-wide ones: equal to fp32 rounding, not bit for bit).  An under-filled grid (B * T < ~200 images)
+// runs at most one tile time per launch either way.
+int launch_conv3x3_pw(const ConvArgs& a, hipStream_t s) {
+    if (!opt_conv_pw() || a.in_bits || a.wgt_b) return BMI_ERR_UNSUPPORTED;
+    if (a.in2 && (!a.wgt2 || a.Cin2 % 64 != 0 || a.in2_mod <= 0 || a.stride2 < 1)) return BMI_ERR_INVALID;
+    if (!conv_takes_pw_kernel(a.ksize, a.stride, a.pad, a.Cin, a.Cout, a.Ho, a.Wo)) return BMI_ERR_UNSUPPORTED;
+    if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
+    if ((size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets
+    if (a.in2 && (size_t)a.in2_mod * a.H2 * a.W2 * a.Cin2 >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;
     return a.Ho == 8 ? launch_pw<8>(a, s) : launch_pw<4>(a, s);
 }

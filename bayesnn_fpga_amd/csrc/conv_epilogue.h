@@ -68,10 +68,9 @@ __device__ __forceinline__ void xcd_tile_map(int bid, int n_pt, int n_ct, int& p
 }
 
 // Dynamic early exit: compact image index of this launch -> row of the tensors / Philox image index (see ConvArgs::imap).
+// One table lookup: a division by the active-image count here cost the general-epilogue kernels 16-24 spilled VGPRs.
 __device__ __forceinline__ int map_image(const ConvArgs& a, int n) {
-    if (!a.imap || n >= a.N) return n;
-    const int tl = n / a.Bc;
-    return tl * a.B + a.imap[n - tl * a.Bc];
+    return (a.imap && n < a.N) ? a.imap[n] : n;
 }
 
 struct PixelCtx {

@@ -508,7 +508,7 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     }
     off = st_base + st_peak;
     h->exit_off = off;
-    off += align_up((2 * (size_t)max_batch + 64) * sizeof(int), 256);
+    off += align_up((2 * (size_t)max_batch + 64 + NS) * sizeof(int), 256);   // two image lists, a counter, the row table
     h->ws_bytes = off;
     h->max_batch = max_batch;
     h->chunk = chunk_samples;
@@ -553,9 +553,10 @@ struct ProfScope {
     }
 };
 
-// imap / Bc: dynamic early exit (ConvArgs::imap): N = samples * Bc compact images of the B-image batch; null = all images
+// imap / rows / Bc: dynamic early exit: N = samples * Bc compact images of the B-image batch; imap = the Bc active images
+// (heads), rows = the N-entry row table (ConvArgs::imap); null = all images
 int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, int B, int t0, uint64_t seed, int cnt0,
-           double* S1, double* S2, double* SL, hipStream_t s, const int* imap = nullptr, int Bc = 0) {
+           double* S1, double* S2, double* SL, hipStream_t s, const int* imap = nullptr, int Bc = 0, const int* rows = nullptr) {
     const bmi_op_desc& d = op.d;
     const TensorInfo& tin = e->tensors[d.in];
     const int n_rows = imap ? (N / Bc) * B : N;     // rows of a stochastic tensor (original folded layout)
@@ -575,7 +576,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.out = (_Float16*)(ws + e->tensors[d.out].offset);
             a.N = N;
             a.n_ref = (tin.stoch || (d.residual >= 0 && e->tensors[d.residual].stoch) || op.stoch) ? B * e->chunk : B;
-            a.imap = imap; a.Bc = Bc;
+            a.imap = rows; a.Bc = Bc;
             a.in_mod = tin.stoch ? n_rows : B;
             if (d.residual >= 0) {
                 a.res = (const _Float16*)(ws + e->tensors[d.residual].offset);
@@ -709,6 +710,7 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
     char* ws = (char*)workspace;
     int* lists[2] = {(int*)(ws + h->exit_off), (int*)(ws + h->exit_off) + h->max_batch};
     int* count_dev = (int*)(ws + h->exit_off) + 2 * h->max_batch;
+    int* rows_dev = count_dev + 64;
     const int last = h->n_exits - 1;
     int rc = launch_fill_int(exit_of_image, batch, last, s);
     if (rc != BMI_OK) return rc;
@@ -718,9 +720,10 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
         if (rc != BMI_OK) return rc;
     }
     const int* imap = nullptr;     // null: every image is still active
+    const int* rows = nullptr;
     int bc = batch, cur = 0;
     for (const OpInfo& op : h->suffix) {
-        rc = run_op(h, op, x_nchw, ws, t_count * bc, batch, 0, seed, mask_cnt0, S1, S2, SL, s, imap, bc);
+        rc = run_op(h, op, x_nchw, ws, t_count * bc, batch, 0, seed, mask_cnt0, S1, S2, SL, s, imap, bc, rows);
         if (rc != BMI_OK) return rc;
         if (op.d.kind != BMI_OP_HEAD) continue;
         const int e = op.d.out;
@@ -738,6 +741,9 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
         imap = lists[cur];
         bc = n_active;
         cur ^= 1;
+        rc = launch_expand_rows(imap, bc, batch, t_count, rows_dev, s);     // compact image -> tensor row, for the conv kernels
+        if (rc != BMI_OK) return rc;
+        rows = rows_dev;
     }
     return BMI_OK;
 }

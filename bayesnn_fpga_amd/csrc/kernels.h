@@ -46,9 +46,9 @@ struct ConvArgs {
     int t0;        // first sample index of this launch
     int bf16;      // 1: activations / weights are bfloat16 bits (v_mfma_*_bf16), 0: fp16
     // dynamic early exit (bmi_forward_mcd_exit): the launch covers N = samples * Bc COMPACT images; compact image n is row
-    // (n / Bc) * B + imap[n % Bc] of every tensor (which keep their original folded layout) and of the Philox index
-    const int* imap;   // device [Bc] original image indices of the still-active images, or null (identity, Bc unused)
-    int Bc;
+    // imap[n] = (n / Bc) * B + active[n % Bc] of every tensor (which keep their original folded layout) and of the Philox index
+    const int* imap;   // device [N] row of each compact image, or null (identity)
+    int Bc;            // still-active images per sample (informational)
     int xcd_split; // channel-tile classes of the XCD-aware tile order (xcd_tile_map's cs); set by the launcher
     SiteArgs site;
 };
@@ -97,6 +97,7 @@ int launch_dense_f32(const void* in, int in_kind, const float* w, const float* b
 int launch_exit_decide(const double* S1e, int C, int t_total, double thr, const int* in, int bc, int* out, int* count,
                        int* exit_of, int e, hipStream_t s);
 int launch_fill_int(int* p, int n, int v, hipStream_t s);
+int launch_expand_rows(const int* active, int bc, int batch, int tc, int* rows, hipStream_t s);   // rows[tl*bc + i] = tl*batch + active[i]
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);

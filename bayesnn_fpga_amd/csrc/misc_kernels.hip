@@ -346,6 +346,21 @@ int launch_exit_decide(const double* S1e, int C, int t_total, double thr, const 
     return BMI_OK;
 }
 
+__global__ void expand_rows_kernel(const int* __restrict__ active, int bc, int batch, int total, int* __restrict__ rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int tl = i / bc;
+    rows[i] = tl * batch + active[i - tl * bc];
+}
+
+int launch_expand_rows(const int* active, int bc, int batch, int tc, int* rows, hipStream_t s) {
+    if (!active || !rows || bc <= 0 || batch <= 0 || tc <= 0) return BMI_ERR_INVALID;
+    const int total = bc * tc;
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, active, bc, batch, total, rows);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
 __global__ void fill_int_kernel(int* p, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
