@@ -15,12 +15,14 @@ combined with ONE all-reduce over RCCL per step.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 10 --warmup 3
 
-Prints ONE JSON line (rank 0).  `roofline` is for the conv kernels (94 % of a step: conv3x3_patch, conv_igemm_wide,
-conv_igemm; `by_kernel` splits it): algorithmic conv FLOPs / HIP-event time of those launches, measured by the
-library on the launch stream in a separate profiled step right after the timed region (event records around every
-launch would perturb the timed steps); `traffic` and the per-kernel MFMA-busy share are quoted from the committed
-rocprofv3 PMC passes of this same command (profiles/, tools/profile_bench.sh).  `cpu_baseline` is the CPU oracle (a
-port of the reference loop) timed on this box's host cores on a bounded sample, at N=1 only.
+Prints ONE JSON line (rank 0).  `roofline` is the DOMINANT kernel family of the step (the conv family with the largest
+share of the step time: conv3x3_pw / conv_igemm_wide / conv3x3_patch / conv_igemm): algorithmic FLOPs (or, where the HBM
+roofline is the tighter one, bytes) per launch / its average launch duration, measured by the library with HIP events on the
+launch stream in a separate profiled step right after the timed region (event records around every launch would perturb
+the timed steps); `all_conv_launches`, `whole_step` and `by_kernel` give the same for all conv launches, the whole timed
+step and each family.  `traffic` and the per-kernel MFMA-busy share are quoted from the committed rocprofv3 PMC passes
+of this same command (profiles/, tools/profile_all.sh).  `cpu_baseline` is the CPU oracle (a port of the reference loop,
+ATen's own RNG) timed on this box's host cores on a bounded sample, at N=1 only.
 """
 import argparse
 import json
@@ -91,16 +93,29 @@ def parse():
     return ap.parse_args()
 
 
-def hbm_traffic(workload, launches_per_step):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py
-    -> profiles/hbm_traffic_<workload>.json; FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes).  None when absent."""
+def _family_match(kernel_name, family):
+    """rocprof kernel names ('conv_igemm_wide_persist_kernel<16, false>') -> the library's kernel families."""
+    stem = family[:-len("_kernel")] if family.endswith("_kernel") else family
+    if not kernel_name.startswith(stem):
+        return False
+    return stem != "conv_igemm" or kernel_name.startswith("conv_igemm_kernel")      # conv_igemm is a prefix of conv_igemm_wide
+
+
+def hbm_traffic(workload, launches_per_step, family=None):
+    """HBM bytes per launch of the conv kernels (or of one family) from the committed rocprofv3 PMC passes of this same
+    command (tools/pmc_summary.py -> profiles/hbm_traffic_<workload>.json; FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes).
+    None when absent or collected for another launch count."""
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     if not os.path.exists(path):
         return None, None
-    ks = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw"))}
-    n = sum(v["launches"] for v in ks.values())
-    if n == 0 or n % launches_per_step:
+    allk = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw"))}
+    n_all = sum(v["launches"] for v in allk.values())
+    if n_all == 0 or n_all % launches_per_step:
         return None, None                   # collected for another batch / T / chunking: do not quote it
+    ks = allk if family is None else {k: v for k, v in allk.items() if _family_match(k, family)}
+    n = sum(v["launches"] for v in ks.values())
+    if n == 0:
+        return None, None
     return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / n, os.path.relpath(path, ROOT)
 
 
@@ -110,9 +125,8 @@ def pmc_sq(workload, family):
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     if not os.path.exists(path):
         return {}
-    stem = family[:-len("_kernel")] if family.endswith("_kernel") else family     # conv_igemm_wide also covers ..._persist_kernel
-    ks = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(stem) and "sq" in v
-          and (stem != "conv_igemm" or k.startswith("conv_igemm_kernel")) and v["sq"]["mfma_busy_share"] > 0.05]
+    ks = [v for k, v in json.load(open(path))["kernels"].items() if _family_match(k, family) and "sq" in v    # (wide covers ..._persist)
+          and v["sq"]["mfma_busy_share"] > 0.05]
     n = sum(v["launches"] for v in ks)
     if not n:
         return {}
@@ -314,30 +328,48 @@ def main():
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
             "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),
             "tflops_naive_equiv": round(2.0 * (eng.prefix_macs + eng.suffix_macs) * samples / dt / 1e12, 2),
-            # the three conv kernels together (94 % of the step); `by_kernel` splits it per kernel name as
-            # rocprofv3 --kernel-trace --stats lists them (profiles/): FLOPs are the algorithmic 2*MACs of each launch
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_kernel + conv_igemm_wide_kernel + conv_igemm_kernel "
-                                                    "(all conv launches of one step)",
-                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None if traffic is None else round(traffic),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_launches, 1)),
-                         "algorithmic_flops_per_launch": round(conv_flops / max(conv_launches, 1)),
-                         "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
-                         # per kernel family both rooflines: MFMA (algorithmic FLOP/s over 2.5 PF) and HBM (algorithmic bytes/s
-                         # over 8 TB/s); `bound` names the tighter one for that family's launches
-                         "by_kernel": {k: {"launches": int(v["launches"]), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
-                                           "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                           "hbm_gbs_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                           "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                           "flop_per_byte": round(v["flops"] / max(v["bytes"], 1.0), 1),
-                                           "bound": "mfma" if v["flops"] / MFMA_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_GBS / 1e9 else "hbm",
-                                           **(pmc_sq(a.workload, k) if traffic is not None else {})}
-                                       for k, v in eng.conv_families.items()},
-                         "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}},
+            "roofline": None,
         }
+        # ---- roofline: the DOMINANT kernel family of the step (largest share of the step time), priced against the roofline
+        # that bounds it: algorithmic FLOPs (or bytes) per launch / its average launch duration, HIP events on the launch
+        # stream.  `all_conv_launches` is the same for every conv launch together, `by_kernel` per family.
+        fam = eng.conv_families
+        by_kernel = {k: {"launches": int(v["launches"]), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                         "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                         "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                         "hbm_gbs_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                         "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "flop_per_byte": round(v["flops"] / max(v["bytes"], 1.0), 1),
+                         "algorithmic_flops_per_launch": round(v["flops"] / v["launches"]),
+                         "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]),
+                         "bound": "mfma" if v["flops"] / MFMA_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_GBS / 1e9 else "hbm",
+                         **(pmc_sq(a.workload, k) if traffic is not None else {})}
+                     for k, v in fam.items()}
+        dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
+        if dom is not None:
+            d = by_kernel[dom]
+            dom_traffic, _ = (hbm_traffic(a.workload, max(alg_launches, 1), dom) if traffic is not None else (None, None))
+            hbm_bound = d["bound"] == "hbm"
+            line["roofline"] = {
+                "bound": d["bound"], "kernel": dom,
+                "achieved": d["hbm_gbs_algorithmic"] if hbm_bound else d["achieved"],
+                "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": d["hbm_frac"] if hbm_bound else d["frac"],
+                "traffic": None if dom_traffic is None else round(dom_traffic),
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
+                "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                "launches": d["launches"], "avg_launch_ms": d["avg_launch_ms"],
+                "share_of_step_ms": round(fam[dom]["ms"], 3),
+                "all_conv_launches": {"achieved": round(achieved, 2), "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                                      "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                                      "traffic": None if traffic is None else round(traffic),
+                                      "algorithmic_bytes_per_launch": round(alg_bytes / max(alg_launches, 1)),
+                                      "algorithmic_flops_per_launch": round(conv_flops / max(conv_launches, 1))},
+                "whole_step": {"achieved": line["tflops_executed"], "unit": "TFLOP/s",
+                               "frac": round(line["tflops_executed"] / MFMA_PEAK_TFLOPS, 4)},
+                "by_kernel": by_kernel,
+                "profile_ms": {k: round(v[0], 3) for k, v in prof.items()}}
         if not a.no_cpu_baseline and world == 1:        # the CPU baseline is reported at N=1 only
             cpu_val, threads, cpu_mean, sweep = cpu_baseline(wl, B, a.cpu_T, a.seed)
             gpu_same = eng.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()

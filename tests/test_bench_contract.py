@@ -26,7 +26,8 @@ def test_bench_prints_the_contract_line():
     assert d["value"] > 1e5 and abs(d["value"] - 250 * 100 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and rf["unit"] == "TFLOP/s"
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 300
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 300 and rf["kernel"] in rf["by_kernel"]
+    assert rf["all_conv_launches"]["frac"] > 0.3 and rf["whole_step"]["frac"] > 0.3
     assert set(rf["by_kernel"]) >= {"conv3x3_patch_kernel", "conv_igemm_wide_kernel"}
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_mean_diff_gpu_vs_cpu"] < 1e-3
