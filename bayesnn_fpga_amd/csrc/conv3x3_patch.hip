@@ -79,7 +79,7 @@ struct PatchGeom {
 // 16 x 32 fragment), same LDS layout and swizzle (the 16 lanes of a read group are 16 consecutive rows either way).
 // Which one is faster is a clock question, not a cycle question (MI355X_MICROARCH.md, DVFS give-back item 7): both are
 // built and launch_conv3x3_patch picks by measured wall time (BMI_MFMA_SHAPE overrides).
-template <int TH, int TW, int IMGS, int TJ, bool PLAIN, int MS, bool BF>
+template <int TH, int TW, int IMGS, int TJ, bool PLAIN, int MS, bool BF, bool IMAP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     using G = PatchGeom<TH, TW, IMGS, TJ>;
     constexpr int BC = G::BC, PH = G::PH, PW = G::PW, PWP = G::PWP, KA = G::KA;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         const int n = n0 + img;
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = cell < G::CELLS && px < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        psrc[i] = ok ? (int)((((size_t)(map_image(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + c * 8) : -1;
+        psrc[i] = ok ? (int)((((size_t)(map_image<IMAP>(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + c * 8) : -1;
     }
     // Weight tile: LDS-DMA one K-step ahead, double buffered, issued as one burst behind the barrier.  Recorded
     // negatives (round 1, same-box A/B on S2/S3/S4): register staging -10 %, hand-pipelined fragment reads -3 %, a third
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 const int oy = rem / TW, ox = rem - oy * TW;
                 const int c = cp ^ (((ox + KA * oy) >> 1) & 7);
                 const int n = n0 + img;
-                const int nm = map_image(a, n) % a.in2_mod;
+                const int nm = map_image<IMAP>(a, n) % a.in2_mod;
                 const _Float16* src = n < a.N ? a.in2 + (((size_t)nm * a.H2 + (size_t)(y0 + oy) * a.stride2) * a.W2 +
                                                         (size_t)(x0 + ox) * a.stride2) * a.Cin2 + c2 * 64 + c * 8
                                               : (const _Float16*)g_zero_page;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         n = n0 + img;
         rem = (y0 + oy) * a.Wo + x0 + ox;
         const bool ok = n < a.N;
-        n = map_image(a, n);
+        n = map_image<IMAP>(a, n);
         return ok;
     };
     auto offmap = [&](int p, size_t& off) -> bool {
@@ -305,7 +305,19 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const bool plain = conv_epilogue_is_plain(a);
     const dim3 grid((unsigned)tiles), block(256);
-    if (a.bf16) {                                  // bf16 operands: the 16x16x32 shape only
+    if (a.imap) {   // dynamic early exit: instantiated for the 16x16 maps only (the 8x8 / 4x4 ones run in conv3x3_pw), 16x16x32
+        if constexpr (TH == 16) {
+            if (a.bf16) {
+                if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, true, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, true, true>), grid, block, 0, s, a);
+            } else {
+                if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, false, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, false, true>), grid, block, 0, s, a);
+            }
+        } else {
+            return BMI_ERR_UNSUPPORTED;
+        }
+    } else if (a.bf16) {                           // bf16 operands: the 16x16x32 shape only
         if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, true>), grid, block, 0, s, a);
     } else if (opt_mfma_shape_patch() == 16) {     // bmi_set_option / BMI_MFMA_SHAPE; default chosen by measured wall time

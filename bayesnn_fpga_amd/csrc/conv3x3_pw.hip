@@ -74,7 +74,7 @@ struct PwGeom {
     __host__ __device__ static constexpr int cell_delta(int j) { return (j / BI) * PH * PWP + 4 * ((j % BI) / BR) * PWP + 4 * ((j % BI) % BR); }
 };
 
-template <int TW, bool PLAIN, bool BF>
+template <int TW, bool PLAIN, bool BF, bool IMAP>
 __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
     using G = PwGeom<TW>;
     constexpr int CT = G::CT, TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
         const int n = n0 + img;
         const int iy = y - 1, ix = x - 1;
         const bool ok = cell < G::CELLS && x < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        psrc[i] = ok ? (int)((((size_t)(map_image(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + ((pos - y) & 3) * 8) : -1;
+        psrc[i] = ok ? (int)((((size_t)(map_image<IMAP>(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + ((pos - y) & 3) * 8) : -1;
     }
 #define ISSUE_P(I, C0, PB)                                                                                   \
     GLDS16(psrc[I] >= 0 ? a.in + (size_t)(unsigned)psrc[I] + (C0) : (const _Float16*)g_zero_page_pw,       \
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
         for (int i = 0; i < XROWS; ++i) {
             const int row = (tid >> 2) + 128 * i;               // tile pixel of this thread's piece
             const int n = n0 + G::p_img(row);
-            x2off[i] = n < a.N ? (int)((((size_t)(map_image(a, n) % a.in2_mod) * a.H2 + (size_t)G::p_oy(row) * a.stride2) * a.W2 +
+            x2off[i] = n < a.N ? (int)((((size_t)(map_image<IMAP>(a, n) % a.in2_mod) * a.H2 + (size_t)G::p_oy(row) * a.stride2) * a.W2 +
                                         (size_t)G::p_ox(row) * a.stride2) * a.Cin2 + lg)
                                : -1;
         }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
         n = n0 + G::p_img(p);
         rem = G::p_oy(p) * TW + G::p_ox(p);
         const bool ok = n < a.N;
-        n = map_image(a, n);
+        n = map_image<IMAP>(a, n);
         return ok;
     };
     auto offmap = [&](int p, size_t& off) -> bool {
@@ -309,24 +309,38 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)tiles), block(512);
     const bool plain = conv_epilogue_is_plain(a);
-    if (a.bf16) {
-        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, true>), grid, block, 0, s, a);
-    } else {
-        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, false>), grid, block, 0, s, a);
+#define PW_LAUNCH(IMAP_)                                                                                              \
+    if (a.bf16) {                                                                                                     \
+        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, true, IMAP_>), grid, block, 0, s, a);              \
+        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, true, IMAP_>), grid, block, 0, s, a);                   \
+    } else {                                                                                                          \
+        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, false, IMAP_>), grid, block, 0, s, a);             \
+        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, false, IMAP_>), grid, block, 0, s, a);                  \
     }
+    if (a.imap) { PW_LAUNCH(true) } else { PW_LAUNCH(false) }
+#undef PW_LAUNCH
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
 
 // BMI_ERR_UNSUPPORTED -> the caller falls back to conv3x3_patch.
-// No minimum-grid rule: which kernel runs depends on the conv's SHAPE only, never on the batch or on how many samples a launch
-// carries, so a result does not depend on batch size, chunking or sharding (conv3x3_patch sums the channels in 64-wide
-// chunks, this kernel in 32-wide ones: equal to fp32 rounding, not bit for bit).  An under-filled grid (B * T < ~200 images)
-// runs at most one tile time per launch either way.
+// Minimum-grid rule: a grid that cannot fill 3/4 of the CUs is better served by conv3x3_patch's 128 x 128 tiles (VGG-11's
+// deterministic 512-channel convs on B = 250 images: 16-63 tiles; 0.061 vs 0.029 ms per launch).  The rule looks at the
+// engine's FULL-CHUNK image count (ConvArgs::n_ref: B x planned chunk for the sample-folded suffix, B for the prefix), never
+// at how many samples this launch carries: a t-shard (one rank of eight, or the last partial chunk) runs the same kernel as
+// the single-rank run and gets the same bits (conv3x3_patch sums the channels in 64-wide chunks, this kernel in 32-wide
+// ones: equal to fp32 rounding, not bit for bit).  "conv_pw" = 2 drops the rule (tests).
 int launch_conv3x3_pw(const ConvArgs& a, hipStream_t s) {
     if (!opt_conv_pw() || a.in_bits || a.wgt_b) return BMI_ERR_UNSUPPORTED;
+    if (opt_conv_pw() != 2) {
+        static const int n_cu = [] {
+            int dev = 0, cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+            return cu;
+        }();
+        const int imgs = a.Ho == 8 ? 4 : 16, n_sel = a.n_ref > 0 ? a.n_ref : a.N;
+        if ((long)((n_sel + imgs - 1) / imgs) * (a.Cout / 256) < (n_cu > 0 ? 3 * n_cu / 4 : 192)) return BMI_ERR_UNSUPPORTED;
+    }
     if (a.in2 && (!a.wgt2 || a.Cin2 % 64 != 0 || a.in2_mod <= 0 || a.stride2 < 1)) return BMI_ERR_INVALID;
     if (!conv_takes_pw_kernel(a.ksize, a.stride, a.pad, a.Cin, a.Cout, a.Ho, a.Wo)) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;

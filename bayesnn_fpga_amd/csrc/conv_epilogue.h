@@ -68,9 +68,14 @@ __device__ __forceinline__ void xcd_tile_map(int bid, int n_pt, int n_ct, int& p
 }
 
 // Dynamic early exit: compact image index of this launch -> row of the tensors / Philox image index (see ConvArgs::imap).
-// One table lookup: a division by the active-image count here cost the general-epilogue kernels 16-24 spilled VGPRs.
+// IMAP is a KERNEL TEMPLATE PARAMETER: the ordinary instantiations (IMAP = false) contain no trace of it.  As a run-time
+// `a.imap ? a.imap[n] : n` inside the epilogue's load loops it made hipcc wait vmcnt(0) around every conditional load and
+// serialised the residual prefetch (+24 % on the general-epilogue wide kernel with no dynamic exit in sight), and a
+// division by the active-image count instead of the row table cost 16-24 spilled VGPRs.
+template <bool IMAP>
 __device__ __forceinline__ int map_image(const ConvArgs& a, int n) {
-    return (a.imap && n < a.N) ? a.imap[n] : n;
+    if constexpr (IMAP) return n < a.N ? a.imap[n] : n;
+    else return n;
 }
 
 struct PixelCtx {

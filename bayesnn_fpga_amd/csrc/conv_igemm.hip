@@ -30,7 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK, bool PLAIN, bool BF>
+template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK, bool PLAIN, bool BF, bool IMAP = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TI = BC / WC / 32;   // 32x32 MFMA tiles per wave along channels
     constexpr int TJ = BP / WP / 32;   // ... along pixels
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int mm = vm[j] ? m : 0;
         const int nc = mm / HoWo;
         const int rem = mm - nc * HoWo;
-        const int n = map_image(a, nc);
+        const int n = map_image<IMAP>(a, nc);
         const int oy = rem / a.Wo;
         const int ox = rem - oy * a.Wo;
         iy0[j] = oy * a.stride - a.pad;
@@ -186,13 +186,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             const int m = pix0 + p;
             n = m / HoWo;
             rem = m - n * HoWo;
-            n = map_image(a, n);
+            n = map_image<IMAP>(a, n);
             return m < a.M;
         };
         auto offmap = [&](int p, size_t& off) -> bool {
-            if (a.imap) {
+            if constexpr (IMAP) {
                 const int m = pix0 + p, n = m / HoWo;
-                off = ((size_t)map_image(a, n) * HoWo + (m - n * HoWo)) * a.Cout;
+                off = ((size_t)map_image<IMAP>(a, n) * HoWo + (m - n * HoWo)) * a.Cout;
             } else {
                 off = (size_t)(pix0 + p) * a.Cout;
             }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             const int m = pix0 + wp * (BP / WP) + 32 * j + r;
             if (m >= a.M) continue;
             const int n = m / HoWo;
-            const PixelCtx px = make_pixel_ctx(a, map_image(a, n), m - n * HoWo);
+            const PixelCtx px = make_pixel_ctx(a, map_image<IMAP>(a, n), m - n * HoWo);
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -229,7 +229,19 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)blocks), block(256);
     const bool plain = BC == 128 && conv_epilogue_is_plain(a);   // the 64-channel tiles use the per-quad epilogue: one instantiation
-    if (a.bf16) {
+    if (a.imap) {   // dynamic early exit: the double-buffered 128-pixel configurations only
+        if constexpr (DBUF && !XMASK && BP == 128) {
+            if (a.bf16) {
+                if (plain) hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, BC == 128, true, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, false, true, true>), grid, block, 0, s, a);
+            } else {
+                if (plain) hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, BC == 128, false, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, false, false, true>), grid, block, 0, s, a);
+            }
+        } else {
+            return BMI_ERR_UNSUPPORTED;
+        }
+    } else if (a.bf16) {
         if (plain) hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, BC == 128, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((conv_igemm_kernel<BC, BP, WC, WP, DBUF, XMASK, false, true>), grid, block, 0, s, a);
     } else {
@@ -252,7 +264,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.Cout % 128 == 0) {
         // 256-pixel tiles (single LDS buffer, 2 barriers per K-step) halve the weight-tile traffic per FLOP
         const long m_sel = a.n_ref > 0 ? (long)a.n_ref * a.Ho * a.Wo : a.M;
-        if (big && (m_sel / 256) * (a.Cout / 128) >= 400 && a.ksize == 3) return launch_cfg<128, 256, 2, 2, false>(a, s);
+        if (big && !a.imap && (m_sel / 256) * (a.Cout / 128) >= 400 && a.ksize == 3) return launch_cfg<128, 256, 2, 2, false>(a, s);
         return launch_cfg<128, 128, 2, 2, true>(a, s);
     }
     return launch_cfg<64, 128, 1, 4, true>(a, s);

@@ -97,7 +97,7 @@ extern "C" int bmi_debug_wide_stamps_clear() {
             _Pragma("unroll") for (int j = 0; j < 4; ++j) { WIDE_MFMA(af[i], bf[j], acc[i][4 * ((KK) & 1) + j]); } \
     }
 
-template <bool PLAIN, int MS, bool BF>
+template <bool PLAIN, int MS, bool BF, bool IMAP = false>
 __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
     WIDE_SHAPE_CONSTS
     __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         const int ox = rem - oy * a.Wo;
         iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;       // a row beyond M never passes the bounds test
         ix0[i] = ox * a.stride - a.pad;
-        xsrc[i] = a.in + (size_t)(map_image(a, n) % a.in_mod) * a.H * a.W * a.Cin + srcchunk;
+        xsrc[i] = a.in + (size_t)(map_image<IMAP>(a, n) % a.in_mod) * a.H * a.W * a.Cin + srcchunk;
     }
     // One row block (64 rows = 8 KB) of the weight / activation tile per call: the fills of the NEXT K-step are
     // spread over the MFMAs of the current one (2 DMA instructions per 8 MFMAs per wave).  Issued as one burst
@@ -275,13 +275,13 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         const int m = pix0 + p;
         n = m / HoWo;
         rem = m - n * HoWo;
-        n = map_image(a, n);
+        n = map_image<IMAP>(a, n);
         return m < a.M;
     };
     auto offmap = [&](int p, size_t& off) -> bool {
-        if (a.imap) {
+        if constexpr (IMAP) {
             const int m = pix0 + p, n = m / HoWo;
-            off = ((size_t)map_image(a, n) * HoWo + (m - n * HoWo)) * b.Cout;
+            off = ((size_t)map_image<IMAP>(a, n) * HoWo + (m - n * HoWo)) * b.Cout;
         } else {
             off = (size_t)(pix0 + p) * b.Cout;
         }
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_persist_kernel(ConvArg
             const int ox = rem - oy * a.Wo;                                                            \
             iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;                                            \
             ix0[i] = ox * a.stride - a.pad;                                                            \
-            xsrc[i] = a.in + (size_t)(map_image(a, n) % a.in_mod) * a.H * a.W * a.Cin + srcchunk;                    \
+            xsrc[i] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + srcchunk;                    \
         }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) ISSUE_X(i, 0, 0, 0, smem);                       \
     }
@@ -565,7 +565,16 @@ int launch_conv_igemm_wide(const ConvArgs& a_in, hipStream_t s) {
         return BMI_OK;
     }
     const dim3 grid((unsigned)blocks), block(512);
-    if (a.bf16) {
+    if (a.imap) {   // dynamic early exit: the 16x16x32 instantiations
+        const bool plain = conv_epilogue_is_plain(a);
+        if (a.bf16) {
+            if (plain) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, true, true>), grid, block, 0, s, a);
+        } else {
+            if (plain) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, false, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, false, true>), grid, block, 0, s, a);
+        }
+    } else if (a.bf16) {
         if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, true>), grid, block, 0, s, a);
     } else if (shape == 16) {

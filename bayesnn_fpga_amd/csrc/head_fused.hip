@@ -8,7 +8,7 @@
 //                 walking all groups left 250 workgroups of latency-bound work on 256 CUs: 2x slower than the three kernels
 //                 it replaced); the groups of an image meet in S1/S2/SL[b][:] by hardware float64 atomic adds (<= 4 per
 //                 address and launch at T = 100).
-//   phase A     = pooling, coalesced: wave w pools columns (samples) 8w..8w+7 of the group, lane = one 8-channel group
+//   phase A     = pooling, coalesced: wave w pools columns (samples) w, w+4, .. of the group, lane = one 8-channel group
 //                 (16 B per pixel row: 64 lanes cover a 512-channel row = 1 KB contiguous), ReLU + mean in fp32, the
 //                 feature-side site (MC dropout / Masksembles1D on the [B, K] tensor), then fp32 into LDS
 //                 feat[32 samples][KC] with the 16-byte chunks XOR-swizzled by the sample index.
@@ -53,22 +53,22 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
         for (int k0 = 0; k0 < K; k0 += HEAD_KC) {
             const int kc = min(HEAD_KC, K - k0);               // multiple of 32
             const int swz = (kc & 63) == 0 ? 15 : 7;          // the XOR must stay inside the row's kc / 4 chunks
-            // this wave's slice of the classifier weights is requested BEFORE the pooling pass (its L2 latency hides under
-            // phase A); RT <= 2 only: 16 float4 per class tile and lane
+            // this wave's slice of the classifier weights, two class tiles (64 classes) at a time: the first pair is requested
+            // BEFORE the pooling pass (its L2 latency hides under phase A), 16 float4 per class tile and lane
             const int kq = kc >> 3;                            // k per (wave, half): multiple of 4, <= 64
             const int koff = wave * (kc >> 2) + hh * kq;
             const float* wp = a.w + (size_t)r * K + k0 + koff;
-            f32x4_h wpre[RT <= 2 ? RT : 1][16];
-            if constexpr (RT <= 2) {
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        wpre[i][q] = 4 * q < kq ? *(const f32x4_h*)(wp + (size_t)(32 * i) * K + 4 * q) : f32x4_h{0.f, 0.f, 0.f, 0.f};
-            }
+            constexpr int NPAIR = (RT + 1) / 2, W2 = RT < 2 ? RT : 2;
+            f32x4_h wpre[W2][16];
+#define HEAD_LOAD_W(PS)                                                                                              \
+    _Pragma("unroll") for (int ii = 0; ii < W2; ++ii)                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q)                                                                \
+            wpre[ii][q] = (2 * (PS) + ii < RT && 4 * q < kq) ? *(const f32x4_h*)(wp + (size_t)(32 * (2 * (PS) + ii)) * K + 4 * q) \
+                                                             : f32x4_h{0.f, 0.f, 0.f, 0.f};
+            HEAD_LOAD_W(0)
             // ---- phase A: pool 8 samples per wave into LDS ----
             for (int jj = 0; jj < 8; ++jj) {
-                const int j = wave * 8 + jj;
+                const int j = jj * 4 + wave;                  // interleaved: a launch with few samples (T = 8) still uses all waves
                 const int tl = g * 32 + j;
                 const int c8 = lane;
                 if (c8 * 8 < kc) {
@@ -113,31 +113,26 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
             // ---- phase B: this wave's quarter of the chunk's K, lane half hh takes half of that ----
             {
                 const float* fr = feat + r * kc;
-                if constexpr (RT <= 2) {
+#pragma unroll
+                for (int ps = 0; ps < NPAIR; ++ps) {
+                    if (ps > 0) { HEAD_LOAD_W(ps) }            // later pairs (C > 64): loaded when their turn comes
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         if (4 * q < kq) {
                             const f32x4_h b4 = *(const f32x4_h*)(fr + ((((koff + 4 * q) >> 2) ^ (r & swz)) << 2));
 #pragma unroll
-                            for (int i = 0; i < RT; ++i) {
+                            for (int ii = 0; ii < W2; ++ii) {
+                                if (2 * ps + ii < RT) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wpre[i][q][e], b4[e], acc[i], 0, 0, 0);
+                                    for (int e = 0; e < 4; ++e)
+                                        acc[2 * ps + ii] = __builtin_amdgcn_mfma_f32_32x32x2f32(wpre[ii][q][e], b4[e], acc[2 * ps + ii], 0, 0, 0);
+                                }
                             }
-                        }
-                    }
-                } else {
-#pragma unroll 4
-                    for (int s = 0; s < kq; s += 4) {
-                        const f32x4_h b4 = *(const f32x4_h*)(fr + ((((koff + s) >> 2) ^ (r & swz)) << 2));
-#pragma unroll
-                        for (int i = 0; i < RT; ++i) {
-                            const f32x4_h a4 = *(const f32x4_h*)(wp + (size_t)(32 * i) * K + s);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i], 0, 0, 0);
                         }
                     }
                 }
             }
+#undef HEAD_LOAD_W
             __syncthreads();                                   // feat is free for the next chunk
         }
         // ---- the four K-quarters meet in LDS ----
@@ -151,27 +146,41 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
         if (wave == 0) {
             const int tl = g * 32 + r;
             const uint32_t t = (uint32_t)(a.t0 + tl);
+            // (three plain passes: with the partial sums, the bias / logits-site code and the running max in ONE loop body
+            //  hipcc gave up unrolling it for 4 class tiles and put the accumulators in scratch)
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][e] += part[((w * RT + i) * 16 + e) * 64 + lane];
+            const bool drop_logits = a.site_logits.kind == BMI_SITE_ELEMENTWISE;
             float mx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    float v = acc[i][e];
-#pragma unroll
-                    for (int w = 1; w < 4; ++w) v += part[((w * RT + i) * 16 + e) * 64 + lane];
-                    if (c < C) {
-                        v += a.bias[c];
-                        if (a.site_logits.kind == BMI_SITE_ELEMENTWISE) {
-                            // dropout on the logits (converter/pytorch wraps the last Linear too, nn2bnn.py:33-45):
-                            // [B, C] tensor, element = b*C + c
-                            const uint64_t elem = (uint64_t)b * C + c;
-                            const uint32_t keep = site_keep8(a.site_logits, elem & ~(uint64_t)7, t);
-                            v = ((keep >> (elem & 7)) & 1u) ? v * a.site_logits.scale : 0.f;
-                        }
-                        mx = fmaxf(mx, v);
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = 32 * i + 8 * q + 4 * hh;          // registers 4q .. 4q+3 = classes c4 .. c4+3
+                    uint32_t keep = 0xFu;
+                    if (drop_logits) {
+                        // dropout on the logits (converter/pytorch wraps the last Linear too, nn2bnn.py:33-45):
+                        // [B, C] tensor, element = b*C + c
+                        const uint64_t elem = (uint64_t)b * C + c4;          // any alignment: b * C need not be a multiple of 4
+                        const uint32_t sh = (uint32_t)(elem & 7);
+                        keep = site_keep8(a.site_logits, elem & ~(uint64_t)7, t) >> sh;
+                        if (sh > 4) keep |= site_keep8(a.site_logits, (elem & ~(uint64_t)7) + 8, t) << (8 - sh);   // the quad straddles two calls
                     }
-                    acc[i][e] = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = c4 + e;
+                        float v = acc[i][4 * q + e];
+                        if (c < C) {
+                            v += a.bias[c];
+                            if (drop_logits) v = ((keep >> e) & 1u) ? v * a.site_logits.scale : 0.f;
+                            mx = fmaxf(mx, v);
+                        }
+                        acc[i][4 * q + e] = v;
+                    }
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float sum = 0.f;

@@ -147,7 +147,7 @@ const char* bmi_error_string(int code);
  *                                           (v_mfma_f32_16x16x32_f16 | v_mfma_f32_32x32x16_f16); 0 = built-in default
  *   "xcd_split"                             0 | 1 | 2 | 4: channel-tile classes of the XCD-aware tile order (0 = chosen from
  *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
- *   "conv_pw"                               0 | 1: 3x3 stride-1 convs on 8x8 / 4x4 maps with Cout % 256 == 0 run in conv3x3_pw (256 x 256
+ *   "conv_pw"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-1 convs on 8x8 / 4x4 maps with Cout % 256 == 0 run in conv3x3_pw (256 x 256
  *                                           tile, 8 waves) instead of conv3x3_patch (128 x 128, 2 workgroups per CU)
  *   "wide_persist_min_x10"                  10..1000: conv_igemm_wide runs persistent (one workgroup per CU walking the tiles)
  *                                           when tiles * 10 > value * CUs

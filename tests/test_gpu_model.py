@@ -129,9 +129,11 @@ def test_full_size_batch_properties():
     for g0, g1 in ((0, 3), (3, 6), (6, 9), (9, 12)):        # 4 ranks' worth of t-shards
         eng.accumulate(x, S2, g0, g1 - g0, 42)
     torch.testing.assert_close(S2, S, rtol=1e-12, atol=1e-12)
-    # row 0 of the big batch equals a batch-of-one run (mask index depends on (b, ...) only)
+    # row 0 of the big batch equals a batch-of-one run: the masks depend on (b, ...) only.  (The 8x8 / 4x4 convs run in
+    # conv3x3_pw for the big batch and in conv3x3_patch for a batch of one — the minimum-grid rule looks at B x planned chunk —
+    # and the two sum the channels in different chunk sizes: equal to fp32 rounding, hence 1e-4 and not 1e-6.)
     r1 = eng.predict(x[:1].contiguous(), T, seed=42)
-    torch.testing.assert_close(r1["mean"][:, 0], r["mean"][:, 0], rtol=0, atol=1e-6)
+    torch.testing.assert_close(r1["mean"][:, 0], r["mean"][:, 0], rtol=0, atol=1e-4)
 
 
 def test_pair_fusion_is_invisible(monkeypatch):

@@ -32,6 +32,7 @@ def test_repeat_launches_are_bit_identical_under_memory_traffic(mfma_shape):
     from bayesnn_fpga_amd import _lib
     for k in ("mfma_shape_patch", "mfma_shape_wide"):
         _lib.set_option(k, mfma_shape)
+    _lib.set_option("conv_pw", 1)
     try:
         bad = race_screen.screen(SHAPES, rounds=24, verbose=True)
     finally:
