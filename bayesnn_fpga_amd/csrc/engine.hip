@@ -9,8 +9,8 @@
 //   2. folds `chunk` Monte-Carlo samples into the GEMM M dimension of every suffix op
 //      (image index n = t_local * B + b), so weights are read once per chunk;
 //   3. accumulates softmax moments per exit in float64 on the device.
-// Activation buffers live in ONE caller-owned workspace; the suffix tensors are packed by
-// live range (first-fit) so a chunk's working set stays small enough for the Infinity Cache.
+// Activation buffers live in ONE caller-owned workspace; the suffix tensors are packed by live range (first-fit): 7 GB of
+// the 288 GB for the bench's 25 500-image-sample chunk (large chunks won every A/B, so activations do round-trip HBM).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
