@@ -79,7 +79,7 @@ struct PatchGeom {
 // 16 x 32 fragment), same LDS layout and swizzle (the 16 lanes of a read group are 16 consecutive rows either way).
 // Which one is faster is a clock question, not a cycle question (MI355X_MICROARCH.md, DVFS give-back item 7): both are
 // built and launch_conv3x3_patch picks by measured wall time (BMI_MFMA_SHAPE overrides).
-template <int TH, int TW, int IMGS, int TJ, bool PLAIN, int MS, bool BF, bool IMAP = false>
+template <int TH, int TW, int IMGS, int TJ, int EPI, int MS, bool BF, bool IMAP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     using G = PatchGeom<TH, TW, IMGS, TJ>;
     constexpr int BC = G::BC, PH = G::PH, PW = G::PW, PWP = G::PWP, KA = G::KA;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         off = ((size_t)n * (a.Ho * a.Wo) + rem) * a.Cout;
         return ok;
     };
-    epilogue_coalesced<TJ, PLAIN, MS, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
+    epilogue_coalesced<TJ, EPI, MS, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
     STAMP(3);
 }
 
@@ -303,30 +303,34 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     a.xcd_split = xcd_split_for(a.Cout / 128, (size_t)a.Cout * 9 * a.Cin * 2);
     const long tiles = (long)((a.N + IMGS - 1) / IMGS) * (a.Ho / TH) * (a.Wo / TW) * (a.Cout / 128);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
-    const bool plain = conv_epilogue_is_plain(a);
+    const int ms = (a.imap || a.bf16) ? 16 : opt_mfma_shape_patch();   // bf16 / dynamic exit: the 16x16x32 shape only
+    const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, ms) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
     const dim3 grid((unsigned)tiles), block(256);
-    if (a.imap) {   // dynamic early exit: instantiated for the 16x16 maps only (the 8x8 / 4x4 ones run in conv3x3_pw), 16x16x32
+#define PATCH_LAUNCH(EPI_, MS_, BF_, IMAP_) \
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, EPI_, MS_, BF_, IMAP_>), grid, block, 0, s, a)
+#define PATCH_LAUNCH_EPI16(BF_, IMAP_)                                            \
+    {                                                                             \
+        if (epi == BMI_EPI_PLAIN) PATCH_LAUNCH(BMI_EPI_PLAIN, 16, BF_, IMAP_);    \
+        else if (epi == BMI_EPI_LITE) PATCH_LAUNCH(BMI_EPI_LITE, 16, BF_, IMAP_); \
+        else PATCH_LAUNCH(BMI_EPI_GENERAL, 16, BF_, IMAP_);                       \
+    }
+    if (a.imap) {   // dynamic early exit: instantiated for the 16x16 maps only (the 8x8 / 4x4 ones run in conv3x3_pw)
         if constexpr (TH == 16) {
-            if (a.bf16) {
-                if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, true, true>), grid, block, 0, s, a);
-                else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, true, true>), grid, block, 0, s, a);
-            } else {
-                if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, false, true>), grid, block, 0, s, a);
-                else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, false, true>), grid, block, 0, s, a);
-            }
+            if (a.bf16) PATCH_LAUNCH_EPI16(true, true)
+            else PATCH_LAUNCH_EPI16(false, true)
         } else {
             return BMI_ERR_UNSUPPORTED;
         }
-    } else if (a.bf16) {                           // bf16 operands: the 16x16x32 shape only
-        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, true>), grid, block, 0, s, a);
-    } else if (opt_mfma_shape_patch() == 16) {     // bmi_set_option / BMI_MFMA_SHAPE; default chosen by measured wall time
-        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 16, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 16, false>), grid, block, 0, s, a);
+    } else if (a.bf16) {
+        PATCH_LAUNCH_EPI16(true, false)
+    } else if (ms == 16) {     // bmi_set_option / BMI_MFMA_SHAPE; default chosen by measured wall time
+        PATCH_LAUNCH_EPI16(false, false)
     } else {
-        if (plain) hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, true, 32, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, false, 32, false>), grid, block, 0, s, a);
+        if (epi == BMI_EPI_PLAIN) PATCH_LAUNCH(BMI_EPI_PLAIN, 32, false, false);
+        else PATCH_LAUNCH(BMI_EPI_GENERAL, 32, false, false);
     }
+#undef PATCH_LAUNCH_EPI16
+#undef PATCH_LAUNCH
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

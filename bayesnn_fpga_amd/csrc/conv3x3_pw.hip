@@ -74,7 +74,7 @@ struct PwGeom {
     __host__ __device__ static constexpr int cell_delta(int j) { return (j / BI) * PH * PWP + 4 * ((j % BI) / BR) * PWP + 4 * ((j % BI) % BR); }
 };
 
-template <int TW, bool PLAIN, bool BF, bool IMAP>
+template <int TW, int EPI, bool BF, bool IMAP>
 __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
     using G = PwGeom<TW>;
     constexpr int CT = G::CT, TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
         off = ((size_t)n * (TH * TW) + rem) * a.Cout;
         return ok;
     };
-    epilogue_coalesced<TJ, PLAIN, 16, BF>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+    epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
 }
 
 // Shapes this kernel takes: 3x3 / stride 1 / pad 1 on 8x8 or 4x4 maps with Cout % 256 == 0.
@@ -308,17 +308,18 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
     const long tiles = (long)((a.N + PwGeom<TW>::IMGS - 1) / PwGeom<TW>::IMGS) * (a.Cout / 256);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)tiles), block(512);
-    const bool plain = conv_epilogue_is_plain(a);
-#define PW_LAUNCH(IMAP_)                                                                                              \
-    if (a.bf16) {                                                                                                     \
-        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, true, IMAP_>), grid, block, 0, s, a);              \
-        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, true, IMAP_>), grid, block, 0, s, a);                   \
-    } else {                                                                                                          \
-        if (plain) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, true, false, IMAP_>), grid, block, 0, s, a);             \
-        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, false, false, IMAP_>), grid, block, 0, s, a);                  \
+    const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+#define PW_LAUNCH_BF(BF_, IMAP_)                                                                                                    \
+    {                                                                                                                               \
+        if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_PLAIN, BF_, IMAP_>), grid, block, 0, s, a);     \
+        else if (epi == BMI_EPI_LITE) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE, BF_, IMAP_>), grid, block, 0, s, a);  \
+        else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_GENERAL, BF_, IMAP_>), grid, block, 0, s, a);                        \
     }
+#define PW_LAUNCH(IMAP_) \
+    if (a.bf16) PW_LAUNCH_BF(true, IMAP_) else PW_LAUNCH_BF(false, IMAP_)
     if (a.imap) { PW_LAUNCH(true) } else { PW_LAUNCH(false) }
 #undef PW_LAUNCH
+#undef PW_LAUNCH_BF
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

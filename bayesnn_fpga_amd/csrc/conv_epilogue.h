@@ -314,17 +314,153 @@ __device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px
     }
 }
 
+// Which epilogue finishes a launch (launch-uniform; a KERNEL TEMPLATE PARAMETER, see below).
+#define BMI_EPI_GENERAL 0   // anything: two fp32 rounds through LDS (epilogue_coalesced)
+#define BMI_EPI_PLAIN 1     // BN + ReLU (epilogue_plain)
+#define BMI_EPI_LITE 2      // BN + residual + ReLU + elementwise 2-bit site, one fp16 trip through LDS (epilogue_lite)
+__host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_shape) {
+    if (conv_epilogue_is_plain(a)) return BMI_EPI_PLAIN;
+    const bool site_ok = a.site.kind == BMI_SITE_NONE ||
+                         (a.site.kind == BMI_SITE_ELEMENTWISE && a.site.log2_bits == 1 && !a.site.drop_all);
+    if (mfma_shape == 16 && site_ok && !a.site_inner && !a.bias_post) return BMI_EPI_LITE;
+    return BMI_EPI_GENERAL;
+}
+
+// "Lite" general epilogue (16x16x32 accumulators): the common non-plain launch of the path is a BasicBlock tail — BN,
+// residual add, ReLU, and (p = 0.25 MC-dropout) an elementwise site drawn at 2 bits per element.  epilogue_coalesced
+// handles it by moving the raw fp32 accumulators through LDS in two 64 KB rounds (four barriers, 2 x the LDS bytes, BN
+// and Philox in the second phase); measured on the 16x16-map conv of the headline: 2.17 ms against 1.71 ms with the
+// plain epilogue, and either feature alone already costs +15-20 %, i.e. the structure is the cost, not the arithmetic.
+// Here everything happens on the accumulator registers and the tile makes ONE fp16 trip through LDS like the plain one:
+//   1. BN scale/bias on the registers;
+//   2. the residual tile (64*TJ pixels x 128 channels, fp16) is DMA'd into LDS in the layout of the plain epilogue's
+//      output image (chunk q of pixel row p at q ^ (p & 15), no quad swap), coalesced 16-byte pieces; while it is in
+//      flight each lane computes its Philox calls: one call masks the 64 channels of (pixel, wave channel half), the
+//      wave's 16*2TJ pixels need 2TJ*16 calls = TJ/2 per lane, exchanged with ds_bpermute;
+//   3. a lane reads the residual quad that sits in ITS output slot, adds, applies ReLU and the keep bits (word i of the
+//      call, byte lane >> 4: the 4 two-bit fields of channels 16*i + 4*(lane >> 4) ..), rounds once and writes the result
+//      back IN PLACE;
+//   4. barrier, then the plain epilogue's store phase.
+// Same arithmetic in the same order as epilogue_coalesced (fp32 throughout, one rounding), so the bits agree.
+template <int TJ, bool BF, class ACC, class PixMap, class OffMap>
+__device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
+                                              PixMap pixmap, OffMap offmap) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wp = wave & 1;
+    const int l16 = lane & 15, q4 = lane >> 4;
+    const int HoWo = a.Ho * a.Wo;
+    const bool masked = a.site.kind == BMI_SITE_ELEMENTWISE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = ch0 + wc * 64 + 16 * i + 4 * q4;
+        f32x4_e sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) sc = *(const f32x4_e*)(a.scale + c4);
+        if (a.bias) bi = *(const f32x4_e*)(a.bias + c4);
+        sc *= a.out_mul;
+#pragma unroll
+        for (int j = 0; j < 2 * TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * sc[e] + bi[e];
+    }
+    lds_barrier();   // the main loop is done with the LDS
+    if (a.res) {
+#pragma unroll
+        for (int i = 0; i < 4 * TJ; ++i) {
+            const int q = i * 256 + tid, p = q >> 4, pos = q & 15;
+            int n, rem;
+            const bool ok = pixmap(p, n, rem);
+            const _Float16* src = ok ? a.res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout + ch0 + ((pos ^ (p & 15)) << 3)
+                                     : a.res;   // rows beyond the tensor are never stored
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    }
+    philox4 mine[TJ / 2];
+    if (masked) {
+#pragma unroll
+        for (int r = 0; r < TJ / 2; ++r) {
+            int n, rem;
+            pixmap(wp * (32 * TJ) + 16 * (q4 + 4 * r) + l16, n, rem);
+            const int tl = n / a.B;
+            const uint64_t e0 = (uint64_t)((n - tl * a.B) * HoWo + rem) * a.Cout + ch0 + wc * 64;
+            mine[r] = philox_site_call(a.site, e0, (uint32_t)(a.t0 + tl));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+#pragma unroll
+    for (int jb = 0; jb < 2 * TJ; jb += 4) {
+        half4 r4[4][4];
+        if (a.res) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int p = wp * (32 * TJ) + 16 * (jb + jj) + l16, cq = wc * 8 + 2 * i + (q4 >> 1);
+                    r4[jj][i] = *(const half4*)(lds + p * 256 + ((cq ^ l16) << 4) + ((q4 & 1) << 3));
+                }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = jb + jj;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (masked) {   // wave-uniform
+                const int src = l16 + 16 * (j & 3);
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) w[wd] = (uint32_t)__shfl((int)mine[j >> 2].w[wd], src, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = wp * (32 * TJ) + 16 * j + l16, cq = wc * 8 + 2 * i + (q4 >> 1);
+                const uint32_t fields = w[i] >> (8 * q4);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][e];
+                    if (a.res) v += a16_to_f32<BF>(r4[jj][i][e]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (masked) v = ((fields >> (2 * e)) & 3u) >= a.site.thresh ? v * a.site.scale : 0.f;
+                    asm("" : "+v"(v));   // keep the fp32 product: fused into v_fma_mixlo_f16 it is rounded once instead of twice,
+                                         // and 1 element in 10^6 ends one fp16 ulp away from what epilogue_coalesced stores
+                    o[e] = a16_from_f32<BF>(v);
+                }
+                *(half4*)(lds + p * 256 + ((cq ^ l16) << 4) + ((q4 & 1) << 3)) = o;
+            }
+        }
+    }
+    lds_barrier();
+    const int k = tid & 15;
+    half8_e o[4 * TJ];
+#pragma unroll
+    for (int it = 0; it < 4 * TJ; ++it) {
+        const int pl = (tid >> 4) + 16 * it;
+        o[it] = *(const half8_e*)(lds + pl * 256 + ((k ^ (pl & 15)) << 4));
+    }
+#pragma unroll
+    for (int it = 0; it < 4 * TJ; ++it) {
+        const int pl = (tid >> 4) + 16 * it;
+        size_t off;
+        if (!offmap(pl, off)) continue;
+        *(half8_e*)(a.out + off + ch0 + 8 * k) = o[it];
+    }
+}
+
 // pixmap(p, n, rem) -> bool: tile pixel p -> image n and y*Wo+x (false beyond the tensor);
 // offmap(p, off) -> bool: the same pixel's element offset in the output tensor (no division for linear tiles).
-// PLAIN (chosen per launch: no residual, no site) selects epilogue_plain at compile time: with both paths in one
-// kernel the register allocator spills 56-80 VGPRs in the other one.
-template <int TJ, bool PLAIN, int MS, bool BF, class ACC, class PixMap, class OffMap>
+// EPI (chosen per launch by conv_epilogue_kind) selects the epilogue at compile time: with two paths in one kernel the
+// register allocator spills 56-80 VGPRs in the other one.
+template <int TJ, int EPI, int MS, bool BF, class ACC, class PixMap, class OffMap>
 __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
                                                    PixMap pixmap, OffMap offmap) {
     static_assert(TJ == 2 || TJ == 4, "two pixel tiles per round");
     static_assert(MS == 32 || MS == 16, "MFMA shape");
-    if constexpr (PLAIN) {
+    if constexpr (EPI == BMI_EPI_PLAIN) {
         epilogue_plain<TJ, MS, BF>(a, acc, lds, tid, ch0, offmap);
+        return;
+    }
+    if constexpr (EPI == BMI_EPI_LITE) {
+        static_assert(MS == 16, "the lite epilogue reads the 16x16x32 accumulator layout");
+        epilogue_lite<TJ, BF>(a, acc, lds, tid, ch0, pixmap, offmap);
         return;
     }
     constexpr int NR = TJ / 2;

@@ -97,7 +97,7 @@ extern "C" int bmi_debug_wide_stamps_clear() {
             _Pragma("unroll") for (int j = 0; j < 4; ++j) { WIDE_MFMA(af[i], bf[j], acc[i][4 * ((KK) & 1) + j]); } \
     }
 
-template <bool PLAIN, int MS, bool BF, bool IMAP = false>
+template <int EPI, int MS, bool BF, bool IMAP = false>
 __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
     WIDE_SHAPE_CONSTS
     __shared__ __attribute__((aligned(16))) char smem[2 * WSTAGE];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide_kernel(ConvArgs a) {
         }
         return pix0 + p < a.M;
     };
-    epilogue_coalesced<TJ, PLAIN, MS, BF>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+    epilogue_coalesced<TJ, EPI, MS, BF>(b, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
     STAMP(3);
 #ifdef BMI_WIDE_STAMPS
     if (tid == 0 && blockIdx.x < 8192) g_wide_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -565,25 +565,28 @@ int launch_conv_igemm_wide(const ConvArgs& a_in, hipStream_t s) {
         return BMI_OK;
     }
     const dim3 grid((unsigned)blocks), block(512);
-    if (a.imap) {   // dynamic early exit: the 16x16x32 instantiations
-        const bool plain = conv_epilogue_is_plain(a);
-        if (a.bf16) {
-            if (plain) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, true, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, true, true>), grid, block, 0, s, a);
-        } else {
-            if (plain) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, false, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, false, true>), grid, block, 0, s, a);
-        }
-    } else if (a.bf16) {
-        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, true>), grid, block, 0, s, a);
-    } else if (shape == 16) {
-        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 16, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 16, false>), grid, block, 0, s, a);
-    } else {
-        if (conv_epilogue_is_plain(a)) hipLaunchKernelGGL((conv_igemm_wide_kernel<true, 32, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_wide_kernel<false, 32, false>), grid, block, 0, s, a);
+    const int ms = (a.imap || a.bf16) ? 16 : shape;   // bf16 / dynamic early exit: the 16x16x32 instantiations only
+    const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, ms) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+#define WIDE_LAUNCH(EPI_, MS_, BF_, IMAP_) hipLaunchKernelGGL((conv_igemm_wide_kernel<EPI_, MS_, BF_, IMAP_>), grid, block, 0, s, a)
+#define WIDE_LAUNCH_EPI16(BF_, IMAP_)                                            \
+    {                                                                            \
+        if (epi == BMI_EPI_PLAIN) WIDE_LAUNCH(BMI_EPI_PLAIN, 16, BF_, IMAP_);    \
+        else if (epi == BMI_EPI_LITE) WIDE_LAUNCH(BMI_EPI_LITE, 16, BF_, IMAP_); \
+        else WIDE_LAUNCH(BMI_EPI_GENERAL, 16, BF_, IMAP_);                       \
     }
+    if (a.imap) {
+        if (a.bf16) WIDE_LAUNCH_EPI16(true, true)
+        else WIDE_LAUNCH_EPI16(false, true)
+    } else if (a.bf16) {
+        WIDE_LAUNCH_EPI16(true, false)
+    } else if (ms == 16) {
+        WIDE_LAUNCH_EPI16(false, false)
+    } else {
+        if (epi == BMI_EPI_PLAIN) WIDE_LAUNCH(BMI_EPI_PLAIN, 32, false, false);
+        else WIDE_LAUNCH(BMI_EPI_GENERAL, 32, false, false);
+    }
+#undef WIDE_LAUNCH_EPI16
+#undef WIDE_LAUNCH
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

@@ -140,6 +140,7 @@ static int shape_from_env(const char* primary, const char* fallback) {
 int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nullptr); return v; }
 int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
 int& opt_conv_pw() { static int v = 1; return v; }
+int& opt_epilogue_lite() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
@@ -173,6 +174,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_pw") == 0) {
         if (value < 0 || value > 2) return BMI_ERR_INVALID;
         opt_conv_pw() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "epilogue_lite") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_epilogue_lite() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "xcd_split") == 0) {

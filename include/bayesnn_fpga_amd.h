@@ -149,6 +149,9 @@ const char* bmi_error_string(int code);
  *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
  *   "conv_pw"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-1 convs on 8x8 / 4x4 maps with Cout % 256 == 0 run in conv3x3_pw (256 x 256
  *                                           tile, 8 waves) instead of conv3x3_patch (128 x 128, 2 workgroups per CU)
+ *   "epilogue_lite"                         0 | 1: BN + residual + ReLU + 2-bit elementwise-site launches finish on the accumulator
+ *                                           registers with one fp16 trip through LDS (1, default) or in the general two-round fp32
+ *                                           epilogue (0); the same bits either way
  *   "wide_persist_min_x10"                  10..1000: conv_igemm_wide runs persistent (one workgroup per CU walking the tiles)
  *                                           when tiles * 10 > value * CUs
  *   "unit_entry_dtype"                      BMI_DTYPE_*: how the single-kernel entry points below (unit tests) interpret

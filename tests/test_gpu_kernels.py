@@ -20,19 +20,23 @@ def _gen(seed):
 
 def pytest_generate_tests(metafunc):
     """Every conv test runs under both MFMA instruction shapes (v_mfma_f32_32x32x16_f16 / 16x16x32_f16: different
-    accumulator layouts, hence different main-loop addressing and epilogue code in conv3x3_patch / conv_igemm_wide)."""
+    accumulator layouts, hence different main-loop addressing and epilogue code in conv3x3_patch / conv_igemm_wide), and the
+    16x16x32 shape with and without the lite epilogue (BN + residual + ReLU + 2-bit elementwise site on the registers)."""
     if metafunc.function.__name__.startswith("test_conv"):
         metafunc.fixturenames.append("mfma_shape")
-        metafunc.parametrize("mfma_shape", [32, 16], indirect=True, ids=["mfma32", "mfma16"])
+        metafunc.parametrize("mfma_shape", [(32, 1), (16, 1), (16, 0)], indirect=True, ids=["mfma32", "mfma16", "mfma16-general"])
 
 
 @pytest.fixture
 def mfma_shape(request):
+    shape, lite = request.param
     for k in ("mfma_shape_patch", "mfma_shape_wide"):
-        _lib.set_option(k, request.param)
-    yield request.param
+        _lib.set_option(k, shape)
+    _lib.set_option("epilogue_lite", lite)
+    yield shape
     for k in ("mfma_shape_patch", "mfma_shape_wide"):
         _lib.set_option(k, 0)
+    _lib.set_option("epilogue_lite", 1)
 
 
 @pytest.mark.parametrize("seed,site,t,p,n", [(42, 0, 0, 0.25, 4096), (7, 3, 99, 0.5, 1003), ((1 << 40) + 5, 6, 5, 0.125, 64),
@@ -643,3 +647,35 @@ def test_conv3x3_pw_kernel(name, n, general, dt):
     torch.testing.assert_close(got, out_patch.float().cpu().permute(0, 3, 1, 2), rtol=tol, atol=tol)
     if site is not None:
         assert torch.equal(got[mult == 0], torch.zeros_like(got[mult == 0])) and (mult == 0).any()
+
+
+@pytest.mark.parametrize("name,n,k1,dt", [("S2", 37, False, "f16"), ("S3", 300, False, "f16"), ("S4", 1100, False, "f16"), ("S3", 900, True, "f16"),
+                                          ("S2", 9, False, "bf16"), ("S4", 1050, False, "bf16")])
+@pytest.mark.parametrize("use_res,use_site", [(1, 0), (0, 1), (1, 1)])
+def test_lite_epilogue_equals_general_bit_for_bit(name, n, k1, dt, use_res, use_site):
+    """epilogue_lite (BN on the accumulator registers, residual DMA'd into the LDS output image, results written back in
+    place) against epilogue_coalesced (fp32 rounds through LDS) on BasicBlock tails: conv3x3_patch (S2), conv3x3_pw (S3 /
+    S4 above the minimum grid) and the wide 1x1 kernel — the same bits, so that a launch that has no lite instantiation
+    (per-tap fallback, 32x32x16 shape, dynamic-exit patch variants) still agrees with one that has."""
+    cin, cout, H, k, s, p = SHAPES[name]
+    if k1:
+        k, p = 1, 0
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = _gen(77)
+    x = torch.randn(n, H, H, cin, generator=g).to(tdt).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(tdt).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    res = torch.randn(n, H, H, cout, generator=g).to(tdt).to(DEV) if use_res else None
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=1, p=0.25) if use_site else None
+    outs = []
+    if dt == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    try:
+        for lite in (0, 1):
+            _lib.set_option("epilogue_lite", lite)
+            outs.append(gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=7, t0=3, seed=9, out_dtype=tdt))
+    finally:
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+        _lib.set_option("epilogue_lite", 1)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))

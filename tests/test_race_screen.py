@@ -23,6 +23,9 @@ SHAPES = [  # cin, cout, H, k, s, p, images
     (256, 512, 8, 1, 2, 0, 5000),    # P4: 1x1 taps (4 K-steps per tile), persistent
     (128, 128, 16, 3, 1, 1, 257), (256, 256, 8, 3, 1, 1, 515), (512, 512, 4, 3, 1, 1, 1031),   # patch kernel S2 / S3 / S4
     (256, 256, 8, 3, 1, 1, 1030), (512, 512, 4, 3, 1, 1, 4100),                                # conv3x3_pw (>= 3/4 tile per CU)
+    # BasicBlock tails (residual + ReLU + p = 0.25 elementwise site): the lite epilogue DMAs the residual into the LDS image the
+    # results are written back to in place — patch S2, conv3x3_pw S3 / S4, wide 1x1
+    (128, 128, 16, 3, 1, 1, 259, 1), (256, 256, 8, 3, 1, 1, 1027, 1), (512, 512, 4, 3, 1, 1, 4099, 1), (256, 512, 8, 1, 1, 0, 3001, 1),
 ]
 
 

@@ -16,9 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesnn_fpga_amd import _lib  # noqa: E402
 
-SHAPES = [  # cin, cout, H, k, s, p, images
+SHAPES = [  # cin, cout, H, k, s, p, images[, 1: BasicBlock tail = residual + ReLU + elementwise p = 0.25 site (epilogue_lite:
+           #  residual DMA'd into the LDS image the results are then written to in place)]
     (128, 256, 16, 3, 2, 1, 333), (256, 512, 8, 3, 2, 1, 777), (64, 256, 32, 3, 2, 1, 130), (256, 512, 8, 1, 2, 0, 901),
     (128, 128, 16, 3, 1, 1, 257), (256, 256, 8, 3, 1, 1, 515), (512, 512, 4, 3, 1, 1, 1031),
+    (128, 128, 16, 3, 1, 1, 259, 1), (256, 256, 8, 3, 1, 1, 1027, 1), (512, 512, 4, 3, 1, 1, 4099, 1), (256, 512, 8, 1, 1, 0, 903, 1),
 ]
 
 
@@ -29,19 +31,25 @@ def screen(shapes, rounds, scale=1, verbose=True):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator().manual_seed(7)
     cases = []
-    for cin, cout, H, k, s, p, n in shapes:
+    for shape in shapes:
+        cin, cout, H, k, s, p, n = shape[:7]
+        tail = len(shape) > 7 and shape[7]
         n = n * scale
         x = torch.randn(n, H, H, cin, generator=g).half().to(dev)
         w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).half().to(dev)
         sc, bi = (0.5 + torch.rand(cout, generator=g)).to(dev), (0.1 * torch.randn(cout, generator=g)).to(dev)
         ho = (H + 2 * p - k) // s + 1
         out = torch.empty(n, ho, ho, cout, dtype=torch.float16, device=dev)
-        cases.append((x, w, sc, bi, out, (n, H, cin, cout, k, s, p)))
+        res = torch.randn(n, ho, ho, cout, generator=g).half().to(dev) if tail else None
+        site = _lib.make_site(_lib.SITE_ELEMENTWISE, 2, 0.25) if tail else None
+        cases.append((x, w, sc, bi, out, (n, H, cin, cout, k, s, p), res, site))
 
     def run(c):
-        x, w, sc, bi, out, (n, H, cin, cout, k, s, p) = c
-        _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), sc.data_ptr(), bi.data_ptr(), None, out.data_ptr(),
-                                          n, n, n, H, H, cin, cout, k, s, p, 1, None, n, 0, 1, 0, st), "conv")
+        x, w, sc, bi, out, (n, H, cin, cout, k, s, p), res, site = c
+        _lib.check(lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), sc.data_ptr(), bi.data_ptr(),
+                                          res.data_ptr() if res is not None else None, out.data_ptr(),
+                                          n, n, n, H, H, cin, cout, k, s, p, 1, C.byref(site) if site is not None else None,
+                                          n, 0, 1, 0, st), "conv")
     first = []
     for c in cases:
         run(c)
