@@ -73,6 +73,7 @@ _PROTOS = {
     "bmi_conv_igemm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 5 + [C.c_int32] * 11 + [C.POINTER(Site), C.c_int32, C.c_int32,
                                                                          C.c_uint64, C.c_int32, C.c_void_p]),
     "bmi_conv3x3_shortcut_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 7 + [C.c_void_p]),
+    "bmi_profile_launches": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)] + [C.POINTER(C.c_int32)] * 4 + [C.POINTER(C.c_double)] * 3),
     "bmi_profile_conv_families": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                             C.POINTER(C.c_double)]),
     "bmi_conv_pair_fwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 11 + [C.c_void_p]),

@@ -50,6 +50,9 @@ struct ProfRec {
     int family = -1;     // BMI_CONV_FAMILY_* of a conv launch
     double flops = 0;    // its algorithmic FLOPs
     double bytes = 0;    // its algorithmic HBM bytes (inputs + residual + weights once, output once)
+    int out = -1;        // output tensor of the op (identifies the op in the graph)
+    int images = 0;      // images (samples x batch) the launch carried
+    float ms = 0.f;      // filled by bmi_profile_read
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -69,7 +72,7 @@ struct bmi_engine_s {
     bool profiling = false;
     double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0}, fam_bytes[BMI_CONV_FAMILIES] = {0};
     int64_t fam_launches[BMI_CONV_FAMILIES] = {0};
-    std::vector<ProfRec> recs;
+    std::vector<ProfRec> recs, last;   // last: the launches of the most recent bmi_profile_read (bmi_profile_launches)
     std::vector<hipEvent_t> pool;
 };
 
@@ -112,7 +115,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int* family) {
         const int rc = launch_conv3x3_patch(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
-    {
+    if (opt_conv_wide()) {
         *family = BMI_CONV_FAMILY_WIDE;
         const int rc = launch_conv_igemm_wide(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
@@ -141,6 +144,7 @@ int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nu
 int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
 int& opt_conv_pw() { static int v = 1; return v; }
 int& opt_epilogue_lite() { static int v = 1; return v; }
+int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
@@ -174,6 +178,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_pw") == 0) {
         if (value < 0 || value > 2) return BMI_ERR_INVALID;
         opt_conv_pw() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "conv_wide") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_conv_wide() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "epilogue_lite") == 0) {
@@ -568,6 +577,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     const int n_rows = imap ? (N / Bc) * B : N;     // rows of a stochastic tensor (original folded layout)
     if (imap && d.kind != BMI_OP_CONV && d.kind != BMI_OP_HEAD) return BMI_ERR_UNSUPPORTED;
     ProfScope prof(e, d.kind == OP_MASKBITS ? BMI_OP_MASK : d.kind, s);
+    prof.r.out = d.out; prof.r.images = N;
     switch (d.kind) {
         case BMI_OP_STEM:
             return launch_stem_conv(x, (const float*)d.weight, d.scale, d.bias, (_Float16*)(ws + e->tensors[d.out].offset), N,
@@ -771,9 +781,12 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
     for (int i = 0; i < BMI_PROFILE_SLOTS; ++i) { ms[i] = 0; launches[i] = 0; }
     for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { h->fam_ms[i] = 0; h->fam_flops[i] = 0; h->fam_bytes[i] = 0; h->fam_launches[i] = 0; }
     int rc = BMI_OK;
+    h->last.clear();
     for (auto& r : h->recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = BMI_ERR_HIP;
+        r.ms = t;
+        h->last.push_back(r);
         if (r.slot >= 0 && r.slot < BMI_PROFILE_SLOTS) { ms[r.slot] += t; launches[r.slot] += 1; }
         if (r.slot == BMI_OP_CONV && r.family >= 0 && r.family < BMI_CONV_FAMILIES) {
             h->fam_ms[r.family] += t; h->fam_flops[r.family] += r.flops; h->fam_bytes[r.family] += r.bytes; h->fam_launches[r.family] += 1;
@@ -789,6 +802,23 @@ int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_
                               double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]) {
     if (!h || !ms || !launches || !flops || !bytes) return BMI_ERR_INVALID;
     for (int i = 0; i < BMI_CONV_FAMILIES; ++i) { ms[i] = h->fam_ms[i]; launches[i] = h->fam_launches[i]; flops[i] = h->fam_flops[i]; bytes[i] = h->fam_bytes[i]; }
+    return BMI_OK;
+}
+
+int bmi_profile_launches(bmi_handle h, int32_t capacity, int32_t* count, int32_t* kind, int32_t* family, int32_t* out_tensor,
+                         int32_t* images, double* ms, double* flops, double* bytes) {
+    if (!h || !count || capacity < 0) return BMI_ERR_INVALID;
+    *count = (int32_t)h->last.size();
+    for (int i = 0; i < *count && i < capacity; ++i) {
+        const ProfRec& r = h->last[i];
+        if (kind) kind[i] = r.slot;
+        if (family) family[i] = r.family;
+        if (out_tensor) out_tensor[i] = r.out;
+        if (images) images[i] = r.images;
+        if (ms) ms[i] = r.ms;
+        if (flops) flops[i] = r.flops;
+        if (bytes) bytes[i] = r.bytes;
+    }
     return BMI_OK;
 }
 

@@ -155,32 +155,54 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][e] += part[((w * RT + i) * 16 + e) * 64 + lane];
             const bool drop_logits = a.site_logits.kind == BMI_SITE_ELEMENTWISE;
+            // bias (registers e of class tile i = classes 32*i + (e & 3) + 8*(e >> 2) + 4*hh)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (c < C) acc[i][e] += a.bias[c];
+                }
+            if (drop_logits) {
+                // dropout on the logits (converter/pytorch wraps the last Linear too, nn2bnn.py:33-45): [B, C] tensor, element =
+                // b*C + c.  Through LDS in a ROLLED loop over this lane's class quads: unrolled over 4 class tiles the two Philox
+                // calls per quad pushed the loop past hipcc's unroll budget and the accumulators into scratch (320 B per lane,
+                // the C = 100 head ran 107 us instead of 30).
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (c < C) pb_l[c * 33 + r] = acc[i][e];
+                    }
+#pragma unroll 1
+                for (int c4 = 4 * hh; c4 < C; c4 += 8) {
+                    const uint64_t elem = (uint64_t)b * C + c4;          // any alignment: b * C need not be a multiple of 4
+                    const uint32_t sh = (uint32_t)(elem & 7);
+                    uint32_t keep = site_keep8(a.site_logits, elem & ~(uint64_t)7, t) >> sh;
+                    if (sh > 4) keep |= site_keep8(a.site_logits, (elem & ~(uint64_t)7) + 8, t) << (8 - sh);   // the quad straddles two calls
+                    for (int e = 0; e < 4; ++e) {
+                        if (c4 + e < C) {
+                            const float v = pb_l[(c4 + e) * 33 + r];
+                            pb_l[(c4 + e) * 33 + r] = ((keep >> e) & 1u) ? v * a.site_logits.scale : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (c < C) acc[i][e] = pb_l[c * 33 + r];
+                    }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c4 = 32 * i + 8 * q + 4 * hh;          // registers 4q .. 4q+3 = classes c4 .. c4+3
-                    uint32_t keep = 0xFu;
-                    if (drop_logits) {
-                        // dropout on the logits (converter/pytorch wraps the last Linear too, nn2bnn.py:33-45):
-                        // [B, C] tensor, element = b*C + c
-                        const uint64_t elem = (uint64_t)b * C + c4;          // any alignment: b * C need not be a multiple of 4
-                        const uint32_t sh = (uint32_t)(elem & 7);
-                        keep = site_keep8(a.site_logits, elem & ~(uint64_t)7, t) >> sh;
-                        if (sh > 4) keep |= site_keep8(a.site_logits, (elem & ~(uint64_t)7) + 8, t) << (8 - sh);   // the quad straddles two calls
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = c4 + e;
-                        float v = acc[i][4 * q + e];
-                        if (c < C) {
-                            v += a.bias[c];
-                            if (drop_logits) v = ((keep >> e) & 1u) ? v * a.site_logits.scale : 0.f;
-                            mx = fmaxf(mx, v);
-                        }
-                        acc[i][4 * q + e] = v;
-                    }
+                for (int e = 0; e < 16; ++e) {
+                    const int c = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (c < C) mx = fmaxf(mx, acc[i][e]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float sum = 0.f;

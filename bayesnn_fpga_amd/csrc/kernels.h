@@ -110,6 +110,7 @@ int& opt_mfma_shape_wide();
 int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
 int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
 int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
+int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
 int& opt_epilogue_lite();      // 1: BN + residual + ReLU + 2-bit elementwise-site launches finish in epilogue_lite
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);

@@ -426,3 +426,15 @@ class MCDEngine(CompiledGraph):
         names = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel")
         self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i], bytes=fby[i]) for i in range(4) if fn[i]}
         return out
+
+    def profile_launches(self):
+        """The launches behind the last profile_read(), in order: dicts with kind, family, out (tensor id), images, ms, flops, bytes."""
+        cnt = C.c_int32(0)
+        _lib.check(self.lib.bmi_profile_launches(self.handle, 0, C.byref(cnt), None, None, None, None, None, None, None), "bmi_profile_launches")
+        n = cnt.value
+        ki, fa, ou, im = ((C.c_int32 * n)() for _ in range(4))
+        ms, fl, by = ((C.c_double * n)() for _ in range(3))
+        _lib.check(self.lib.bmi_profile_launches(self.handle, n, C.byref(cnt), ki, fa, ou, im, ms, fl, by), "bmi_profile_launches")
+        names = ("conv3x3_patch", "conv_igemm_wide", "conv_igemm", "conv3x3_pw")
+        return [dict(kind=_lib.PROFILE_NAMES.get(ki[i], str(ki[i])), family=names[fa[i]] if 0 <= fa[i] < 4 else None, out=ou[i], images=im[i],
+                     ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]

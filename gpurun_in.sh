@@ -1,4 +1,3 @@
-set -x
-timeout 300 python tools/experiments/ab_bitwise.py wide_direct_w=0 wide_direct_w=1 2>&1 | tail -13
-timeout 600 python tools/conv_bench.py --images 8000 --iters 10 --rounds 5 --only D3,D4,P4 --sparse-input --nores --ab "wide_direct_w=0,wide_direct_w=1" 2>&1 | tail -8
-BMI_WIDE_PERSIST=0 timeout 600 python tools/conv_bench.py --images 8000 --iters 10 --rounds 5 --only D3,D4,P4 --sparse-input --nores --ab "wide_direct_w=0,wide_direct_w=1" 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "head" 2>&1 | tail -3
+timeout 500 python tools/head_bench.py 2>&1 | grep -v amdgpu
+timeout 500 python tools/head_bench.py --cases 100:8,100:100 --K 2048 2>&1 | grep -v amdgpu

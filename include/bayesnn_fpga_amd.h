@@ -213,6 +213,13 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
                               double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]);
 
+/* The individual launches behind the most recent bmi_profile_read, in launch order: op kind (BMI_OP_*), conv family (-1 for
+ * non-conv ops), the op's output tensor id (identifies the op in the graph), images carried, device milliseconds, algorithmic
+ * FLOPs and HBM bytes (conv ops).  *count = number of launches recorded; at most `capacity` entries are written; any array
+ * may be NULL.  (tools/per_launch.py prints the table: which launch of a model sits where against its roofline.) */
+int bmi_profile_launches(bmi_handle h, int32_t capacity, int32_t* count, int32_t* kind, int32_t* family, int32_t* out_tensor,
+                         int32_t* images, double* ms, double* flops, double* bytes);
+
 /* ---- single-kernel entry points (unit parity tests) -------------------------------------- */
 
 /* keep bits (0/1 bytes) of elements 0..n-1 of stream (seed, site, t). */

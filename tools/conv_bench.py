@@ -21,6 +21,9 @@ SHAPES = {  # Cin, Cout, H, k, stride, pad
     "S2": (128, 128, 16, 3, 1, 1), "D3": (128, 256, 16, 3, 2, 1), "P3": (128, 256, 16, 1, 2, 0),
     "S3": (256, 256, 8, 3, 1, 1), "D4": (256, 512, 8, 3, 2, 1), "P4": (256, 512, 8, 1, 2, 0),
     "S4": (512, 512, 4, 3, 1, 1),
+    # Bottleneck 1x1 convs of ResNet-50 (HBM-bound): expand (with residual in the network) and reduce
+    "E2": (128, 512, 16, 1, 1, 0), "E3": (256, 1024, 8, 1, 1, 0), "E4": (512, 2048, 4, 1, 1, 0),
+    "R2": (512, 128, 16, 1, 1, 0), "R3": (1024, 256, 8, 1, 1, 0), "R4": (2048, 512, 4, 1, 1, 0),
 }
 
 
@@ -40,7 +43,7 @@ def main():
     a = ap.parse_args()
     lib = _lib.lib()
     dev = "cuda:0"
-    names = [s for s in a.only.split(",") if s] or list(SHAPES)
+    names = [s for s in a.only.split(",") if s] or [k for k in SHAPES if k[0] not in "ER"]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     total_t = total_f = 0.0
     for name in names:
@@ -92,7 +95,8 @@ def main():
         for v in variants:
             t = sorted(times[v])
             ms = t[len(t) // 2]
-            print(f"{name} {v or 'default':28s}: median {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s   min {t[0] * 1e3:8.1f} us "
+            nbytes = 2.0 * (n * H * H * cin + n * ho * ho * cout * (1 if a.nores else 2) + cout * k * k * cin)
+            print(f"{name} {v or 'default':28s}: median {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  {nbytes / ms / 1e6:6.0f} GB/s   min {t[0] * 1e3:8.1f} us "
                   f"{flops / t[0] / 1e9:7.1f} TFLOP/s   (M={n * ho * ho}, N={cout}, K={k * k * cin})", flush=True)
         total_t += sorted(times[variants[0]])[len(times[variants[0]]) // 2]
         total_f += flops
