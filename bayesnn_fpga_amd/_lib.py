@@ -15,6 +15,8 @@ SITE_POS_OUTER, SITE_POS_INNER = 0, 1
 DTYPE_F16, DTYPE_BF16 = 0, 1
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
 PROFILE_SLOTS = 8
+CONV_FAMILY_KERNELS = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel", "conv1x1_stream_kernel")
+CONV_FAMILIES = len(CONV_FAMILY_KERNELS)     # BMI_CONV_FAMILIES
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
                  OP_DENSE: "dense"}
 

@@ -1,0 +1,164 @@
+// HBM-bound 1x1 convolutions (the expand / reduce convs of Bottleneck nets, SA-style ResNet-50: a few hundred FLOPs per
+// byte at most, K = Cin <= 256): a kernel shaped for memory overlap instead of MFMA efficiency.
+//
+// conv_igemm_wide gives these launches a 256 x 256 tile, 8 waves and 128-136 KB of LDS: ONE workgroup per CU, whose life is
+// a chain of memory phases that never overlap (operand DMA -> wait -> 2-4 K-steps -> residual DMA -> wait -> stores).
+// Measured (tools/per_launch.py, ResNet-50 multi-exit, 16000 image-samples): the 128 -> 512 tails run at 3.5-3.7 TB/s of
+// algorithmic bytes, the 256 -> 1024 ones at 3.0, while a plain `out = a + b` over the same three tensors streams 6.1 TB/s
+// (tools/experiments/hbm_streams.py).  Here:
+//   tile        = 128 channels x 256 pixels, 4 waves (each 64 ch x 128 px, v_mfma_f32_16x16x32), 256 threads;
+//   LDS         = 64 KB: one single-buffered [weights 16 KB | pixels 32 KB] K-step of 64 channels, then the epilogue's
+//                 output image -> TWO workgroups per CU, 256 VGPRs each: while one waits for its operands or its residual,
+//                 the other computes or stores.  No intra-workgroup pipelining at all: the overlap is between workgroups;
+//   operands    = LDS-DMA (global_load_lds), 128-byte rows with the XOR swizzle of conv_igemm_wide on the source side;
+//   epilogue    = conv_epilogue.h (plain / lite / general), the same code and the same bits as every other conv kernel.
+// Taken for ksize 1, pad 0, stride 1 or 2, Cin % 64 == 0, Cin <= 256, Cout % 128 == 0 (conv_takes_stream_kernel) when the launch
+// carries a residual (the Bottleneck tails); the engine tries it before conv_igemm_wide.  Selection depends on the conv's
+// shape and epilogue terms only.  Measured: 128 -> 512 tail 2502 -> 2227 us, 256 -> 1024 tail 1529 -> 1373 us (bit-identical
+// results); still 4.2 / 3.4 TB/s against the 6.1 TB/s of an elementwise kernel: each workgroup exposes three HBM round trips
+// (operands per K-step, residual) and two workgroups per CU do not cover them all.
+#include "conv_epilogue.h"
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define GLDS16(SRC, LDSPTR)                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),       \
+                                     (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
+
+#define SBC 128
+#define SBP 256
+
+template <int EPI, bool BF>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[BMI_EPILOGUE_LDS_BYTES];
+    constexpr int XBASE = SBC * 128;   // pixel tile behind the weight tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int wc = wave >> 1, wp = wave & 1;
+
+    int ptile, ctile;
+    xcd_tile_map(blockIdx.x, (a.M + SBP - 1) / SBP, a.Cout / SBC, ptile, ctile, a.xcd_split);
+    const int ch0 = ctile * SBC;
+    const int pix0 = ptile * SBP;
+    const int HoWo = a.Ho * a.Wo;
+
+    // DMA piece q = tid + 256*i -> tile row (q >> 3) = 32*i + (tid >> 3), 16-byte slot tid & 7 (swizzled on the source side)
+    const int rowt = tid >> 3;
+    const int srcchunk = ((tid & 7) ^ ((rowt >> 1) & 7)) * 8;   // (32*i >> 1) & 7 == 0: the same for all i
+    const _Float16* wsrc[4];
+    const _Float16* xsrc[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wsrc[i] = a.wgt + (size_t)(ch0 + 32 * i + rowt) * a.Cin + srcchunk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(wsrc[i], smem + (i * 256 + wave * 64) * 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = pix0 + 32 * i + rowt;
+        const int mm = m < a.M ? m : 0;               // rows beyond the tensor read pixel 0: computed, never stored
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        xsrc[i] = a.in + ((size_t)(n % a.in_mod) * a.H * a.W + (size_t)(oy * a.stride) * a.W + ox * a.stride) * a.Cin + srcchunk;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) GLDS16(xsrc[i], smem + XBASE + (i * 256 + wave * 64) * 16);
+
+    typedef float accv __attribute__((ext_vector_type(4)));
+    accv acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    const int a_off = (wc * 64 + r) * 128;
+    const int b_off = XBASE + (wp * 128 + r) * 128;
+    const int sw_r = (r >> 1) & 7;
+    const int nK = a.Cin / 64;
+    for (int ks = 0; ks < nK; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // K-step ks has landed (every wave waited for its own pieces)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int coff = ((4 * sub + kq) ^ sw_r) << 4;
+            half8 af[4], bf[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(smem + a_off + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[j] = *(const half8*)(smem + b_off + j * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
+        }
+        if (ks + 1 < nK) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // every wave has read K-step ks: the buffer may be refilled
+            asm volatile("" ::: "memory");
+            const int koff = (ks + 1) * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) GLDS16(wsrc[i] + koff, smem + (i * 256 + wave * 64) * 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) GLDS16(xsrc[i] + koff, smem + XBASE + (i * 256 + wave * 64) * 16);
+        }
+    }
+
+    auto pixmap = [&](int p, int& n, int& rem) -> bool {
+        const int m = pix0 + p;
+        n = m / HoWo;
+        rem = m - n * HoWo;
+        return m < a.M;
+    };
+    auto offmap = [&](int p, size_t& off) -> bool {
+        off = (size_t)(pix0 + p) * a.Cout;
+        return pix0 + p < a.M;
+    };
+    epilogue_coalesced<4, EPI, 16, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
+}
+
+bool conv_takes_stream_kernel(int ksize, int stride, int pad, int cin, int cout) {
+    return ksize == 1 && pad == 0 && (stride == 1 || stride == 2) && cin % 64 == 0 && cin <= 256 && cout % SBC == 0;
+}
+
+// BMI_ERR_UNSUPPORTED -> the caller goes on to conv_igemm_wide / conv_igemm.
+int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
+    if (!opt_conv_stream() || a_in.in_bits || a_in.wgt_b || a_in.in2 || a_in.imap) return BMI_ERR_UNSUPPORTED;
+    if (!conv_takes_stream_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout)) return BMI_ERR_UNSUPPORTED;
+    if (a_in.N <= 0 || a_in.M <= 0 || a_in.in_mod <= 0 || a_in.B <= 0 || (a_in.res && a_in.res_mod <= 0)) return BMI_ERR_INVALID;
+    ConvArgs a = a_in;
+    a.xcd_split = xcd_split_for(a.Cout / SBC, (size_t)a.Cout * a.Cin * 2);
+    const long tiles = (((long)a.M + SBP - 1) / SBP) * (a.Cout / SBC);
+    if (tiles > 0x7fffffffL) return BMI_ERR_INVALID;
+    // the minimum-grid rule of the other wide-tile kernels (on the engine's full-chunk image count, never this launch's)
+    static const int n_cu = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+        return cu;
+    }();
+    const long tiles_sel = a.n_ref > 0 ? (((long)a.n_ref * a.Ho * a.Wo + SBP - 1) / SBP) * (a.Cout / SBC) : tiles;
+    if (opt_conv_stream() != 2 && tiles_sel < (n_cu > 0 ? 3 * n_cu / 2 : 384)) return BMI_ERR_UNSUPPORTED;
+    const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+    // (the general epilogue — Masksembles / channel sites, 4-16-bit probabilities — spills 16 VGPRs next to this kernel's twelve
+    //  DMA row pointers: those launches stay with conv_igemm_wide)
+    if (epi == BMI_EPI_GENERAL) return BMI_ERR_UNSUPPORTED;
+    // Plain launches (no residual: one read stream, one write stream) stay with the persistent conv_igemm_wide, which prefetches
+    // the next tile under its epilogue: same-process A/B at 16000 image-samples, 128 -> 512 / 256 -> 1024: 1333 / 914 us there,
+    // 1470 / 970 us here; with the residual 2502 / 1529 us there, 2227 / 1373 us here.  "conv_stream" = 2 takes them too (tests).
+    if (epi == BMI_EPI_PLAIN && opt_conv_stream() != 2) return BMI_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)tiles), block(256);
+#define STREAM_LAUNCH(BF_)                                                                                                      \
+    {                                                                                                                           \
+        if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_>), grid, block, 0, s, a);                              \
+    }
+    if (a.bf16) STREAM_LAUNCH(true) else STREAM_LAUNCH(false)
+#undef STREAM_LAUNCH
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}

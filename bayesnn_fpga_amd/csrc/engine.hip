@@ -115,6 +115,11 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int* family) {
         const int rc = launch_conv3x3_patch(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
+    {
+        *family = BMI_CONV_FAMILY_STREAM;
+        const int rc = launch_conv1x1_stream(a, s);
+        if (rc != BMI_ERR_UNSUPPORTED) return rc;
+    }
     if (opt_conv_wide()) {
         *family = BMI_CONV_FAMILY_WIDE;
         const int rc = launch_conv_igemm_wide(a, s);
@@ -144,6 +149,7 @@ int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nu
 int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
 int& opt_conv_pw() { static int v = 1; return v; }
 int& opt_epilogue_lite() { static int v = 1; return v; }
+int& opt_conv_stream() { static int v = 1; return v; }
 int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
@@ -183,6 +189,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_wide") == 0) {
         if (value != 0 && value != 1) return BMI_ERR_INVALID;
         opt_conv_wide() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "conv_stream") == 0) {
+        if (value < 0 || value > 2) return BMI_ERR_INVALID;
+        opt_conv_stream() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "epilogue_lite") == 0) {

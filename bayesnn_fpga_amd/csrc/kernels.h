@@ -102,6 +102,7 @@ int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, 
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
 int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s);
+int launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);
 
 // process-wide kernel-selection switches (bmi_set_option); 16 or 32
@@ -111,6 +112,7 @@ int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
 int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
 int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
 int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
+int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
 int& opt_epilogue_lite();      // 1: BN + residual + ReLU + 2-bit elementwise-site launches finish in epilogue_lite
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);

@@ -12,6 +12,7 @@
 #include "kernels.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void site_mask8(const SiteArgs& s, float v[8], uint64_t elem0, int t, const float* mrow) {
@@ -115,6 +116,61 @@ __global__ __launch_bounds__(256) void mask_apply_shared_kernel(EltArgs a) {
     }
 }
 
+// The MC-dropout case proper (2 bits per element: p = 0.25 / 0.5 / 0.75; no affine + ReLU behind the mask), made HBM-bound.
+// mask_apply_shared_kernel spends ~4100 cycles of vector ALU per super-block and SIMD (the 8 KB it writes need ~2900 at
+// 6 TB/s): four ds_bpermute per item to fetch the owner's whole Philox output, a compare + select per element.  Here
+//   * every lane parks its call's four words in a 1 KB per-wave LDS table (one ds_write_b128), and an item fetches just
+//     ITS 16 bits (8 two-bit fields) with one ds_read_u16 (the LDS operations of one wave complete in order: no barrier);
+//   * the keep test runs on all 8 fields at once: with b0 / b1 the even / odd bits, field >= thresh is b1|b0 (thresh 1),
+//     b1 (2) or b1&b0 (3);
+//   * a kept element is x * scale rounded once from fp32 (the oracle's arithmetic), a dropped one is cleared by ANDing
+//     the packed 16-bit results with a mask built from sign-extended bit extracts: no per-element select.
+template <bool BF>
+__global__ __launch_bounds__(256) void mask_apply_lb1_kernel(EltArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t words[4][64 * 4];
+    const int lane = threadIdx.x & 63;
+    uint32_t* const W = words[threadIdx.x >> 6];
+    const long sample_elems = (long)a.B * a.HW * a.C;
+    const long sb_per_sample = sample_elems / (64L * 8 * 8);
+    const long n_sb = sb_per_sample * (a.N / a.B);
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long)gridDim.x * blockDim.x) >> 6;
+    const size_t in_sample_stride = a.in_mod == a.B ? 0 : (size_t)sample_elems;   // deterministic input: every sample reads [B]
+    const uint32_t thresh = a.site.thresh;
+    const uint32_t use_or = thresh == 1 ? 0xFFFFu : 0u, use_and = thresh == 3 ? 0xFFFFu : 0u;
+    const char* const myfield = (const char*)W + (lane >> 3) * 16 + 2 * (lane & 7);   // + 128 * j: owner lane j*8 + lane/8
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (long sb = wave0; sb < n_sb; sb += n_waves) {
+        const long tl = sb / sb_per_sample, sbs = sb - tl * sb_per_sample;
+        const uint64_t g = (uint64_t)sbs * 64 + lane;                          // this lane's call
+        const philox4 mine = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(a.t0 + tl), (uint32_t)a.site.site_id,
+                                           a.site.seed_lo, a.site.seed_hi);
+        *(u32x4*)(W + lane * 4) = u32x4{mine.w[0], mine.w[1], mine.w[2], mine.w[3]};
+        const _Float16* src = a.in + (size_t)tl * in_sample_stride + ((size_t)sbs * 512 + lane) * 8;
+        _Float16* dst = (_Float16*)a.out + (size_t)tl * sample_elems + ((size_t)sbs * 512 + lane) * 8;
+        half8 x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = *(const half8*)(src + j * 512);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t f = *(const uint16_t*)(myfield + 128 * j);
+            const uint32_t b0 = f & 0x5555u, b1 = (f >> 1) & 0x5555u;
+            const uint32_t kb = a.site.drop_all ? 0u : ((b1 | (b0 & use_or)) & (b0 | ~use_and));   // bit 2e = keep element e
+            half8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = a16_from_f32<BF>(a16_to_f32<BF>(x[j][e]) * a.site.scale);
+            const u32x4 rb = __builtin_bit_cast(u32x4, r);
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lo = (uint32_t)(((int)(kb << (31 - 4 * i))) >> 31);        // element 2i   kept: all ones
+                const uint32_t hi = (uint32_t)(((int)(kb << (29 - 4 * i))) >> 31);        // element 2i+1
+                o[i] = rb[i] & ((lo & 0xFFFFu) | (hi & 0xFFFF0000u));
+            }
+            *(u32x4*)(dst + j * 512) = o;
+        }
+    }
+}
+
 int launch_mask_apply(const EltArgs& a, hipStream_t s) {
     if (a.C % 8 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
@@ -130,6 +186,13 @@ int launch_mask_apply(const EltArgs& a, hipStream_t s) {
         long wblocks = (n_sb + 3) / 4;                 // 4 waves per block, one super-block per wave and iteration
         if (wblocks > 256 * 16) wblocks = 256 * 16;
         const dim3 g((unsigned)wblocks), b(256);
+        static const int lean = [] { const char* v = std::getenv("BMI_MASK_LEAN"); return v ? std::atoi(v) : 1; }();
+        if (lean && lb == 1 && !a.bias_post && !a.relu) {
+            if (a.bf16) hipLaunchKernelGGL((mask_apply_lb1_kernel<true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((mask_apply_lb1_kernel<false>), g, b, 0, s, a);
+            BMI_CHECK_LAUNCH();
+            return BMI_OK;
+        }
         if (a.bf16) {
             if (lb == 1) hipLaunchKernelGGL((mask_apply_shared_kernel<1, true>), g, b, 0, s, a);
             else if (lb == 2) hipLaunchKernelGGL((mask_apply_shared_kernel<2, true>), g, b, 0, s, a);

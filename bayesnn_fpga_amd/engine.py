@@ -421,10 +421,11 @@ class MCDEngine(CompiledGraph):
         n = (C.c_int64 * _lib.PROFILE_SLOTS)()
         _lib.check(self.lib.bmi_profile_read(self.handle, ms, n), "bmi_profile_read")
         out = {_lib.PROFILE_NAMES.get(i, str(i)): (ms[i], n[i]) for i in range(_lib.PROFILE_SLOTS) if n[i]}
-        fms, fn, ffl, fby = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)(), (C.c_double * 4)()
+        nf = _lib.CONV_FAMILIES
+        fms, fn, ffl, fby = (C.c_double * nf)(), (C.c_int64 * nf)(), (C.c_double * nf)(), (C.c_double * nf)()
         _lib.check(self.lib.bmi_profile_conv_families(self.handle, fms, fn, ffl, fby), "bmi_profile_conv_families")
-        names = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel")
-        self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i], bytes=fby[i]) for i in range(4) if fn[i]}
+        names = _lib.CONV_FAMILY_KERNELS
+        self.conv_families = {names[i]: dict(ms=fms[i], launches=fn[i], flops=ffl[i], bytes=fby[i]) for i in range(nf) if fn[i]}
         return out
 
     def profile_launches(self):
@@ -435,6 +436,6 @@ class MCDEngine(CompiledGraph):
         ki, fa, ou, im = ((C.c_int32 * n)() for _ in range(4))
         ms, fl, by = ((C.c_double * n)() for _ in range(3))
         _lib.check(self.lib.bmi_profile_launches(self.handle, n, C.byref(cnt), ki, fa, ou, im, ms, fl, by), "bmi_profile_launches")
-        names = ("conv3x3_patch", "conv_igemm_wide", "conv_igemm", "conv3x3_pw")
-        return [dict(kind=_lib.PROFILE_NAMES.get(ki[i], str(ki[i])), family=names[fa[i]] if 0 <= fa[i] < 4 else None, out=ou[i], images=im[i],
+        names = [k[:-len("_kernel")] for k in _lib.CONV_FAMILY_KERNELS]
+        return [dict(kind=_lib.PROFILE_NAMES.get(ki[i], str(ki[i])), family=names[fa[i]] if 0 <= fa[i] < len(names) else None, out=ou[i], images=im[i],
                      ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]

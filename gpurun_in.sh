@@ -1,3 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "head" 2>&1 | tail -3
-timeout 500 python tools/head_bench.py 2>&1 | grep -v amdgpu
-timeout 500 python tools/head_bench.py --cases 100:8,100:100 --K 2048 2>&1 | grep -v amdgpu
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 600 python tools/step_ab.py --workload resnet50_me --rounds 5 --steps 2 --ab "conv_stream=0,conv_stream=1" 2>&1 | tail -4

@@ -149,6 +149,9 @@ const char* bmi_error_string(int code);
  *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
  *   "conv_pw"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-1 convs on 8x8 / 4x4 maps with Cout % 256 == 0 run in conv3x3_pw (256 x 256
  *                                           tile, 8 waves) instead of conv3x3_patch (128 x 128, 2 workgroups per CU)
+ *   "conv_stream"                           0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 1x1 convs with Cin <= 256 (HBM-bound) run in
+ *                                           conv1x1_stream (128 x 256 tile, two workgroups per CU) instead of conv_igemm_wide
+ *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
  *   "epilogue_lite"                         0 | 1: BN + residual + ReLU + 2-bit elementwise-site launches finish on the accumulator
  *                                           registers with one fp16 trip through LDS (1, default) or in the general two-round fp32
  *                                           epilogue (0); the same bits either way
@@ -209,7 +212,8 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
 #define BMI_CONV_FAMILY_WIDE 1  /* conv_igemm_wide_kernel */
 #define BMI_CONV_FAMILY_IGEMM 2 /* conv_igemm_kernel */
 #define BMI_CONV_FAMILY_PW 3    /* conv3x3_pw_kernel */
-#define BMI_CONV_FAMILIES 4
+#define BMI_CONV_FAMILY_STREAM 4 /* conv1x1_stream_kernel */
+#define BMI_CONV_FAMILIES 5
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
                               double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]);
 

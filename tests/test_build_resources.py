@@ -11,7 +11,7 @@ import pytest
 
 from bayesnn_fpga_amd import _build
 
-FILES = ["conv3x3_patch.hip", "conv3x3_pw.hip", "conv_igemm_wide.hip", "conv_igemm.hip"]
+FILES = ["conv3x3_patch.hip", "conv3x3_pw.hip", "conv_igemm_wide.hip", "conv_igemm.hip", "conv1x1_stream.hip", "head_fused.hip"]
 
 
 @pytest.mark.parametrize("src", FILES)

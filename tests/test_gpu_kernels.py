@@ -679,3 +679,38 @@ def test_lite_epilogue_equals_general_bit_for_bit(name, n, k1, dt, use_res, use_
         _lib.set_option("epilogue_lite", 1)
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("cin,cout,H,stride,n,dt", [(128, 512, 16, 1, 37, "f16"), (256, 1024, 8, 1, 131, "f16"), (64, 256, 32, 1, 5, "bf16"),
+                                                    (256, 512, 8, 2, 77, "f16")])
+@pytest.mark.parametrize("use_res,use_site", [(0, 0), (1, 0), (1, 1)])
+def test_conv1x1_stream_kernel(cin, cout, H, stride, n, dt, use_res, use_site):
+    """conv1x1_stream (HBM-bound Bottleneck 1x1 convs: 128 x 256 tile, single-buffered K-steps, two workgroups per CU) against the
+    fp32 reference, and bit for bit against the kernels it replaces (same K order, same epilogue code): ragged pixel counts,
+    stride 2, plain / residual / residual + elementwise site."""
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = _gen(41)
+    x = torch.randn(n, H, H, cin, generator=g).to(tdt).to(DEV)
+    w = (torch.randn(cout, 1, 1, cin, generator=g) * (2.0 / cin) ** 0.5).to(tdt).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    ho = (H - 1) // stride + 1
+    res = torch.randn(n, ho, ho, cout, generator=g).to(tdt).to(DEV) if use_res else None
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=2, p=0.25) if use_site else None
+    if dt == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    try:
+        _lib.set_option("conv_stream", 2)          # no minimum grid, plain launches too
+        out = gh.run_conv(x, w, scale, bias, res, True, stride, 0, n, n, n, site=site, batch=n, t0=1, seed=3, out_dtype=tdt)
+        _lib.set_option("conv_stream", 0)
+        out_other = gh.run_conv(x, w, scale, bias, res, True, stride, 0, n, n, n, site=site, batch=n, t0=1, seed=3, out_dtype=tdt)
+    finally:
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+        _lib.set_option("conv_stream", 1)
+    ref = gh.conv_ref(x, w, scale, bias, res, True, stride, 0, n, n, n)
+    if site is not None:
+        ref = ref * gh.folded_site_mask(site, n, cout, ho, ho, 1, 1, 3)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    tol = 2e-3 if dt == "f16" else 1e-2
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
+    assert torch.equal(out.view(torch.int16), out_other.view(torch.int16))

@@ -14,7 +14,7 @@ lib, dev = _lib.lib(), "cuda:0"
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 g = torch.Generator().manual_seed(3)
 variants = sys.argv[1:3]
-for cin, cout, H, k, s, p, n in [(64, 256, 32, 3, 2, 1, 300), (128, 256, 16, 3, 2, 1, 1100), (256, 512, 8, 3, 2, 1, 4200), (256, 512, 8, 1, 2, 0, 5000),
+for cin, cout, H, k, s, p, n in [(64, 256, 32, 3, 2, 1, 300), (128, 256, 16, 3, 2, 1, 1100), (256, 512, 8, 3, 2, 1, 4200), (256, 512, 8, 1, 2, 0, 5000), (128, 512, 16, 1, 1, 0, 2001), (64, 128, 32, 1, 2, 0, 777), (256, 1024, 8, 1, 1, 0, 3003),
                                  (256, 512, 8, 1, 1, 0, 3000), (128, 256, 16, 3, 2, 1, 4001)]:
     x = torch.randn(n, H, H, cin, generator=g).half().to(dev)
     w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).half().to(dev)
