@@ -150,7 +150,9 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
     // Plain launches (no residual: one read stream, one write stream) stay with the persistent conv_igemm_wide, which prefetches
     // the next tile under its epilogue: same-process A/B at 16000 image-samples, 128 -> 512 / 256 -> 1024: 1333 / 914 us there,
     // 1470 / 970 us here; with the residual 2502 / 1529 us there, 2227 / 1373 us here.  "conv_stream" = 2 takes them too (tests).
-    if (epi == BMI_EPI_PLAIN && opt_conv_stream() != 2) return BMI_ERR_UNSUPPORTED;
+    // Where the wide kernel cannot go (Cout % 256 != 0: the 256 -> 128 / 64 -> 128 reduce and downsample convs) the alternative is the
+    // per-tap conv_igemm, and this kernel wins plain launches too: 256 -> 128 on 32x32 2723 -> 2310 us, 64 -> 128 stride 2 455 -> 312 us.
+    if (epi == BMI_EPI_PLAIN && a.Cout % 256 == 0 && opt_conv_stream() != 2) return BMI_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
 #define STREAM_LAUNCH(BF_)                                                                                                      \
     {                                                                                                                           \

@@ -62,6 +62,7 @@ struct EltArgs {  // MASK op
     SiteArgs site;
     const float* bias_post;  // MASK with an inner site: out = relu?(x * mask + bias_post[c]); or null
     int relu;
+    int tchunk;              // (set by the launcher) samples per work item of mask_apply_lb1_kernel
 };
 
 struct HeadArgs {   // fused exit head (head_fused.hip)

@@ -116,15 +116,17 @@ __global__ __launch_bounds__(256) void mask_apply_shared_kernel(EltArgs a) {
     }
 }
 
-// The MC-dropout case proper (2 bits per element: p = 0.25 / 0.5 / 0.75; no affine + ReLU behind the mask), made HBM-bound.
-// mask_apply_shared_kernel spends ~4100 cycles of vector ALU per super-block and SIMD (the 8 KB it writes need ~2900 at
-// 6 TB/s): four ds_bpermute per item to fetch the owner's whole Philox output, a compare + select per element.  Here
-//   * every lane parks its call's four words in a 1 KB per-wave LDS table (one ds_write_b128), and an item fetches just
-//     ITS 16 bits (8 two-bit fields) with one ds_read_u16 (the LDS operations of one wave complete in order: no barrier);
-//   * the keep test runs on all 8 fields at once: with b0 / b1 the even / odd bits, field >= thresh is b1|b0 (thresh 1),
-//     b1 (2) or b1&b0 (3);
-//   * a kept element is x * scale rounded once from fp32 (the oracle's arithmetic), a dropped one is cleared by ANDing
-//     the packed 16-bit results with a mask built from sign-extended bit extracts: no per-element select.
+// The MC-dropout case proper (2 bits per element: p = 0.25 / 0.5 / 0.75; no affine + ReLU behind the mask).  Two things kept
+// mask_apply_shared_kernel at 4.2 TB/s of writes (0.78 ms for the 3.3 GB of the headline's first site; a fill reaches 6.9):
+//   * vector ALU: four ds_bpermute per item to fetch the owner's whole Philox output, a compare + select per element.  Here every
+//     lane parks its call's four words in a 1 KB per-wave LDS table (one ds_write_b128) and an item fetches just ITS 16 bits
+//     (8 two-bit fields) with one ds_read_u16 (the LDS operations of one wave complete in order: no barrier); the keep test
+//     runs on all 8 fields at once (with b0 / b1 the even / odd bits, field >= thresh is b1|b0, b1 or b1&b0 for thresh 1, 2,
+//     3); a dropped element is cleared by ANDing the packed 16-bit results with a mask built from sign-extended bit
+//     extracts.  0.75 -> 0.69 ms;
+//   * fabric reads: see the work-item comment below.  0.69 -> 0.62 ms (ResNet-50's first site, 8.4 GB: 2.8 -> 1.6 ms).
+// A kept element is x * scale in fp32 rounded once (the oracle's arithmetic).  (Letting the producing conv apply the scale so
+// that this kernel is a pure AND was built and measured: no change, the conversions are not what it waits for.)
 template <bool BF>
 __global__ __launch_bounds__(256) void mask_apply_lb1_kernel(EltArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t words[4][64 * 4];
@@ -132,41 +134,58 @@ __global__ __launch_bounds__(256) void mask_apply_lb1_kernel(EltArgs a) {
     uint32_t* const W = words[threadIdx.x >> 6];
     const long sample_elems = (long)a.B * a.HW * a.C;
     const long sb_per_sample = sample_elems / (64L * 8 * 8);
-    const long n_sb = sb_per_sample * (a.N / a.B);
     const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long)gridDim.x * blockDim.x) >> 6;
-    const size_t in_sample_stride = a.in_mod == a.B ? 0 : (size_t)sample_elems;   // deterministic input: every sample reads [B]
     const uint32_t thresh = a.site.thresh;
     const uint32_t use_or = thresh == 1 ? 0xFFFFu : 0u, use_and = thresh == 3 ? 0xFFFFu : 0u;
     const char* const myfield = (const char*)W + (lane >> 3) * 16 + 2 * (lane & 7);   // + 128 * j: owner lane j*8 + lane/8
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (long sb = wave0; sb < n_sb; sb += n_waves) {
-        const long tl = sb / sb_per_sample, sbs = sb - tl * sb_per_sample;
+    // Work item = (super-block of the sample, chunk of `tchunk` samples).  With a deterministic input (the usual case: the site
+    // expands the once-per-batch prefix to the folded batch) the item's 8 KB of input are loaded ONCE and masked tchunk times:
+    // as one item per (sample, super-block) every sample re-read the whole [B] tensor through the fabric (33 MB does not fit an
+    // XCD's 4 MB L2: 3.3 GB of Infinity-Cache reads next to the 3.3 GB of HBM writes, 4.8 TB/s of writes where a fill reaches
+    // 6.9), and the kernel stayed at 0.68 ms however few vector instructions it issued.
+    const int T = a.N / a.B;
+    const int tchunk = a.in_mod == a.B ? a.tchunk : 1;
+    const long n_tchunks = (T + tchunk - 1) / tchunk;
+    const long n_items = sb_per_sample * n_tchunks;
+    for (long it = wave0; it < n_items; it += n_waves) {
+        const long tci = it / sb_per_sample, sbs = it - tci * sb_per_sample;
         const uint64_t g = (uint64_t)sbs * 64 + lane;                          // this lane's call
-        const philox4 mine = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(a.t0 + tl), (uint32_t)a.site.site_id,
-                                           a.site.seed_lo, a.site.seed_hi);
-        *(u32x4*)(W + lane * 4) = u32x4{mine.w[0], mine.w[1], mine.w[2], mine.w[3]};
-        const _Float16* src = a.in + (size_t)tl * in_sample_stride + ((size_t)sbs * 512 + lane) * 8;
-        _Float16* dst = (_Float16*)a.out + (size_t)tl * sample_elems + ((size_t)sbs * 512 + lane) * 8;
+        const int t_lo = (int)tci * tchunk, t_hi = min(T, t_lo + tchunk);
         half8 x[8];
+        if (a.in_mod == a.B) {
+            const _Float16* src = a.in + ((size_t)sbs * 512 + lane) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = *(const half8*)(src + j * 512);
+            for (int j = 0; j < 8; ++j) x[j] = *(const half8*)(src + j * 512);
+        }
+        for (int tl = t_lo; tl < t_hi; ++tl) {
+            const philox4 mine = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(a.t0 + tl), (uint32_t)a.site.site_id,
+                                               a.site.seed_lo, a.site.seed_hi);
+            *(u32x4*)(W + lane * 4) = u32x4{mine.w[0], mine.w[1], mine.w[2], mine.w[3]};
+            if (a.in_mod != a.B) {
+                const _Float16* src = a.in + (size_t)tl * sample_elems + ((size_t)sbs * 512 + lane) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t f = *(const uint16_t*)(myfield + 128 * j);
-            const uint32_t b0 = f & 0x5555u, b1 = (f >> 1) & 0x5555u;
-            const uint32_t kb = a.site.drop_all ? 0u : ((b1 | (b0 & use_or)) & (b0 | ~use_and));   // bit 2e = keep element e
-            half8 r;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = a16_from_f32<BF>(a16_to_f32<BF>(x[j][e]) * a.site.scale);
-            const u32x4 rb = __builtin_bit_cast(u32x4, r);
-            u32x4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t lo = (uint32_t)(((int)(kb << (31 - 4 * i))) >> 31);        // element 2i   kept: all ones
-                const uint32_t hi = (uint32_t)(((int)(kb << (29 - 4 * i))) >> 31);        // element 2i+1
-                o[i] = rb[i] & ((lo & 0xFFFFu) | (hi & 0xFFFF0000u));
+                for (int j = 0; j < 8; ++j) x[j] = *(const half8*)(src + j * 512);
             }
-            *(u32x4*)(dst + j * 512) = o;
+            _Float16* dst = (_Float16*)a.out + (size_t)tl * sample_elems + ((size_t)sbs * 512 + lane) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t f = *(const uint16_t*)(myfield + 128 * j);
+                const uint32_t b0 = f & 0x5555u, b1 = (f >> 1) & 0x5555u;
+                const uint32_t kb = a.site.drop_all ? 0u : ((b1 | (b0 & use_or)) & (b0 | ~use_and));   // bit 2e = keep element e
+                half8 r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = a16_from_f32<BF>(a16_to_f32<BF>(x[j][e]) * a.site.scale);
+                const u32x4 rb = __builtin_bit_cast(u32x4, r);
+                u32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t lo = (uint32_t)(((int)(kb << (31 - 4 * i))) >> 31);        // element 2i   kept: all ones
+                    const uint32_t hi = (uint32_t)(((int)(kb << (29 - 4 * i))) >> 31);        // element 2i+1
+                    o[i] = rb[i] & ((lo & 0xFFFFu) | (hi & 0xFFFF0000u));
+                }
+                *(u32x4*)(dst + j * 512) = o;
+            }
         }
     }
 }
@@ -188,6 +207,17 @@ int launch_mask_apply(const EltArgs& a, hipStream_t s) {
         const dim3 g((unsigned)wblocks), b(256);
         static const int lean = [] { const char* v = std::getenv("BMI_MASK_LEAN"); return v ? std::atoi(v) : 1; }();
         if (lean && lb == 1 && !a.bias_post && !a.relu) {
+            // samples per work item (deterministic input): as many as still leave ~2 items per wave slot of the chip
+            EltArgs al = a;
+            const long sbs = sample_elems / 4096, T = a.N / a.B;
+            long chunks = (16384 + sbs - 1) / sbs;
+            if (chunks > T) chunks = T;
+            al.tchunk = (int)((T + chunks - 1) / chunks);
+            const long items = sbs * (a.in_mod == a.B ? (T + al.tchunk - 1) / al.tchunk : T);
+            long lblocks = (items + 3) / 4;
+            if (lblocks > 256 * 16) lblocks = 256 * 16;
+            const dim3 g((unsigned)lblocks);
+            const EltArgs& a = al;
             if (a.bf16) hipLaunchKernelGGL((mask_apply_lb1_kernel<true>), g, b, 0, s, a);
             else hipLaunchKernelGGL((mask_apply_lb1_kernel<false>), g, b, 0, s, a);
             BMI_CHECK_LAUNCH();

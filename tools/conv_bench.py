@@ -23,7 +23,7 @@ SHAPES = {  # Cin, Cout, H, k, stride, pad
     "S4": (512, 512, 4, 3, 1, 1),
     # Bottleneck 1x1 convs of ResNet-50 (HBM-bound): expand (with residual in the network) and reduce
     "E2": (128, 512, 16, 1, 1, 0), "E3": (256, 1024, 8, 1, 1, 0), "E4": (512, 2048, 4, 1, 1, 0),
-    "R2": (512, 128, 16, 1, 1, 0), "R3": (1024, 256, 8, 1, 1, 0), "R4": (2048, 512, 4, 1, 1, 0),
+    "Q1": (256, 128, 32, 1, 1, 0), "R2": (512, 128, 16, 1, 1, 0), "R3": (1024, 256, 8, 1, 1, 0), "R4": (2048, 512, 4, 1, 1, 0),
 }
 
 
@@ -43,7 +43,7 @@ def main():
     a = ap.parse_args()
     lib = _lib.lib()
     dev = "cuda:0"
-    names = [s for s in a.only.split(",") if s] or [k for k in SHAPES if k[0] not in "ER"]
+    names = [s for s in a.only.split(",") if s] or [k for k in SHAPES if k[0] not in "EQR"]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     total_t = total_f = 0.0
     for name in names:
