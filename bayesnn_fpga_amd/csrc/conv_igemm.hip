@@ -30,7 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // first-class 
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK, bool PLAIN, bool BF, bool IMAP = false>
+template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK, bool PLAIN, bool BF, bool IMAP = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TI = BC / WC / 32;   // 32x32 MFMA tiles per wave along channels
     constexpr int TJ = BP / WP / 32;   // ... along pixels
@@ -128,8 +128,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nK = a.ksize * a.ksize * (a.Cin / BK);
+    const int nK_all = a.ksize * a.ksize * (a.Cin / BK);
+    int ks_begin = 0, nK = nK_all;
     int ky = 0, kx = 0, c0 = 0;
+    if constexpr (SPLITK) {   // blockIdx.y takes K-steps [ks_begin, ks_begin + nK)
+        ks_begin = (int)((long)blockIdx.y * nK_all / a.nsplit);
+        nK = (int)((long)(blockIdx.y + 1) * nK_all / a.nsplit) - ks_begin;
+        const int cpt = a.Cin / BK, tap = ks_begin / cpt;
+        c0 = (ks_begin - tap * cpt) * BK;
+        ky = tap / a.ksize;
+        kx = tap - ky * a.ksize;
+    }
     GLOAD(ky, kx, c0);
     if constexpr (DBUF) {
         LSTORE(0);
@@ -180,7 +189,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #undef GLOAD
 #undef LSTORE
     // ---- epilogue ---------------------------------------------------------------------------
-    if constexpr (BC == 128 && WC == 2 && WP == 2) {
+    if constexpr (SPLITK) {
+        // raw partial sums; BN / ReLU / the 16-bit rounding happen in splitk_finish_kernel once all splits are added
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = pix0 + wp * (BP / WP) + 32 * j + r;
+            if (m >= a.M) continue;
+            float* prow = a.partial + ((size_t)blockIdx.y * a.M + m) * a.Cout;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c4 = ch0 + wc * (BC / WC) + 32 * i + 8 * g4 + 4 * hh;
+                    *(float4*)(prow + c4) = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+                }
+        }
+    } else if constexpr (BC == 128 && WC == 2 && WP == 2) {
         // coalesced through LDS (conv_epilogue.h); the double buffer is exactly the 64 KB it needs
         auto pixmap = [&](int p, int& n, int& rem) -> bool {
             const int m = pix0 + p;
@@ -252,11 +276,58 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     return BMI_OK;
 }
 
+// out = fp16(relu?(bn(sum over the splits, in split order))): the plain epilogue's arithmetic on the added partial sums.
+template <bool BF>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs a) {
+    const long total = (long)a.M * (a.Cout >> 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (a.Cout >> 2)) * 4;
+        const long m = i / (a.Cout >> 2);
+        float4 sum = *(const float4*)(a.partial + (size_t)m * a.Cout + c4);
+        for (int sp = 1; sp < a.nsplit; ++sp) {
+            const float4 p = *(const float4*)(a.partial + ((size_t)sp * a.M + m) * a.Cout + c4);
+            sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+        }
+        float v[4] = {sum.x, sum.y, sum.z, sum.w};
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sc = (a.scale ? a.scale[c4 + e] : 1.f) * a.out_mul, bi = a.bias ? a.bias[c4 + e] : 0.f;
+            float x = v[e] * sc + bi;
+            if (a.relu) x = fmaxf(x, 0.f);
+            o[e] = a16_from_f32<BF>(x);
+        }
+        *(half4*)(a.out + (size_t)m * a.Cout + c4) = o;
+    }
+}
+
+int launch_splitk_finish(const ConvArgs& a, hipStream_t s) {
+    if (!a.partial || a.nsplit < 2 || a.Cout % 4 != 0) return BMI_ERR_INVALID;
+    const long total = (long)a.M * (a.Cout >> 2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (a.bf16) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.Cin % BK != 0 || a.Cout % 64 != 0 || a.in2) return BMI_ERR_UNSUPPORTED;   // the fused shortcut is a patch-kernel feature
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
     if (a.res && a.res_mod <= 0) return BMI_ERR_INVALID;
     static const int big = [] { const char* v = std::getenv("BMI_IGEMM_BP256"); return v ? std::atoi(v) : 1; }();
+    if (a.partial) {   // split-K: 128 x 128 tiles, nsplit workgroups per tile, then the finishing pass
+        if (a.nsplit < 2 || a.nsplit > a.ksize * a.ksize * (a.Cin / BK) || !conv_epilogue_is_plain(a) || a.Cout % 128 != 0 || a.in_bits || a.imap)
+            return BMI_ERR_INVALID;
+        const long tiles = (((long)a.M + 127) / 128) * (a.Cout / 128);
+        if (tiles > 0x7fffffffL) return BMI_ERR_INVALID;
+        const dim3 grid((unsigned)tiles, (unsigned)a.nsplit), block(256);
+        if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, true, false, true, true, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, true, false, true, false, false, true>), grid, block, 0, s, a);
+        BMI_CHECK_LAUNCH();
+        return launch_splitk_finish(a, s);
+    }
     if (a.in_bits) {   // masked-input variant (register budget: 128-pixel tiles only)
         if (a.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2, true, true>(a, s);
         return launch_cfg<64, 128, 1, 4, true, true>(a, s);

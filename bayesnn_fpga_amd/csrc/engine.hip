@@ -39,6 +39,7 @@ struct OpInfo {
     int ho = 0, wo = 0, cout = 0;
     int bits_tensor = -1;   // CONV: keep bits applied to the input while staging, or -1
     float out_mul = 1.f;    // CONV: multiplies the folded-BN scale (1/(1-p) of the input-side site)
+    int nsplit = 0;         // CONV (prefix): split-K workgroups per tile (bmi_plan; 0 = none)
     bool has_pair = false;  // CONV: a second conv on the same input rides in this launch (conv_igemm_wide pair mode)
     bmi_op_desc pair_d;
     int pair_cout = 0;
@@ -68,6 +69,7 @@ struct bmi_engine_s {
     // plan
     int max_batch = 0, chunk = 0;
     size_t ws_bytes = 0, exit_off = 0;   // exit_off: 2 active-image lists + a counter (dynamic early exit)
+    size_t splitk_off = 0;               // fp32 partial sums of the split-K prefix convs
     // profiling
     bool profiling = false;
     double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0}, fam_bytes[BMI_CONV_FAMILIES] = {0};
@@ -149,6 +151,7 @@ int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nu
 int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
 int& opt_conv_pw() { static int v = 1; return v; }
 int& opt_epilogue_lite() { static int v = 1; return v; }
+int& opt_splitk() { static int v = 1; return v; }
 int& opt_conv_stream() { static int v = 1; return v; }
 int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
@@ -194,6 +197,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_stream") == 0) {
         if (value < 0 || value > 2) return BMI_ERR_INVALID;
         opt_conv_stream() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "splitk") == 0) {   // read by bmi_plan
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_splitk() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "epilogue_lite") == 0) {
@@ -535,6 +543,25 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     off = st_base + st_peak;
     h->exit_off = off;
     off += align_up((2 * (size_t)max_batch + 64 + NS) * sizeof(int), 256);   // two image lists, a counter, the row table
+    // Split-K for the skinny deterministic 3x3 convs (VGG's 512 -> 512 convs on 2x2 maps: 250 images are 1000 pixels = 32 tiles
+    // of 128 x 128 on 256 CUs, 65 us at 73 TFLOP/s): one workgroup per (tile, tap), fp32 partial sums, a finishing pass.
+    // Decided here from the shape and the planned batch only.
+    h->splitk_off = off;
+    size_t sk_bytes = 0;
+    for (OpInfo& op : h->prefix) {
+        op.nsplit = 0;
+        const bmi_op_desc& d = op.d;
+        if (d.kind != BMI_OP_CONV || !opt_splitk() || d.ksize != 3 || d.stride != 1 || d.residual >= 0 || d.in2 >= 0 || d.site.kind != BMI_SITE_NONE ||
+            op.has_pair || op.bits_tensor >= 0 || op.cout % 128 != 0)
+            continue;
+        const TensorInfo& ti = h->tensors[d.in];
+        const size_t M = B * op.ho * op.wo;
+        const size_t tiles = (M + 127) / 128 * (op.cout / 128);
+        if (ti.c % 64 != 0 || ti.c < 256 || tiles > 64) continue;
+        op.nsplit = 9;
+        sk_bytes = std::max(sk_bytes, align_up((size_t)op.nsplit * M * op.cout * sizeof(float), 256));
+    }
+    off += sk_bytes;
     h->ws_bytes = off;
     h->max_batch = max_batch;
     h->chunk = chunk_samples;
@@ -649,6 +676,12 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 const int rc2 = launch_conv(a, s, &fam);
                 prof.tag(fam, flops, bytes);
                 return rc2 != BMI_OK ? rc2 : launch_conv(q, s);
+            }
+            if (op.nsplit > 1 && !op.stoch && !rows) {
+                a.partial = (float*)(ws + e->splitk_off);
+                a.nsplit = op.nsplit;
+                prof.tag(BMI_CONV_FAMILY_IGEMM, flops, bytes);
+                return launch_conv_igemm(a, s);
             }
             int fam = -1;
             const int rcc = launch_conv(a, s, &fam);

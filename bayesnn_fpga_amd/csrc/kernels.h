@@ -49,6 +49,11 @@ struct ConvArgs {
     // imap[n] = (n / Bc) * B + active[n % Bc] of every tensor (which keep their original folded layout) and of the Philox index
     const int* imap;   // device [N] row of each compact image, or null (identity)
     int Bc;            // still-active images per sample (informational)
+    // split-K (small grids: a 3x3 conv on a 2x2 map of a 250-image batch is 32 tiles): nsplit workgroups per tile each take a
+    // contiguous range of the K-steps and store raw fp32 partial sums [nsplit][M][Cout]; launch_splitk_finish adds them in a
+    // fixed order and applies BN / ReLU.  Plain epilogue only; null = no split.
+    float* partial;
+    int nsplit;
     int xcd_split; // channel-tile classes of the XCD-aware tile order (xcd_tile_map's cs); set by the launcher
     SiteArgs site;
 };
@@ -103,6 +108,7 @@ int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, 
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
 int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s);
+int launch_splitk_finish(const ConvArgs& a, hipStream_t s);   // after a split-K conv_igemm launch
 int launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);
 
@@ -114,6 +120,7 @@ int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > valu
 int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
 int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
+int& opt_splitk();             // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch
 int& opt_epilogue_lite();      // 1: BN + residual + ReLU + 2-bit elementwise-site launches finish in epilogue_lite
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);

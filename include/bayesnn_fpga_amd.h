@@ -152,6 +152,8 @@ const char* bmi_error_string(int code);
  *   "conv_stream"                           0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 1x1 convs with Cin <= 256 (HBM-bound) run in
  *                                           conv1x1_stream (128 x 256 tile, two workgroups per CU) instead of conv_igemm_wide
  *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
+ *   "splitk"                                0 | 1, read by bmi_plan: 3x3 convs of the once-per-batch prefix whose grid is <= 64 tiles (VGG's convs on
+ *                                           2x2 maps) run split-K: one workgroup per (tile, tap), fp32 partial sums, a finishing pass
  *   "epilogue_lite"                         0 | 1: BN + residual + ReLU + 2-bit elementwise-site launches finish on the accumulator
  *                                           registers with one fp16 trip through LDS (1, default) or in the general two-round fp32
  *                                           epilogue (0); the same bits either way

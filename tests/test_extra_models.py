@@ -76,3 +76,25 @@ def test_gpu_extra_model_against_oracle(cls, ocls, kw):
     r = m.engine(xd.device, max_batch=B).predict(xd, T, seed=seed)
     np.testing.assert_allclose(r["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(r["var"].cpu().numpy(), ref["var"], rtol=0, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_splitk_prefix_convs_match_unsplit():
+    """bmi_plan gives the skinny deterministic 3x3 convs (VGG-11's 256+ channel convs on 8x8 ... 2x2 maps at a small batch: a few
+    tiles on 256 CUs) a split-K launch: one workgroup per (tile, tap), fp32 partial sums in workspace scratch, a finishing
+    pass.  Same function as the unsplit launch up to the fp32 summation order over K."""
+    from bayesnn_fpga_amd import _lib
+    B, T, seed = 6, 4, 3
+    x = synthetic_images(B, seed=7).to("cuda:0")
+    out, ws = {}, {}
+    for sk in (0, 1):
+        _lib.set_option("splitk", sk)
+        try:
+            m = synthetic_weights_(build_seeded(bx.VGG11MC, dict(num_bayes_layer=3, dropout_p=0.25, out_dim=10)), 0).to("cuda:0").eval()
+            eng = m.engine(x.device, max_batch=B)
+            ws[sk] = eng.workspace_bytes
+            out[sk] = eng.predict(x, T, seed=seed)["mean"].cpu().numpy()
+        finally:
+            _lib.set_option("splitk", 1)
+    assert ws[1] > ws[0]                                  # the partial-sum scratch was planned, i.e. the split path ran
+    np.testing.assert_allclose(out[1], out[0], rtol=0, atol=5e-4)
