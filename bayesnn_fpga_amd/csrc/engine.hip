@@ -373,7 +373,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 }
                 const TensorInfo& to = e->tensors[d.out];
                 if (tin.h != 1 || tin.w != 1 || to.h != 1 || to.w != 1) { rc = BMI_ERR_INVALID; break; }
-                if (tin.c % 16 != 0 || to.c % 64 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                if (tin.c % 32 != 0 || to.c % 64 != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
                 op.d.residual = -1; op.d.in2 = -1;
                 // a site makes the layer per-sample even on a deterministic input (the layer is tiny: no conv + MASK split)
                 op.stoch = in_st || d.site.kind != BMI_SITE_NONE;

@@ -283,7 +283,7 @@ int bmi_head_fused(const void* in, int32_t in_is_f32, int32_t in_mod, int32_t hw
 
 /* Hidden dense layer in fp32 (BMI_OP_DENSE): out[n][c] = relu?(in[n % in_mod] . weight[c] + bias[c]) (site on the
  * [batch, cout] tensor, sample index n / batch + t0).  `in` is fp16 (in_is_f32 = 0) or fp32 [.][k]; weight fp32 [cout][k];
- * k % 16 == 0, cout % 64 == 0.  Replaces the Dense 512 layers of the VGG-11 classifier stack
+ * k % 32 == 0, cout % 64 == 0.  Replaces the Dense 512 layers of the VGG-11 classifier stack
  * (Hardware_Artifact/bayes_hw/models/models.py:262-281) with their dropout (:268-281). */
 int bmi_dense_f32(const void* in, int32_t in_is_f32 /* 0: 16-bit (unit_entry_dtype), 1: fp32 */, const float* weight, const float* bias, float* out, int32_t n,
                   int32_t in_mod, int32_t k, int32_t cout, int32_t relu, const bmi_site* site, int32_t batch, int32_t t0,
