@@ -1,5 +1,5 @@
 // HBM-bound 1x1 convolutions (the expand / reduce convs of Bottleneck nets, SA-style ResNet-50: a few hundred FLOPs per
-// byte at most, K = Cin <= 256): a kernel shaped for memory overlap instead of MFMA efficiency.
+// byte at most, K = Cin <= 512): a kernel shaped for memory overlap instead of MFMA efficiency.
 //
 // conv_igemm_wide gives these launches a 256 x 256 tile, 8 waves and 128-136 KB of LDS: ONE workgroup per CU, whose life is
 // a chain of memory phases that never overlap (operand DMA -> wait -> 2-4 K-steps -> residual DMA -> wait -> stores).
@@ -12,7 +12,7 @@
 //                 the other computes or stores.  No intra-workgroup pipelining at all: the overlap is between workgroups;
 //   operands    = LDS-DMA (global_load_lds), 128-byte rows with the XOR swizzle of conv_igemm_wide on the source side;
 //   epilogue    = conv_epilogue.h (plain / lite / general), the same code and the same bits as every other conv kernel.
-// Taken for ksize 1, pad 0, stride 1 or 2, Cin % 64 == 0, Cin <= 256, Cout % 128 == 0 (conv_takes_stream_kernel) when the launch
+// Taken for ksize 1, pad 0, stride 1 or 2, Cin % 64 == 0, Cin <= 512, Cout % 128 == 0 (conv_takes_stream_kernel) when the launch
 // carries a residual (the Bottleneck tails); the engine tries it before conv_igemm_wide.  Selection depends on the conv's
 // shape and epilogue terms only.  Measured: 128 -> 512 tail 2502 -> 2227 us, 256 -> 1024 tail 1529 -> 1373 us (bit-identical
 // results); still 4.2 / 3.4 TB/s against the 6.1 TB/s of an elementwise kernel: each workgroup exposes three HBM round trips
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
 }
 
 bool conv_takes_stream_kernel(int ksize, int stride, int pad, int cin, int cout) {
-    return ksize == 1 && pad == 0 && (stride == 1 || stride == 2) && cin % 64 == 0 && cin <= 256 && cout % SBC == 0;
+    return ksize == 1 && pad == 0 && (stride == 1 || stride == 2) && cin % 64 == 0 && cin <= 512 && cout % SBC == 0;
 }
 
 // BMI_ERR_UNSUPPORTED -> the caller goes on to conv_igemm_wide / conv_igemm.

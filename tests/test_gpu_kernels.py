@@ -682,7 +682,7 @@ def test_lite_epilogue_equals_general_bit_for_bit(name, n, k1, dt, use_res, use_
 
 
 @pytest.mark.parametrize("cin,cout,H,stride,n,dt", [(128, 512, 16, 1, 37, "f16"), (256, 1024, 8, 1, 131, "f16"), (64, 256, 32, 1, 5, "bf16"),
-                                                    (256, 512, 8, 2, 77, "f16")])
+                                                    (256, 512, 8, 2, 77, "f16"), (512, 256, 4, 1, 700, "f16")])
 @pytest.mark.parametrize("use_res,use_site", [(0, 0), (1, 0), (1, 1)])
 def test_conv1x1_stream_kernel(cin, cout, H, stride, n, dt, use_res, use_site):
     """conv1x1_stream (HBM-bound Bottleneck 1x1 convs: 128 x 256 tile, single-buffered K-steps, two workgroups per CU) against the
