@@ -19,6 +19,8 @@
 //                 float64 (32 lanes = 32 samples of one class; the reference averages in float64; per-sample values are
 //                 bit-identical however the samples are chunked or sharded, so only the float64 summation order depends
 //                 on it: <= 1e-13 relative).
+#include <cstdlib>
+
 #include "conv_epilogue.h"
 #include "kernels.h"
 
@@ -30,8 +32,15 @@ typedef _Float16 half8_h __attribute__((ext_vector_type(8)));
 #define HEAD_FEAT_BYTES (32 * HEAD_KC * 4)
 
 // KIND: 0 fp16, 1 fp32, 2 bf16 input tensor
-template <int RT, int KIND>
+// STAGED (RT >= 3, K % 128 == 0): the classifier weights go through LDS.  In the direct form every lane streams its own 2 KB
+// weight row (one float4 per load: 64 cache lines per wave instruction, and the 4 waves x 2 class tiles in flight thrash the
+// 32 KB L1): with 4 class tiles (C = 100) a workgroup pulls 256 KB that way and the head took 54 us where the 10-class one takes
+// 16.  Staged, a wave fetches [64 classes][32 k] blocks of its K quarter with 8 lanes per 128-byte row segment into its own
+// 9 KB of LDS (rows padded to 36 floats; the region aliases `part`, which is only used after the K loop; wave-private: the LDS
+// operations of a wave complete in order, no barrier) one block ahead of the MFMAs, and lane half h reads k0 + 16h .. + 15.
+template <int RT, int KIND, bool STAGED = false>
 __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
+    static_assert(!STAGED || RT >= 3, "the staging buffers alias `part` (16 KB x RT): 4 x 9 KB need RT >= 3");
     __shared__ __attribute__((aligned(16))) char smem[HEAD_FEAT_BYTES + 4 * RT * 16 * 64 * 4];
     float* const feat = (float*)smem;
     float* const part = (float*)(smem + HEAD_FEAT_BYTES);     // [4 waves][RT][16 regs][64 lanes]
@@ -59,13 +68,21 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
             const int koff = wave * (kc >> 2) + hh * kq;
             const float* wp = a.w + (size_t)r * K + k0 + koff;
             constexpr int NPAIR = (RT + 1) / 2, W2 = RT < 2 ? RT : 2;
-            f32x4_h wpre[W2][16];
+            f32x4_h wpre[STAGED ? 1 : W2][STAGED ? 1 : 16];
+            f32x4_h wst[STAGED ? 8 : 1];                       // STAGED: the next [64 classes][32 k] block, 8 float4 per lane
+            const int kw0 = wave * (kc >> 2);                  // this wave's K quarter inside the chunk
+#define HEAD_FETCH_W(PS, CK)                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                \
+        const int f_ = lane + 64 * i_, row_ = f_ >> 3, kq_ = f_ & 7;                                                  \
+        wst[i_] = (64 * (PS) + row_ < 32 * RT) ? *(const f32x4_h*)(a.w + (size_t)(64 * (PS) + row_) * K + k0 + kw0 + 32 * (CK) + 4 * kq_) \
+                                               : f32x4_h{0.f, 0.f, 0.f, 0.f};                                         \
+    }
 #define HEAD_LOAD_W(PS)                                                                                              \
     _Pragma("unroll") for (int ii = 0; ii < W2; ++ii)                                                                 \
         _Pragma("unroll") for (int q = 0; q < 16; ++q)                                                                \
             wpre[ii][q] = (2 * (PS) + ii < RT && 4 * q < kq) ? *(const f32x4_h*)(wp + (size_t)(32 * (2 * (PS) + ii)) * K + 4 * q) \
                                                              : f32x4_h{0.f, 0.f, 0.f, 0.f};
-            HEAD_LOAD_W(0)
+            if constexpr (STAGED) { HEAD_FETCH_W(0, 0) } else { HEAD_LOAD_W(0) }
             // ---- phase A: pool 8 samples per wave into LDS ----
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = jj * 4 + wave;                  // interleaved: a launch with few samples (T = 8) still uses all waves
@@ -111,7 +128,38 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
             }
             __syncthreads();
             // ---- phase B: this wave's quarter of the chunk's K, lane half hh takes half of that ----
-            {
+            if constexpr (STAGED) {
+                const float* fr = feat + r * kc;
+                float* const Wt = part + wave * (64 * 36);     // wave-private [64 classes][36]
+                const int nck = (kc >> 2) >> 5;                // 32-deep blocks in this wave's quarter
+#pragma unroll
+                for (int ps = 0; ps < NPAIR; ++ps) {
+                    for (int ck = 0; ck < nck; ++ck) {
+#pragma unroll
+                        for (int i_ = 0; i_ < 8; ++i_) {
+                            const int f_ = lane + 64 * i_;
+                            *(f32x4_h*)(Wt + (f_ >> 3) * 36 + 4 * (f_ & 7)) = wst[i_];
+                        }
+                        // the block after this one (next k block, or the first of the next class-tile pair)
+                        if (ck + 1 < nck) { HEAD_FETCH_W(ps, ck + 1) }
+                        else if (ps + 1 < NPAIR) { HEAD_FETCH_W(ps + 1, 0) }
+                        f32x4_h aq[W2][4], bq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bq[q] = *(const f32x4_h*)(fr + ((((kw0 + 32 * ck + 16 * hh + 4 * q) >> 2) ^ (r & swz)) << 2));
+#pragma unroll
+                            for (int ii = 0; ii < W2; ++ii) aq[ii][q] = *(const f32x4_h*)(Wt + (32 * ii + r) * 36 + 16 * hh + 4 * q);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int ii = 0; ii < W2; ++ii)
+                                    if (2 * ps + ii < RT) acc[2 * ps + ii] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ii][q][e], bq[q][e], acc[2 * ps + ii], 0, 0, 0);
+                    }
+                }
+            } else {
                 const float* fr = feat + r * kc;
 #pragma unroll
                 for (int ps = 0; ps < NPAIR; ++ps) {
@@ -133,6 +181,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
                 }
             }
 #undef HEAD_LOAD_W
+#undef HEAD_FETCH_W
             __syncthreads();                                   // feat is free for the next chunk
         }
         // ---- the four K-quarters meet in LDS ----
@@ -255,6 +304,15 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
 template <int RT>
 static void launch_rt(const HeadArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.imap ? a.Bc : a.B), (unsigned)((a.tc + 31) / 32)), block(256);
+    if constexpr (RT >= 3) {
+        static const int staged = [] { const char* v = std::getenv("BMI_HEAD_STAGED"); return v ? std::atoi(v) : 1; }();
+        if (staged && a.K % 128 == 0 && (a.K <= HEAD_KC || a.K % HEAD_KC == 0)) {   // every LDS chunk a multiple of 128
+            if (a.in_kind == 1) hipLaunchKernelGGL((head_fused_kernel<RT, 1, true>), grid, block, 0, s, a);
+            else if (a.in_kind == 2) hipLaunchKernelGGL((head_fused_kernel<RT, 2, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((head_fused_kernel<RT, 0, true>), grid, block, 0, s, a);
+            return;
+        }
+    }
     if (a.in_kind == 1) hipLaunchKernelGGL((head_fused_kernel<RT, 1>), grid, block, 0, s, a);
     else if (a.in_kind == 2) hipLaunchKernelGGL((head_fused_kernel<RT, 2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((head_fused_kernel<RT, 0>), grid, block, 0, s, a);
