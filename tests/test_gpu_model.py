@@ -268,3 +268,33 @@ def test_bf16_engine_runs_configs_as_written_and_is_looser_than_fp16():
     assert model.engine(x.device, max_batch=B).dtype == "f16"                  # the default engine
     model.engine_dtype = "bf16"
     assert model.engine(x.device, max_batch=B).dtype == "bf16"
+
+
+def test_profile_hooks_account_for_every_launch():
+    """bmi_profile_read / bmi_profile_conv_families / bmi_profile_launches (what bench.py's roofline and tools/per_launch.py are
+    built on): the per-launch records add up to the per-kind and per-family totals, every conv launch carries its algorithmic
+    FLOPs and bytes, and the conv FLOPs add up to the engine's own MAC count."""
+    B, T = 6, 3
+    model = _product(ResNet18MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    eng = model.engine(torch.device(DEV), max_batch=B)
+    x = synthetic_images(B, seed=5).to(DEV)
+    S = eng.new_moments(B)
+    eng.profile(True)
+    eng.accumulate(x, S, 0, T, 1)
+    torch.cuda.synchronize()
+    kinds = eng.profile_read()
+    rows = eng.profile_launches()
+    eng.profile(False)
+    assert rows and sum(n for _, n in kinds.values()) == len(rows)
+    for kind, (ms, n) in kinds.items():
+        mine = [r for r in rows if r["kind"] == kind]
+        assert len(mine) == n and abs(sum(r["ms"] for r in mine) - ms) < 1e-6 * max(1.0, ms)
+    convs = [r for r in rows if r["family"] is not None]
+    assert convs and all(r["flops"] > 0 and r["bytes"] > 0 and r["ms"] > 0 for r in convs)
+    fam = eng.conv_families
+    assert sum(v["launches"] for v in fam.values()) == len(convs)
+    assert abs(sum(v["flops"] for v in fam.values()) - sum(r["flops"] for r in convs)) < 1.0
+    # prefix once per batch + T x suffix, 2 FLOPs per MAC (stem and heads are not conv-family launches)
+    want = 2.0 * B * (eng.prefix_macs - eng.stem_macs) + 2.0 * B * T * (eng.suffix_macs - eng.head_macs - eng.dense_macs)
+    assert abs(sum(r["flops"] for r in convs) - want) <= 1e-6 * want
+    assert {r["images"] for r in rows} <= {B, B * T}
