@@ -338,5 +338,10 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         if (big && !a.imap && (m_sel / 256) * (a.Cout / 128) >= 400 && a.ksize == 3) return launch_cfg<128, 256, 2, 2, false>(a, s);
         return launch_cfg<128, 128, 2, 2, true>(a, s);
     }
+    // 64-channel convs (layer1 of the ResNets: B images of the once-per-batch prefix, ~1000 small workgroups): single LDS buffer,
+    // 24 KB per workgroup -> six workgroups per CU instead of three: 59 / 65 / 55 / 64 -> 52 / 60 / 49 / 59 us for the four
+    // launches of the headline net.  (A 64-channel instantiation of conv3x3_patch measured the same 220 us: these launches sit
+    // on a ~20 us ramp + latency floor, not on their main loop.)  The dynamic-exit variants exist for the double-buffered form.
+    if (!a.imap) return launch_cfg<64, 128, 1, 4, false>(a, s);
     return launch_cfg<64, 128, 1, 4, true>(a, s);
 }
