@@ -439,3 +439,48 @@ class MCDEngine(CompiledGraph):
         names = [k[:-len("_kernel")] for k in _lib.CONV_FAMILY_KERNELS]
         return [dict(kind=_lib.PROFILE_NAMES.get(ki[i], str(ki[i])), family=names[fa[i]] if 0 <= fa[i] < len(names) else None, out=ou[i], images=im[i],
                      ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]
+
+
+class BatchesInFlight:
+    """`n` independent engines of one model (own workspace, own device copy of the weights) on `n` streams: consecutive batches
+    alternate between them, so the launch-bound once-per-batch prefix of batch k+1 (five ~50 us launches on B images) runs
+    beside the sample-folded suffix of batch k instead of in front of it.  Nothing changes inside a batch — every result is bit
+    for bit the single-stream one — only the order in which the GPU sees the launches of neighbouring batches.  Measured on
+    one MI355X (tools/experiments/two_batches.py), 1 -> 2 batches in flight: VGG-11 T=30 0.368 -> 0.297 ms per batch, ResNet-18
+    Masksembles T=8 2.52 -> 2.23 ms, ResNet-18 multi-exit at T=13 (one rank's share of eight) 3.77 -> 3.34 ms, at T=100 24.19 ->
+    23.76 ms.
+
+        pipe = BatchesInFlight(model, device, n=2, max_batch=250)
+        for x in batches:
+            out = pipe.submit(lambda eng: eng.predict(x, T, seed))     # asynchronous; device tensors
+        pipe.synchronize()
+    """
+
+    def __init__(self, model, device, n=2, **engine_kwargs):
+        if n < 1:
+            raise ValueError("n >= 1 batches in flight")
+        self.engines = [MCDEngine(model, device, **engine_kwargs) for _ in range(n)]
+        self.device = self.engines[0].device
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else [None]
+        self.k = 0
+
+    def slot(self):
+        return self.k % len(self.engines)
+
+    def submit(self, fn):
+        """Runs fn(engine) on the next slot's stream (after everything already queued on the caller's current stream, which is
+        where the inputs come from) and returns what it returns."""
+        i = self.slot()
+        self.k += 1
+        st = self.streams[i]
+        if st is None:
+            return fn(self.engines[i])
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            return fn(self.engines[i])
+
+    def synchronize(self):
+        for st in self.streams:
+            if st is not None:
+                st.synchronize()
+

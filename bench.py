@@ -9,7 +9,9 @@ One "step" = one batch through the whole hot path: deterministic prefix once, T 
 passes (folded into the GEMM M dimension in chunks), per-exit softmax moments, finalize to
 mean / variance.  Inputs are resident in HBM before the timed region.  With N GPUs the T samples
 are sharded across ranks (strong scaling, total work fixed) and the float64 moment buffers are
-combined with ONE all-reduce over RCCL per step.
+combined with ONE all-reduce over RCCL per step.  Consecutive steps alternate between two engines / streams (--in-flight 2,
+engine.BatchesInFlight): the launch-bound once-per-batch prefix of step k+1 runs beside the suffix of step k; every step still
+does all of its own work inside the timed region and its results are bit for bit the one-stream ones.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
@@ -89,6 +91,9 @@ def parse():
                     help="dry run of the N>1 code path on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-T", type=int, default=10, help="MC passes of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-1t-images", type=int, default=16, help="images of the 1-thread CPU-baseline sample (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight: consecutive steps alternate between this many engines / streams (engine.BatchesInFlight), so "
+                         "the once-per-batch prefix of step k+1 runs beside the suffix of step k; 1 = one stream")
     ap.add_argument("--dump-mean", default="", help="rank 0 writes the final predictive mean [E,B,C] float64 to this .npy (tests)")
     return ap.parse_args()
 
@@ -260,17 +265,26 @@ def main():
     np.random.seed(0)
     model = synthetic_weights_(_load(wl[0])(**kw), 0).to(dev).eval()
     B, T = a.batch or wl[3], a.T or wl[4]
-    eng = model.engine(dev, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
+    from bayesnn_fpga_amd.engine import BatchesInFlight
+    if a.in_flight < 1:
+        raise SystemExit("--in-flight >= 1")
+    pipe = BatchesInFlight(model, dev, n=a.in_flight, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
+    eng = pipe.engines[0]
     x = synthetic_images(B, seed=1234).to(dev)
     t_lo, t_hi = shard_range(T, rank, world)
-    S = eng.new_moments(B)
+    Ss = [e.new_moments(B) for e in pipe.engines]
 
-    def step():
+    def one_batch(e, S):
         S.zero_()
         # the library's N>1 path (bayesnn_fpga_amd/sharding.py): this rank's t-shard into S, then ONE all-reduce (RCCL
         # over xGMI) of the [3,E,B,C] float64 buffer; a single rank skips the collective
-        accumulate_sharded(lambda buf, t0, n: eng.accumulate(x, buf, t0, n, a.seed), S, T)
-        return eng.finalize(S, T)
+        accumulate_sharded(lambda buf, t0, n: e.accumulate(x, buf, t0, n, a.seed), S, T)
+        return e.finalize(S, T)
+
+    def step():
+        # one step = one batch through the whole path; consecutive steps alternate between the engines / streams of `pipe`
+        i = pipe.slot()
+        return pipe.submit(lambda e: one_batch(e, Ss[i]))
 
     def fence():
         if dist is not None:
@@ -292,7 +306,7 @@ def main():
 
     # ---- per-kernel profile (rank 0's share of the samples), outside the timed region ----------
     eng.profile(True)
-    step()
+    one_batch(eng, Ss[0])
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile(False)
@@ -323,7 +337,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
-                       "workspace_gb": round(eng.workspace_bytes / 2**30, 2),
+                       "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight,
                        "sharding": f"T over {world} rank(s), one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
             "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),

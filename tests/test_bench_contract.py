@@ -70,3 +70,21 @@ def test_bench_rejects_mismatched_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_batches_in_flight_do_not_change_results(tmp_path):
+    """bench.py runs consecutive steps on two engines / streams (engine.BatchesInFlight: the prefix of step k+1 beside the suffix
+    of step k).  Nothing inside a batch changes: the predictive mean of the last step is bit for bit the one-stream one."""
+    import numpy as np
+    common = ["--steps", "3", "--warmup", "1", "--T", "6", "--no-cpu-baseline"]
+    fs = []
+    for n in (1, 2, 3):
+        f = str(tmp_path / f"m{n}.npy")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--in-flight", str(n), "--dump-mean", f],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][0])
+        assert d["config"]["batches_in_flight"] == n and d["steps"] == 3
+        fs.append(np.load(f))
+    assert np.array_equal(fs[0], fs[1]) and np.array_equal(fs[0], fs[2])
