@@ -462,20 +462,27 @@ class BatchesInFlight:
         self.engines = [MCDEngine(model, device, **engine_kwargs) for _ in range(n)]
         self.device = self.engines[0].device
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else [None]
+        self.last_stream = None
         self.k = 0
 
     def slot(self):
         return self.k % len(self.engines)
 
-    def submit(self, fn):
+    def submit(self, fn, inputs=()):
         """Runs fn(engine) on the next slot's stream (after everything already queued on the caller's current stream, which is
-        where the inputs come from) and returns what it returns."""
+        where the inputs come from) and returns what it returns.  `inputs`: device tensors fn reads that the caller may drop
+        before the batch has run (they are recorded on the stream so the caching allocator does not hand their memory out
+        early).  The results are produced on `self.last_stream`: wait for it (stream.synchronize() / wait_stream) before
+        reading them from another stream."""
         i = self.slot()
         self.k += 1
         st = self.streams[i]
+        self.last_stream = st
         if st is None:
             return fn(self.engines[i])
         st.wait_stream(torch.cuda.current_stream(self.device))
+        for t in inputs:
+            t.record_stream(st)
         with torch.cuda.stream(st):
             return fn(self.engines[i])
 

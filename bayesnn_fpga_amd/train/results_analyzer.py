@@ -67,6 +67,41 @@ class FullAnalysis:
         self.model.advance(self.mc_passes)
         return {k: v.cpu().numpy() for k, v in r.items()}
 
+    def _predict_async(self, b_x):
+        """The same call queued on one of two engines / streams (engine.BatchesInFlight): returns the DEVICE tensors; the caller
+        converts them after it has queued the next batch, so that batch's launch-bound prefix and this batch's host-side
+        collation both overlap the GPU work.  Results are bit for bit those of _predict."""
+        from ..engine import BatchesInFlight
+        if getattr(self, "_pipe", None) is None or self._pipe.device != b_x.device or self._pipe.engines[0].max_batch < b_x.shape[0]:
+            self._pipe = BatchesInFlight(self.model, b_x.device, n=2, max_batch=b_x.shape[0])
+        ml = self.model.mask_layers()
+        T, seed, cnt0 = self.mc_passes, self.seed + self._batch_index, (ml[0].cnt if ml else 0)
+        r = self._pipe.submit(lambda eng: eng.predict(b_x, T, seed=seed, t_begin=0, cnt0=cnt0), inputs=(b_x,))
+        self.model.advance(self.mc_passes)
+        return r, self._pipe.last_stream
+
+    def _predict_deferred(self, b_x):
+        """Queues the batch and returns a zero-argument function that waits for it and gives _predict's numpy dict."""
+        if type(self)._predict is not FullAnalysis._predict:      # a subclass with its own per-batch predictor (tests inject the oracle)
+            r = self._predict(b_x)
+            return lambda: r
+        r_dev, st = self._predict_async(b_x)
+
+        def get():
+            if st is not None:
+                st.synchronize()                       # this batch is done (the next one is already queued behind it)
+            return {k: v.cpu().numpy() for k, v in r_dev.items()}
+        return get
+
+    def _outputs_from(self, r):
+        self.last_var = r["var"]
+        logit_mean, prob_mean = r["logit_mean"], r["mean"]
+        output = [torch.from_numpy(a) for a in logit_mean]
+        output_sm = [torch.from_numpy(a) for a in prob_mean]
+        ens_out = [torch.from_numpy(a) for a in exit_ensembles(logit_mean)]
+        ens_sm = [torch.from_numpy(a) for a in exit_ensembles(prob_mean)]
+        return output, output_sm, prob_mean, ens_out, ens_sm
+
     def _get_output(self, b_x):
         r = self._predict(b_x)
         self.last_var = r["var"]
@@ -104,10 +139,21 @@ class FullAnalysis:
         labels = np.zeros((n, C))
         trackers = [[(set(), set(), {}, {}) for _ in range(n_exits)] for _ in range(2)]
         off = 0
-        for self._batch_index, batch in enumerate(loader):
-            b_x = batch[0].to(self.device)
-            b_y = batch[1].cpu().numpy().astype(np.int64)
-            output, output_sm, output_sm_np, ens_out, ens_sm = self._get_output(b_x)
+
+        def queued(it):
+            """(result getter, labels) of each batch, one batch behind the one being queued (two batches in flight)."""
+            pending = None
+            for self._batch_index, batch in enumerate(it):
+                b_x = batch[0].to(self.device)
+                nxt = (self._predict_deferred(b_x), batch[1].cpu().numpy().astype(np.int64))
+                if pending is not None:
+                    yield pending
+                pending = nxt
+            if pending is not None:
+                yield pending
+
+        for get, b_y in queued(loader):
+            output, output_sm, output_sm_np, ens_out, ens_sm = self._outputs_from(get())
             B = len(b_y)
             for e in range(n_exits):
                 self._track(output[e].numpy(), output_sm[e].numpy(), b_y, off, *trackers[0][e])
