@@ -26,6 +26,9 @@ SHAPES = [  # cin, cout, H, k, s, p, images
     # BasicBlock tails (residual + ReLU + p = 0.25 elementwise site): the lite epilogue DMAs the residual into the LDS image the
     # results are written back to in place — patch S2, conv3x3_pw S3 / S4, wide 1x1
     (128, 128, 16, 3, 1, 1, 259, 1), (256, 256, 8, 3, 1, 1, 1027, 1), (512, 512, 4, 3, 1, 1, 4099, 1), (256, 512, 8, 1, 1, 0, 3001, 1),
+    # conv1x1_stream (single-buffered K-steps refilled behind a barrier, two workgroups per CU): Bottleneck tail and a plain
+    # Cout = 128 reduce conv
+    (128, 512, 16, 1, 1, 0, 1203, 1), (512, 128, 16, 1, 1, 0, 777),
 ]
 
 
