@@ -317,10 +317,10 @@ __device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px
 // Which epilogue finishes a launch (launch-uniform; a KERNEL TEMPLATE PARAMETER, see below).
 #define BMI_EPI_GENERAL 0   // anything: two fp32 rounds through LDS (epilogue_coalesced)
 #define BMI_EPI_PLAIN 1     // BN + ReLU (epilogue_plain)
-#define BMI_EPI_LITE 2      // BN + residual + ReLU + elementwise 2-bit site, one fp16 trip through LDS (epilogue_lite)
+#define BMI_EPI_LITE 2      // BN + residual + ReLU + elementwise 2-bit or Masksembles site, one fp16 trip through LDS (epilogue_lite)
 __host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_shape) {
     if (conv_epilogue_is_plain(a)) return BMI_EPI_PLAIN;
-    const bool site_ok = a.site.kind == BMI_SITE_NONE ||
+    const bool site_ok = a.site.kind == BMI_SITE_NONE || a.site.kind == BMI_SITE_MASKSEMBLE ||
                          (a.site.kind == BMI_SITE_ELEMENTWISE && a.site.log2_bits == 1 && !a.site.drop_all);
     if (mfma_shape == 16 && site_ok && !a.site_inner && !a.bias_post) return BMI_EPI_LITE;
     return BMI_EPI_GENERAL;
@@ -350,6 +350,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
     const int l16 = lane & 15, q4 = lane >> 4;
     const int HoWo = a.Ho * a.Wo;
     const bool masked = a.site.kind == BMI_SITE_ELEMENTWISE;
+    const bool msk = a.site.kind == BMI_SITE_MASKSEMBLE;      // Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c4 = ch0 + wc * 64 + 16 * i + 4 * q4;
@@ -409,10 +410,18 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
 #pragma unroll
                 for (int wd = 0; wd < 4; ++wd) w[wd] = (uint32_t)__shfl((int)mine[j >> 2].w[wd], src, 64);
             }
+            const float* mrow = nullptr;
+            if (msk) {
+                int n, rem;
+                pixmap(wp * (32 * TJ) + 16 * j + l16, n, rem);
+                mrow = a.site.masks + (size_t)((a.site.cnt0 + a.t0 + n / a.B) % a.site.num_masks) * a.Cout + ch0 + wc * 64 + 4 * q4;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int p = wp * (32 * TJ) + 16 * j + l16, cq = wc * 8 + 2 * i + (q4 >> 1);
                 const uint32_t fields = w[i] >> (8 * q4);
+                f32x4_e mk = {1.f, 1.f, 1.f, 1.f};
+                if (msk) mk = *(const f32x4_e*)(mrow + 16 * i);
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -420,6 +429,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
                     if (a.res) v += a16_to_f32<BF>(r4[jj][i][e]);
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (masked) v = ((fields >> (2 * e)) & 3u) >= a.site.thresh ? v * a.site.scale : 0.f;
+                    if (msk) v = mk[e] == 0.f ? 0.f : v * mk[e];
                     asm("" : "+v"(v));   // keep the fp32 product: fused into v_fma_mixlo_f16 it is rounded once instead of twice,
                                          // and 1 element in 10^6 ends one fp16 ulp away from what epilogue_coalesced stores
                     o[e] = a16_from_f32<BF>(v);

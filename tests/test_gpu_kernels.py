@@ -651,7 +651,7 @@ def test_conv3x3_pw_kernel(name, n, general, dt):
 
 @pytest.mark.parametrize("name,n,k1,dt", [("S2", 37, False, "f16"), ("S3", 300, False, "f16"), ("S4", 1100, False, "f16"), ("S3", 900, True, "f16"),
                                           ("S2", 9, False, "bf16"), ("S4", 1050, False, "bf16")])
-@pytest.mark.parametrize("use_res,use_site", [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("use_res,use_site", [(1, 0), (0, 1), (1, 1), (1, 2), (0, 2)])
 def test_lite_epilogue_equals_general_bit_for_bit(name, n, k1, dt, use_res, use_site):
     """epilogue_lite (BN on the accumulator registers, residual DMA'd into the LDS output image, results written back in
     place) against epilogue_coalesced (fp32 rounds through LDS) on BasicBlock tails: conv3x3_patch (S2), conv3x3_pw (S3 /
@@ -666,14 +666,16 @@ def test_lite_epilogue_equals_general_bit_for_bit(name, n, k1, dt, use_res, use_
     w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(tdt).to(DEV)
     scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
     res = torch.randn(n, H, H, cout, generator=g).to(tdt).to(DEV) if use_res else None
-    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=1, p=0.25) if use_site else None
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=1, p=0.25) if use_site == 1 else None
+    if use_site == 2:      # Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M, t = image // batch
+        site = dict(kind=_lib.SITE_MASKSEMBLE, site_id=1, masks=(torch.rand(4, cout, generator=g) < 0.6).float().numpy() * 1.5)
     outs = []
     if dt == "bf16":
         _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
     try:
         for lite in (0, 1):
             _lib.set_option("epilogue_lite", lite)
-            outs.append(gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=7, t0=3, seed=9, out_dtype=tdt))
+            outs.append(gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=7, t0=3, seed=9, cnt0=2, out_dtype=tdt))
     finally:
         _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
         _lib.set_option("epilogue_lite", 1)
