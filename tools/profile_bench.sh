@@ -7,7 +7,9 @@ W=${1:-resnet18_me}; TAG=${2:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline"
+# one batch at a time under the profiler: with two batches in flight (bench.py's default) the kernels of neighbouring batches share
+# the GPU, and a kernel's trace duration / PMC window would include its neighbour's work
+ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --in-flight 1"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_write.log 2>&1
