@@ -6,10 +6,10 @@
 // Measured (tools/per_launch.py, ResNet-50 multi-exit, 16000 image-samples): the 128 -> 512 tails run at 3.5-3.7 TB/s of
 // algorithmic bytes, the 256 -> 1024 ones at 3.0, while a plain `out = a + b` over the same three tensors streams 6.1 TB/s
 // (tools/experiments/hbm_streams.py).  Here:
-//   tile        = 128 channels x 256 pixels, 4 waves (each 64 ch x 128 px, v_mfma_f32_16x16x32), 256 threads;
-//   LDS         = 64 KB: one single-buffered [weights 16 KB | pixels 32 KB] K-step of 64 channels, then the epilogue's
-//                 output image -> TWO workgroups per CU, 256 VGPRs each: while one waits for its operands or its residual,
-//                 the other computes or stores.  No intra-workgroup pipelining at all: the overlap is between workgroups;
+//   tile        = 128 channels x 128 pixels (first version: 256), 4 waves (each 64 ch x 64 px, v_mfma_f32_16x16x32), 256 threads;
+//   LDS         = 32 KB: one single-buffered [weights 16 KB | pixels 16 KB] K-step of 64 channels, then the epilogue's
+//                 output image -> THREE or FOUR workgroups per CU: while one waits for its operands or its residual, the
+//                 others compute or store.  No intra-workgroup pipelining at all: the overlap is between workgroups;
 //   operands    = LDS-DMA (global_load_lds), 128-byte rows with the XOR swizzle of conv_igemm_wide on the source side;
 //   epilogue    = conv_epilogue.h (plain / lite / general), the same code and the same bits as every other conv kernel.
 // Taken for ksize 1, pad 0, stride 1 or 2, Cin % 64 == 0, Cin <= 512, Cout % 128 == 0 (conv_takes_stream_kernel) when the launch
@@ -27,11 +27,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
                                      (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
 
 #define SBC 128
-#define SBP 256
 
-template <int EPI, bool BF>
-__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[BMI_EPILOGUE_LDS_BYTES];
+// TJ = 2 (default): 128-pixel tile, 32 KB of LDS, three (residual launches: 164 VGPRs) or four workgroups per CU.
+// TJ = 4 ("conv_stream" = 3, the first version): 256-pixel tile, 64 KB, two workgroups per CU.  Same-process A/B at 16000
+// image-samples, tails 128 -> 512 / 256 -> 1024 / 512 -> 2048: 2467 / 1476 / 1027 us with TJ = 4, 2245 / 1370 / 963 us with TJ = 2.
+template <int EPI, bool BF, int TJ = 4>
+__global__ __launch_bounds__(256, TJ == 4 ? 2 : 3) void conv1x1_stream_kernel(ConvArgs a) {
+    constexpr int SBP = 64 * TJ;
+    __shared__ __attribute__((aligned(16))) char smem[TJ == 4 ? BMI_EPILOGUE_LDS_BYTES : BMI_EPILOGUE_LDS_BYTES / 2];
     constexpr int XBASE = SBC * 128;   // pixel tile behind the weight tile
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -49,13 +52,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
     const int rowt = tid >> 3;
     const int srcchunk = ((tid & 7) ^ ((rowt >> 1) & 7)) * 8;   // (32*i >> 1) & 7 == 0: the same for all i
     const _Float16* wsrc[4];
-    const _Float16* xsrc[8];
+    const _Float16* xsrc[2 * TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) wsrc[i] = a.wgt + (size_t)(ch0 + 32 * i + rowt) * a.Cin + srcchunk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) GLDS16(wsrc[i], smem + (i * 256 + wave * 64) * 16);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 2 * TJ; ++i) {
         const int m = pix0 + 32 * i + rowt;
         const int mm = m < a.M ? m : 0;               // rows beyond the tensor read pixel 0: computed, never stored
         const int n = mm / HoWo;
@@ -65,19 +68,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
         xsrc[i] = a.in + ((size_t)(n % a.in_mod) * a.H * a.W + (size_t)(oy * a.stride) * a.W + ox * a.stride) * a.Cin + srcchunk;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) GLDS16(xsrc[i], smem + XBASE + (i * 256 + wave * 64) * 16);
+    for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i], smem + XBASE + (i * 256 + wave * 64) * 16);
 
     typedef float accv __attribute__((ext_vector_type(4)));
-    accv acc[4][8];
+    accv acc[4][2 * TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 2 * TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
     const int a_off = (wc * 64 + r) * 128;
-    const int b_off = XBASE + (wp * 128 + r) * 128;
+    const int b_off = XBASE + (wp * (32 * TJ) + r) * 128;
     const int sw_r = (r >> 1) & 7;
     const int nK = a.Cin / 64;
     for (int ks = 0; ks < nK; ++ks) {
@@ -87,15 +90,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int coff = ((4 * sub + kq) ^ sw_r) << 4;
-            half8 af[4], bf[8];
+            half8 af[4], bf[2 * TJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(smem + a_off + i * 16 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bf[j] = *(const half8*)(smem + b_off + j * 16 * 128 + coff);
+            for (int j = 0; j < 2 * TJ; ++j) bf[j] = *(const half8*)(smem + b_off + j * 16 * 128 + coff);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < 2 * TJ; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
         }
         if (ks + 1 < nK) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) GLDS16(wsrc[i] + koff, smem + (i * 256 + wave * 64) * 16);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) GLDS16(xsrc[i] + koff, smem + XBASE + (i * 256 + wave * 64) * 16);
+            for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i] + koff, smem + XBASE + (i * 256 + wave * 64) * 16);
         }
     }
 
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a) {
         off = (size_t)(pix0 + p) * a.Cout;
         return pix0 + p < a.M;
     };
-    epilogue_coalesced<4, EPI, 16, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
+    epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
 }
 
 bool conv_takes_stream_kernel(int ksize, int stride, int pad, int cin, int cout) {
@@ -133,6 +136,7 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
     if (a_in.N <= 0 || a_in.M <= 0 || a_in.in_mod <= 0 || a_in.B <= 0 || (a_in.res && a_in.res_mod <= 0)) return BMI_ERR_INVALID;
     ConvArgs a = a_in;
     a.xcd_split = xcd_split_for(a.Cout / SBC, (size_t)a.Cout * a.Cin * 2);
+    const int SBP = opt_conv_stream() == 3 ? 256 : 128;   // 3: the 256-pixel tile (A/B)
     const long tiles = (((long)a.M + SBP - 1) / SBP) * (a.Cout / SBC);
     if (tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     // the minimum-grid rule of the other wide-tile kernels (on the engine's full-chunk image count, never this launch's)
@@ -156,7 +160,10 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
     const dim3 grid((unsigned)tiles), block(256);
 #define STREAM_LAUNCH(BF_)                                                                                                      \
     {                                                                                                                           \
-        if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_>), grid, block, 0, s, a);        \
+        if (SBP == 128) {                                                                                                       \
+            if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_, 2>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_, 2>), grid, block, 0, s, a);                       \
+        } else if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_>), grid, block, 0, s, a);                              \
     }
     if (a.bf16) STREAM_LAUNCH(true) else STREAM_LAUNCH(false)

@@ -195,7 +195,7 @@ int bmi_set_option(const char* name, int32_t value) {
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_stream") == 0) {
-        if (value < 0 || value > 2) return BMI_ERR_INVALID;
+        if (value < 0 || value > 3) return BMI_ERR_INVALID;
         opt_conv_stream() = value;
         return BMI_OK;
     }
