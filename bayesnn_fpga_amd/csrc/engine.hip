@@ -551,13 +551,14 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     for (OpInfo& op : h->prefix) {
         op.nsplit = 0;
         const bmi_op_desc& d = op.d;
-        if (d.kind != BMI_OP_CONV || !opt_splitk() || d.ksize != 3 || d.stride != 1 || d.residual >= 0 || d.in2 >= 0 || d.site.kind != BMI_SITE_NONE ||
+        if (d.kind != BMI_OP_CONV || !opt_splitk() || d.ksize != 3 || d.residual >= 0 || d.in2 >= 0 || d.site.kind != BMI_SITE_NONE ||
             op.has_pair || op.bits_tensor >= 0 || op.cout % 128 != 0)
             continue;
         const TensorInfo& ti = h->tensors[d.in];
         const size_t M = B * op.ho * op.wo;
         const size_t tiles = (M + 127) / 128 * (op.cout / 128);
-        if (ti.c % 64 != 0 || ti.c < 256 || tiles > 64) continue;
+        if (ti.c % 64 != 0 || ti.c < 256 || tiles > 64) continue;      // stride 1 or 2 (VGG-19's 256 -> 512 exit convs: 37 -> 22 us); at
+                                                                       // Cin = 128 (18 K-steps) the split measured slower: 23 -> 28 us
         op.nsplit = 9;
         sk_bytes = std::max(sk_bytes, align_up((size_t)op.nsplit * M * op.cout * sizeof(float), 256));
     }
