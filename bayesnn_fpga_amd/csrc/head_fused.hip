@@ -84,6 +84,11 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
                                                              : f32x4_h{0.f, 0.f, 0.f, 0.f};
             if constexpr (STAGED) { HEAD_FETCH_W(0, 0) } else { HEAD_LOAD_W(0) }
             // ---- phase A: pool 8 samples per wave into LDS ----
+            // deterministic input (in_mod == B: exit-only dropout, the image's features are the same for every sample): pooled
+            // once per wave and chunk, then only the site differs per sample (VGG-19 multi-exit: 0.16 -> 0.0x ms per head)
+            const bool det = a.in_mod == a.B;
+            float pooled[8];
+            bool have = false;
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = jj * 4 + wave;                  // interleaved: a launch with few samples (T = 8) still uses all waves
                 const int tl = g * 32 + j;
@@ -93,6 +98,10 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
                     if (tl < a.tc) {
                         const int n = tl * a.B + b;
                         const size_t row0 = (size_t)(n % a.in_mod) * a.HW * K + k0 + c8 * 8;
+                        if (det && have) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = pooled[e];
+                        } else {
 #pragma unroll 8
                         for (int p = 0; p < a.HW; ++p) {
                             if constexpr (KIND == 1) {
@@ -106,10 +115,12 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
                                 for (int e = 0; e < 8; ++e) v[e] += fmaxf(a16_to_f32<KIND == 2>(x[e]), 0.f);   // F.relu before the pool
                             }
                         }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { v[e] *= inv_hw; pooled[e] = v[e]; }
+                        have = true;
+                        }
                         const int t = a.t0 + tl;
                         const int kk = k0 + c8 * 8;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= inv_hw;
                         if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
                             // [B, K] tensor: element = b*K + k (a per-(image, channel) draw is the same thing here)
                             const uint32_t keep = site_keep8(a.site, (uint64_t)b * K + kk, (uint32_t)t);
