@@ -32,18 +32,26 @@ typedef _Float16 half8_h __attribute__((ext_vector_type(8)));
 #define HEAD_FEAT_BYTES (32 * HEAD_KC * 4)
 
 // KIND: 0 fp16, 1 fp32, 2 bf16 input tensor
-// STAGED (RT >= 3, K % 128 == 0): the classifier weights go through LDS.  In the direct form every lane streams its own 2 KB
-// weight row (one float4 per load: 64 cache lines per wave instruction, and the 4 waves x 2 class tiles in flight thrash the
-// 32 KB L1): with 4 class tiles (C = 100) a workgroup pulls 256 KB that way and the head took 54 us where the 10-class one takes
-// 16.  Staged, a wave fetches [64 classes][32 k] blocks of its K quarter with 8 lanes per 128-byte row segment into its own
-// 9 KB of LDS (rows padded to 36 floats; the region aliases `part`, which is only used after the K loop; wave-private: the LDS
-// operations of a wave complete in order, no barrier) one block ahead of the MFMAs, and lane half h reads k0 + 16h .. + 15.
-template <int RT, int KIND, bool STAGED = false>
-__global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
-    static_assert(!STAGED || RT >= 3, "the staging buffers alias `part` (16 KB x RT): 4 x 9 KB need RT >= 3");
-    __shared__ __attribute__((aligned(16))) char smem[HEAD_FEAT_BYTES + 4 * RT * 16 * 64 * 4];
+// CSPLIT (RT >= 3 class tiles, K % 32 == 0; round 2): the four waves split the CLASSES instead of K — wave w owns class tile w
+// for the whole K — and the classifier weights go through LDS.  Why: with the K split every wave holds partial sums of all RT
+// tiles (64 accumulators at RT = 4) and they meet in a [4][RT][16][64] fp32 LDS array (64 KB) next to the 64 KB feature chunk:
+// 128 KB of LDS and 231 + 64 registers = ONE workgroup of four waves per CU, and ablation builds showed where that hurts: of
+// the 330 us of a 100-class head at T = 100 the pooling pass alone was 200 (four waves do not keep enough loads in flight).
+// Here a wave keeps 16 accumulators, nothing is exchanged (the logits tile goes straight to the [class][sample] array the
+// softmax reads), the feature chunk is 256 deep (32 KB) and a wave stages its [32 classes][32 k] weight blocks in 4.5 KB of
+// its own (8 lanes per 128-byte row segment instead of one 2 KB row per lane): 66 KB of LDS, two workgroups per CU.
+template <int RT, int KIND, bool CSPLIT = false>
+__global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArgs a) {
+    static_assert(!CSPLIT || (RT >= 3 && RT <= 4), "class split: one wave per class tile");
+    constexpr int KC = CSPLIT ? 256 : HEAD_KC;                 // K chunk held in LDS (floats per sample)
+    constexpr int FEAT_BYTES = 32 * KC * 4;
+    // behind the features: K split -> the partial sums [4 waves][RT][16 regs][64 lanes]; class split -> 4 wave-private weight
+    // blocks [32][36] during the K loop, then (both) the [class][33] softmax / logit arrays
+    constexpr int PART_BYTES = CSPLIT ? 2 * 32 * RT * 33 * 4 : 4 * RT * 16 * 64 * 4;
+    static_assert(!CSPLIT || PART_BYTES >= 4 * 32 * 36 * 4, "weight blocks alias the softmax arrays");
+    __shared__ __attribute__((aligned(16))) char smem[FEAT_BYTES + PART_BYTES];
     float* const feat = (float*)smem;
-    float* const part = (float*)(smem + HEAD_FEAT_BYTES);     // [4 waves][RT][16 regs][64 lanes]
+    float* const part = (float*)(smem + FEAT_BYTES);
 
     const int b = a.imap ? a.imap[blockIdx.x] : (int)blockIdx.x;    // dynamic early exit: only the still-active images
     const int g = blockIdx.y;                                  // this workgroup's group of 32 samples
@@ -59,8 +67,11 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-        for (int k0 = 0; k0 < K; k0 += HEAD_KC) {
-            const int kc = min(HEAD_KC, K - k0);               // multiple of 32
+        f32x16_h accw[2];                                      // CSPLIT: this wave's class tile, two interleaved chains
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accw[0][e] = 0.f; accw[1][e] = 0.f; }
+        for (int k0 = 0; k0 < K; k0 += KC) {
+            const int kc = min(KC, K - k0);                    // multiple of 32
             const int swz = (kc & 63) == 0 ? 15 : 7;          // the XOR must stay inside the row's kc / 4 chunks
             // this wave's slice of the classifier weights, two class tiles (64 classes) at a time: the first pair is requested
             // BEFORE the pooling pass (its L2 latency hides under phase A), 16 float4 per class tile and lane
@@ -68,31 +79,31 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
             const int koff = wave * (kc >> 2) + hh * kq;
             const float* wp = a.w + (size_t)r * K + k0 + koff;
             constexpr int NPAIR = (RT + 1) / 2, W2 = RT < 2 ? RT : 2;
-            f32x4_h wpre[STAGED ? 1 : W2][STAGED ? 1 : 16];
-            f32x4_h wst[STAGED ? 8 : 1];                       // STAGED: the next [64 classes][32 k] block, 8 float4 per lane
-            const int kw0 = wave * (kc >> 2);                  // this wave's K quarter inside the chunk
-#define HEAD_FETCH_W(PS, CK)                                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                \
+            f32x4_h wpre[CSPLIT ? 1 : W2][CSPLIT ? 1 : 16];
+            f32x4_h wst[CSPLIT ? 4 : 1];                       // CSPLIT: the next [32 classes][32 k] block, 4 float4 per lane
+#define HEAD_FETCH_W(CK)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                                \
         const int f_ = lane + 64 * i_, row_ = f_ >> 3, kq_ = f_ & 7;                                                  \
-        wst[i_] = (64 * (PS) + row_ < 32 * RT) ? *(const f32x4_h*)(a.w + (size_t)(64 * (PS) + row_) * K + k0 + kw0 + 32 * (CK) + 4 * kq_) \
-                                               : f32x4_h{0.f, 0.f, 0.f, 0.f};                                         \
+        wst[i_] = *(const f32x4_h*)(a.w + (size_t)(32 * wave + row_) * K + k0 + 32 * (CK) + 4 * kq_);                 \
     }
 #define HEAD_LOAD_W(PS)                                                                                              \
     _Pragma("unroll") for (int ii = 0; ii < W2; ++ii)                                                                 \
         _Pragma("unroll") for (int q = 0; q < 16; ++q)                                                                \
             wpre[ii][q] = (2 * (PS) + ii < RT && 4 * q < kq) ? *(const f32x4_h*)(wp + (size_t)(32 * (2 * (PS) + ii)) * K + 4 * q) \
                                                              : f32x4_h{0.f, 0.f, 0.f, 0.f};
-            if constexpr (STAGED) { HEAD_FETCH_W(0, 0) } else { HEAD_LOAD_W(0) }
+            if constexpr (CSPLIT) { if (wave < RT) { HEAD_FETCH_W(0) } } else { HEAD_LOAD_W(0) }
             // ---- phase A: pool 8 samples per wave into LDS ----
             // deterministic input (in_mod == B: exit-only dropout, the image's features are the same for every sample): pooled
             // once per wave and chunk, then only the site differs per sample (VGG-19 multi-exit: 0.16 -> 0.0x ms per head)
             const bool det = a.in_mod == a.B;
             float pooled[8];
             bool have = false;
-            for (int jj = 0; jj < 8; ++jj) {
-                const int j = jj * 4 + wave;                  // interleaved: a launch with few samples (T = 8) still uses all waves
+            for (int jj = 0; jj < (CSPLIT ? 4 : 8); ++jj) {
+                // interleaved: a launch with few samples (T = 8) still uses all waves.  CSPLIT (256-deep chunk = 32 lanes of 8
+                // channels): the two lane halves pool two samples at once
+                const int j = CSPLIT ? jj * 8 + wave * 2 + (lane >> 5) : jj * 4 + wave;
                 const int tl = g * 32 + j;
-                const int c8 = lane;
+                const int c8 = CSPLIT ? (lane & 31) : lane;
                 if (c8 * 8 < kc) {
                     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     if (tl < a.tc) {
@@ -139,35 +150,28 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
             }
             __syncthreads();
             // ---- phase B: this wave's quarter of the chunk's K, lane half hh takes half of that ----
-            if constexpr (STAGED) {
-                const float* fr = feat + r * kc;
-                float* const Wt = part + wave * (64 * 36);     // wave-private [64 classes][36]
-                const int nck = (kc >> 2) >> 5;                // 32-deep blocks in this wave's quarter
-#pragma unroll
-                for (int ps = 0; ps < NPAIR; ++ps) {
+            if constexpr (CSPLIT) {
+                if (wave < RT) {                               // (wave-uniform)
+                    const float* fr = feat + r * kc;
+                    float* const Wt = part + wave * (32 * 36); // wave-private [32 classes][36]; the LDS operations of a wave are in order
+                    const int nck = kc >> 5;
                     for (int ck = 0; ck < nck; ++ck) {
 #pragma unroll
-                        for (int i_ = 0; i_ < 8; ++i_) {
+                        for (int i_ = 0; i_ < 4; ++i_) {
                             const int f_ = lane + 64 * i_;
                             *(f32x4_h*)(Wt + (f_ >> 3) * 36 + 4 * (f_ & 7)) = wst[i_];
                         }
-                        // the block after this one (next k block, or the first of the next class-tile pair)
-                        if (ck + 1 < nck) { HEAD_FETCH_W(ps, ck + 1) }
-                        else if (ps + 1 < NPAIR) { HEAD_FETCH_W(ps + 1, 0) }
-                        f32x4_h aq[W2][4], bq[4];
+                        if (ck + 1 < nck) { HEAD_FETCH_W(ck + 1) }
+                        f32x4_h aq[4], bq[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            bq[q] = *(const f32x4_h*)(fr + ((((kw0 + 32 * ck + 16 * hh + 4 * q) >> 2) ^ (r & swz)) << 2));
-#pragma unroll
-                            for (int ii = 0; ii < W2; ++ii) aq[ii][q] = *(const f32x4_h*)(Wt + (32 * ii + r) * 36 + 16 * hh + 4 * q);
+                            bq[q] = *(const f32x4_h*)(fr + ((((32 * ck + 16 * hh + 4 * q) >> 2) ^ (r & swz)) << 2));
+                            aq[q] = *(const f32x4_h*)(Wt + r * 36 + 16 * hh + 4 * q);
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                                for (int ii = 0; ii < W2; ++ii)
-                                    if (2 * ps + ii < RT) acc[2 * ps + ii] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ii][q][e], bq[q][e], acc[2 * ps + ii], 0, 0, 0);
+                            for (int e = 0; e < 4; ++e) accw[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q][e], bq[q][e], accw[e & 1], 0, 0, 0);
                     }
                 }
             } else {
@@ -195,25 +199,41 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadArgs a) {
 #undef HEAD_FETCH_W
             __syncthreads();                                   // feat is free for the next chunk
         }
+        float* const pb_p = part;                              // [class][33]: softmax of the group's 32 samples (aliases `part`:
+        float* const pb_l = part + 32 * RT * 33;               //  wave 0 has read all of it before it writes) and their logits
+        if constexpr (CSPLIT) {
+            // every wave's raw logits tile -> pb_l (the weight blocks it aliases are dead: barrier first)
+            __syncthreads();
+            if (wave < RT) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pb_l[(32 * wave + (e & 3) + 8 * (e >> 2) + 4 * hh) * 33 + r] = accw[0][e] + accw[1][e];
+            }
+        } else {
         // ---- the four K-quarters meet in LDS ----
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) part[((wave * RT + i) * 16 + e) * 64 + lane] = acc[i][e];
+        }
         __syncthreads();
-        float* const pb_p = part;                              // [class][33]: softmax of the group's 32 samples (aliases `part`:
-        float* const pb_l = part + 32 * RT * 33;               //  wave 0 has read all of it before it writes) and their logits
         if (wave == 0) {
             const int tl = g * 32 + r;
             const uint32_t t = (uint32_t)(a.t0 + tl);
             // (three plain passes: with the partial sums, the bias / logits-site code and the running max in ONE loop body
             //  hipcc gave up unrolling it for 4 class tiles and put the accumulators in scratch)
+            if constexpr (CSPLIT) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][e] = pb_l[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh) * 33 + r];
+            } else {
 #pragma unroll
             for (int w = 1; w < 4; ++w)
 #pragma unroll
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][e] += part[((w * RT + i) * 16 + e) * 64 + lane];
+            }
             const bool drop_logits = a.site_logits.kind == BMI_SITE_ELEMENTWISE;
             // bias (registers e of class tile i = classes 32*i + (e & 3) + 8*(e >> 2) + 4*hh)
 #pragma unroll
@@ -316,8 +336,8 @@ template <int RT>
 static void launch_rt(const HeadArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.imap ? a.Bc : a.B), (unsigned)((a.tc + 31) / 32)), block(256);
     if constexpr (RT >= 3) {
-        static const int staged = [] { const char* v = std::getenv("BMI_HEAD_STAGED"); return v ? std::atoi(v) : 1; }();
-        if (staged && a.K % 128 == 0 && (a.K <= HEAD_KC || a.K % HEAD_KC == 0)) {   // every LDS chunk a multiple of 128
+        static const int csplit = [] { const char* v = std::getenv("BMI_HEAD_CSPLIT"); return v ? std::atoi(v) : 1; }();
+        if (csplit) {
             if (a.in_kind == 1) hipLaunchKernelGGL((head_fused_kernel<RT, 1, true>), grid, block, 0, s, a);
             else if (a.in_kind == 2) hipLaunchKernelGGL((head_fused_kernel<RT, 2, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((head_fused_kernel<RT, 0, true>), grid, block, 0, s, a);
