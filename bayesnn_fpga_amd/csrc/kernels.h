@@ -121,6 +121,7 @@ int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0:
 int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
 int& opt_splitk();             // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch
+int& opt_dense_exact();        // 1: hidden dense layers on the exact-f32 MFMA instead of the split-fp16 form
 int& opt_epilogue_lite();      // 1: BN + residual + ReLU + 2-bit elementwise-site launches finish in epilogue_lite
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);

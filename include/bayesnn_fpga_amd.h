@@ -154,6 +154,9 @@ const char* bmi_error_string(int code);
  *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
  *   "splitk"                                0 | 1, read by bmi_plan: 3x3 convs of the once-per-batch prefix whose grid is <= 64 tiles (VGG's convs on
  *                                           2x2 maps) run split-K: one workgroup per (tile, tap), fp32 partial sums, a finishing pass
+ *   "dense_exact"                           0 | 1: hidden dense layers (BMI_OP_DENSE / bmi_dense_f32) on the exact-f32 MFMA (1) or as
+ *                                           fp16 head + tail products on the fp16 MFMA with fp32 accumulation (0, default: fp32-equivalent
+ *                                           to a few 1e-7, 2.5x faster)
  *   "epilogue_lite"                         0 | 1: BN + residual + ReLU + 2-bit elementwise-site launches finish on the accumulator
  *                                           registers with one fp16 trip through LDS (1, default) or in the general two-round fp32
  *                                           epilogue (0); the same bits either way
