@@ -716,3 +716,34 @@ def test_conv1x1_stream_kernel(cin, cout, H, stride, n, dt, use_res, use_site):
     tol = 2e-3 if dt == "f16" else 1e-2
     torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
     assert torch.equal(out.view(torch.int16), out_other.view(torch.int16))
+
+
+@pytest.mark.parametrize("in_f32", [0, 1])
+def test_dense_split_fp16_is_fp32_equivalent(in_f32):
+    """The default dense kernel multiplies fp16 head + tail pairs on the fp16 MFMA (fp32 accumulation); against the exact-f32
+    MFMA kernel (bmi_set_option "dense_exact") the outputs agree to a few 1e-7 of the operand scale, far inside the 1e-5 the
+    float64 reference test allows."""
+    lib = _lib.lib()
+    N, K, Cout = 777, 512, 512
+    g = _gen(23)
+    x = torch.randn(N, K, generator=g) * 3.0
+    xd = x.to(DEV) if in_f32 else x.half().to(DEV)
+    w = 0.05 * torch.randn(Cout, K, generator=g)
+    b = 0.3 * torch.randn(Cout, generator=g)
+    wd, bd = w.to(DEV), b.to(DEV)
+    outs = []
+    try:
+        for exact in (1, 0):
+            _lib.set_option("dense_exact", exact)
+            out = torch.full((N, Cout), float("nan"), device=DEV)
+            _lib.check(lib.bmi_dense_f32(gh.ptr(xd), in_f32, gh.ptr(wd), gh.ptr(bd), gh.ptr(out), N, N, K, Cout, 0, None, N, 0, 0, 0,
+                                         gh.stream()), "bmi_dense_f32")
+            torch.cuda.synchronize()
+            outs.append(out.cpu().double())
+    finally:
+        _lib.set_option("dense_exact", 0)
+    ref = xd.cpu().double() @ w.double().T + b.double()
+    scale = float((xd.cpu().double().abs() @ w.double().abs().T).max())          # sum |x||w|: what a relative error multiplies
+    assert float((outs[0] - ref).abs().max()) < 2e-6 * scale                      # exact-f32 chain vs float64
+    assert float((outs[1] - ref).abs().max()) < 2e-6 * scale                      # split-fp16 vs float64: the same class
+    assert float((outs[1] - outs[0]).abs().max()) < 1e-6 * scale
