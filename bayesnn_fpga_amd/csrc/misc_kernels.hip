@@ -320,17 +320,20 @@ int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int 
 // One thread = one output pixel x 32 output channels (lane = consecutive pixels: the fp32 NCHW reads and the 64-byte NHWC
 // stores are coalesced; a tap's 32 weights are an LDS broadcast of 8 x ds_read_b128).  The first version mapped 8 lanes to
 // one pixel (8 channels each): every wave-load fetched 8 distinct words and the kernel sat at 80 us for 0.9 GFLOP.
-template <bool BF>
+// FAST: three input channels and whole 32-channel blocks (every model of the path): no per-quad channel guards, the three
+// loads of a tap issued together.
+template <bool BF, bool FAST>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
-                                                        _Float16* __restrict__ out, int N, int Cin, int H, int W, int Cout,
+                                                        _Float16* __restrict__ out, int N, int Cin_, int H, int W, int Cout,
                                                         int ks, int stride, int pad, int Ho, int Wo, int relu) {
+    const int Cin = FAST ? 3 : Cin_;
     __shared__ __attribute__((aligned(16))) float wl[STEM_MAX_W];      // transposed: [tap][Cout]
     const int kvol = ks * ks * Cin;
     for (int i = threadIdx.x; i < Cout * kvol; i += blockDim.x) { const int c = i / kvol, t = i - c * kvol; wl[t * Cout + c] = w[i]; }
     __syncthreads();
     const int c0 = blockIdx.y * 32;                                    // this block's 32 output channels (uniform: LDS broadcast)
-    const int nc = min(32, Cout - c0);                                 // multiple of 8
+    const int nc = FAST ? 32 : min(32, Cout - c0);                     // multiple of 8
     const long total = (long)N * Ho * Wo;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -344,15 +347,22 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     for (int ky = 0; ky < ks; ++ky) {
         const int iy = oy * stride - pad + ky;
         const bool oky = (unsigned)iy < (unsigned)H;
+#pragma unroll 1
         for (int kx = 0; kx < ks; ++kx) {
             const int ix = ox * stride - pad + kx;
             const bool ok = oky && (unsigned)ix < (unsigned)W;
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float xv = ok ? x[(((size_t)n * Cin + ci) * H + iy) * W + ix] : 0.f;
+            float xin[3] = {0.f, 0.f, 0.f};
+            if constexpr (FAST) {
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) xin[ci] = ok ? x[(((size_t)n * 3 + ci) * H + iy) * W + ix] : 0.f;
+            }
+#pragma unroll
+            for (int ci = 0; ci < (FAST ? 3 : Cin); ++ci) {
+                const float xv = FAST ? xin[ci] : (ok ? x[(((size_t)n * Cin + ci) * H + iy) * W + ix] : 0.f);
                 const float* wr = wl + ((ky * ks + kx) * Cin + ci) * Cout + c0;
 #pragma unroll
                 for (int e4 = 0; e4 < 8; ++e4) {
-                    if (4 * e4 < nc) {
+                    if (FAST || 4 * e4 < nc) {
                         const float4 w4 = *(const float4*)(wr + 4 * e4);
                         acc[4 * e4] = fmaf(xv, w4.x, acc[4 * e4]); acc[4 * e4 + 1] = fmaf(xv, w4.y, acc[4 * e4 + 1]);
                         acc[4 * e4 + 2] = fmaf(xv, w4.z, acc[4 * e4 + 2]); acc[4 * e4 + 3] = fmaf(xv, w4.w, acc[4 * e4 + 3]);
@@ -386,8 +396,10 @@ int launch_stem_conv(const float* x, const float* w, const float* scale, const f
     const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wdt + 2 * pad - ksize) / stride + 1;
     const long total = (long)n * ho * wo;
     const dim3 grid((unsigned)((total + 255) / 256), (unsigned)((cout + 31) / 32)), block(256);
-    if (bf16) hipLaunchKernelGGL(stem_conv_kernel<true>, grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
-    else hipLaunchKernelGGL(stem_conv_kernel<false>, grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+#define STEM_LAUNCH(BF_, F_) hipLaunchKernelGGL((stem_conv_kernel<BF_, F_>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu)
+    if (cin == 3 && cout % 32 == 0) { if (bf16) STEM_LAUNCH(true, true); else STEM_LAUNCH(false, true); }
+    else { if (bf16) STEM_LAUNCH(true, false); else STEM_LAUNCH(false, false); }
+#undef STEM_LAUNCH
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
