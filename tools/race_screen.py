@@ -21,6 +21,7 @@ SHAPES = [  # cin, cout, H, k, s, p, images[, 1: BasicBlock tail = residual + Re
     (128, 256, 16, 3, 2, 1, 333), (256, 512, 8, 3, 2, 1, 777), (64, 256, 32, 3, 2, 1, 130), (256, 512, 8, 1, 2, 0, 901),
     (128, 128, 16, 3, 1, 1, 257), (256, 256, 8, 3, 1, 1, 515), (512, 512, 4, 3, 1, 1, 1031),
     (128, 128, 16, 3, 1, 1, 259, 1), (256, 256, 8, 3, 1, 1, 1027, 1), (512, 512, 4, 3, 1, 1, 4099, 1), (256, 512, 8, 1, 1, 0, 903, 1),
+    (128, 512, 16, 1, 1, 0, 1203, 1), (512, 128, 16, 1, 1, 0, 777),       # conv1x1_stream: Bottleneck tail, Cout = 128 reduce conv
 ]
 
 
