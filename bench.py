@@ -254,6 +254,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
+        # the communicator is created by its first collective: do that here, on the default stream, before any step issues an
+        # all-reduce from one of the in-flight side streams
+        _probe = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(_probe)
+        torch.cuda.synchronize()
 
     from bayesnn_fpga_amd.sharding import accumulate_sharded, shard_range
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
