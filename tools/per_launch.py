@@ -53,7 +53,7 @@ def main():
     by_out = {op["out"]: op for op in g.ops if op.get("out", -1) >= 0 and "ksize" in op}   # conv ops (heads / masks print no shape)
     total = sum(r["ms"] for r in rows)
     print(f"{a.workload}: batch {B} x T {T}, {len(rows)} launches, {total:.2f} ms of device time")
-    print(f"{'#':>3} {'kind':6} {'family':16} {'shape':34} {'images':>7} {'ms':>7} {'TFLOP/s':>8} {'GB/s':>7}  flags")
+    print(f"{'#':>3} {'kind':7} {'family':16} {'shape':34} {'images':>7} {'ms':>7} {'TFLOP/s':>8} {'GB/s':>7}  flags")
     lines = []
     for i, r in enumerate(rows):
         op = by_out.get(r["out"]) if r["kind"] in ("conv_igemm", "conv", "stem") else None
@@ -67,7 +67,8 @@ def main():
                                              ("shortcut", op.get("in2", -1) >= 0)) if on)
         tf = r["flops"] / r["ms"] / 1e9 if r["ms"] > 0 and r["flops"] else 0.0
         gb = r["bytes"] / r["ms"] / 1e6 if r["ms"] > 0 and r["bytes"] else 0.0
-        line = f"{i:3d} {r['kind']:6} {r['family'] or '':16} {shape:34} {r['images']:7d} {r['ms']:7.3f} {tf:8.1f} {gb:7.0f}  {flags}"
+        kind = "conv" if r["kind"] == "conv_igemm" else r["kind"]      # (the library's slot name for every conv op)
+        line = f"{i:3d} {kind:7} {r['family'] or '':16} {shape:34} {r['images']:7d} {r['ms']:7.3f} {tf:8.1f} {gb:7.0f}  {flags}"
         lines.append((r["ms"], line))
         print(line)
     if a.top:
