@@ -149,8 +149,9 @@ const char* bmi_error_string(int code);
  *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
  *   "conv_pw"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-1 convs on 8x8 / 4x4 maps with Cout % 256 == 0 run in conv3x3_pw (256 x 256
  *                                           tile, 8 waves) instead of conv3x3_patch (128 x 128, 2 workgroups per CU)
- *   "conv_stream"                           0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 1x1 convs with Cin <= 256 (HBM-bound) run in
- *                                           conv1x1_stream (128 x 256 tile, two workgroups per CU) instead of conv_igemm_wide
+ *   "conv_stream"                           0 | 1 | 2 (= 1 without the minimum-grid rule and for plain launches too: tests) | 3 (= 1 with the
+ *                                           256-pixel tile: A/B): HBM-bound 1x1 convs (Cin <= 512; with a residual, or Cout % 256 != 0) run
+ *                                           in conv1x1_stream (128 x 128 tile, three or four workgroups per CU) instead of conv_igemm_wide
  *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
  *   "splitk"                                0 | 1, read by bmi_plan: 3x3 convs of the once-per-batch prefix whose grid is <= 64 tiles (VGG's convs on
  *                                           2x2 maps) run split-K: one workgroup per (tile, tap), fp32 partial sums, a finishing pass
