@@ -139,6 +139,7 @@ class FullAnalysis:
         labels = np.zeros((n, C))
         trackers = [[(set(), set(), {}, {}) for _ in range(n_exits)] for _ in range(2)]
         off = 0
+        self._pipe = None            # engines snapshot the weights when they are built: a fresh pair per collection run
 
         def queued(it):
             """(result getter, labels) of each batch, one batch behind the one being queued (two batches in flight)."""
