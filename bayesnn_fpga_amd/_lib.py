@@ -15,7 +15,9 @@ SITE_POS_OUTER, SITE_POS_INNER = 0, 1
 DTYPE_F16, DTYPE_BF16 = 0, 1
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
 PROFILE_SLOTS = 8
-CONV_FAMILY_KERNELS = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel", "conv1x1_stream_kernel")
+CONV_FAMILY_KERNELS = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel", "conv1x1_stream_kernel",
+                       "conv3x3_s2_kernel")
+ABI_VERSION = 300             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
 CONV_FAMILIES = len(CONV_FAMILY_KERNELS)     # BMI_CONV_FAMILIES
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
                  OP_DENSE: "dense"}
@@ -109,6 +111,9 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.bmi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports C-ABI version {l.bmi_version()}, this binding expects {ABI_VERSION}: "
+                               "rebuild the library (python -m bayesnn_fpga_amd._build)")
         _lib = l
     return _lib
 

@@ -1,0 +1,477 @@
+// 3x3 / stride-2 / pad-1 convolution with the input patch resident in LDS as four PARITY PLANES (gfx950): the stride-2 convs of
+// the path — BasicBlock conv1 of layers 2-4 and every exit-head conv, SA/models/resnet18/resnet18.py:280-299, :306-329 — on
+// conv3x3_pw's 256 x 256 tile / 8 waves / ping-pong main loop, persistent like conv_igemm_wide_persist.
+//
+// Why.  conv_igemm_wide streams a [256 px][64 ch] activation tile per (tap, 64-channel chunk) from L2: every input line is
+// requested 2.25 times per channel tile, and the re-reads miss the XCD's 4 MB L2 (32 workgroups x a 256-px tile's input, with
+// the taps of one line 2-8 K-steps apart): rocprofv3 FETCH_SIZE 1.5x (64 -> 128 on 32x32 maps) to 4.2x (256 -> 512 + 512 on 8x8
+// maps) the algorithmic input bytes, the kernel at 845 / 985 / 1070 TFLOP/s on the three shape classes against 1270-1420 for
+// conv3x3_pw (profiles/experiments/r3_per_launch_before_s2.log).  Here a tile's input is DMA'd ONCE per 32-channel chunk and all
+// nine taps are served from LDS.
+//
+// A stride-2 tap (ky, kx) reads input rows 2 oy + ky - 1 and columns 2 ox + kx - 1: rows of ONE parity per ky, columns of one
+// parity per kx.  The patch is therefore kept as four planes — A (odd rows, odd columns; taps (0,0) (0,2) (2,0) (2,2)),
+// B (odd, even; (0,1) (2,1)), C (even, odd; (1,0) (1,2)), D (even, even; (1,1)) — inside which a tap is a shift by 0 or 1 cell,
+// exactly the stride-1 addressing of conv3x3_pw.  The taps run plane by plane (A A A A B B C C D per 32-channel chunk), so a
+// plane's cells are dead long before they are needed again: ONE copy of the patch (72-88 KB for 32 channels) is enough, each
+// plane is refilled with the next chunk's channels while the other planes compute (A during the C / D taps, B at the end of
+// the period, C and D at the start of their own period), and nothing ever waits for a whole-patch refill.
+//
+//   tile       = IMGS whole output maps (256 pixels: 1 map of 16x16, 4 of 8x8, 16 of 4x4) x 256 output channels
+//   waves      = 2 channel halves (g) x [2 (channels) x 2 (pixels)], wave tile 64 ch x 128 px = 4 x 8 tiles of v_mfma_f32_16x16x32;
+//                the 16 pixels of an MFMA tile are a 4 x 4 block of output pixels (conv3x3_pw's tile-pixel order)
+//   LDS        = [W0 | W1 | patch pieces | (pad) | W2] + BN table: three weight stages [256 ch][32 k] (64-byte rows), the patch as
+//                NPT pieces of 128 cells x 64 B (piece = one DMA instruction per thread), planes back to back with plane A
+//                padded to whole pieces.  132-152 KB: one 512-thread workgroup per CU.
+//   64-B rows  = four rows share a 256-byte bank window.  ds_read_b128 is served in four lane groups {0-3, 12-15, 20-27},
+//                {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS): a group reads 16-byte chunk kq of rows 0-3 and 12-15 of
+//                a 16-row fragment and chunk kq ^ 1 of rows 4-11.  Chunk c of weight row r is stored at position
+//                c ^ 2 ((r >> 2) & 1), chunk c of a patch cell in plane row y at c ^ 2 (y & 1): the 16 lanes of every group then
+//                hit 16 distinct 16-byte slots, for every tap shift and every cell pitch (tight pitches: TW or TW + 1 cells).
+//                LDS-DMA writes lane-linearly, so the permutation is applied to the per-lane SOURCE address.
+//   main loop  = conv3x3_pw's: K-step = one tap x 32 channels, two phases (LOAD part / barrier / MFMA part / barrier), the two
+//                wave groups one barrier apart, weights of the step AFTER NEXT in flight, counted vmcnt with compile-time
+//                immediates (the 9 steps of a chunk are unrolled).  Per step at most two patch pieces ride along.
+//   persistent = one workgroup per CU walks the tiles; the next tile's weight stages 0 / 1 and its plane A / B pieces are
+//                issued when the main loop ends and land while the epilogue (BN + ReLU, fp16, two rounds of 128 pixels per
+//                channel half in the 64 KB the C / D pieces and W2 occupy) runs.
+//   pair mode  = as conv_igemm_wide: channel tiles >= split use the second conv's weights / BN / output tensor.
+//   epilogue   = plain (BN + ReLU) only: every stride-2 conv of the path.  Anything else stays with conv_igemm_wide.
+#include <cstdlib>
+
+#include "conv_epilogue.h"
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define S2_BN_MAX 1024
+
+// TW = OUTPUT map size (TW x TW; the input map is 2 TW x 2 TW): 16, 8 or 4.
+template <int TW>
+struct S2Geom {
+    static constexpr int CT = 256, PX = 256, IMGS = PX / (TW * TW);
+    static_assert(IMGS >= 1 && IMGS * TW * TW == PX, "whole output maps per tile");
+    // planes in tap-use order: 0 = A (odd input rows, odd columns), 1 = B (odd, even), 2 = C (even, odd), 3 = D (even, even).
+    // Plane row y of an odd-row plane is input row 2 y - 1 (y = 0: the padding row), of an even-row plane input row 2 y.
+    __host__ __device__ static constexpr int py(int pl) { return pl < 2 ? 1 : 0; }
+    __host__ __device__ static constexpr int px(int pl) { return (pl == 0 || pl == 2) ? 1 : 0; }
+    __host__ __device__ static constexpr int rows(int pl) { return TW + py(pl); }
+    __host__ __device__ static constexpr int cols(int pl) { return TW + px(pl); }                 // = cell pitch
+    __host__ __device__ static constexpr int cells(int pl) { return IMGS * rows(pl) * cols(pl); }
+    static constexpr int A_PAD = (cells(0) + 127) / 128 * 128;                                    // plane A ends on a piece boundary
+    __host__ __device__ static constexpr int cell0(int pl) {
+        return pl == 0 ? 0 : A_PAD + (pl >= 2 ? cells(1) : 0) + (pl >= 3 ? cells(2) : 0);
+    }
+    static constexpr int TOTAL = cell0(3) + cells(3);
+    static constexpr int NPT = (TOTAL + 127) / 128;               // pieces (= DMA instructions per thread and chunk): 11 | 10 | 10
+    __host__ __device__ static constexpr int plane_of(int cell) { return cell < A_PAD ? 0 : (cell < cell0(2) ? 1 : (cell < cell0(3) ? 2 : 3)); }
+    __host__ __device__ static constexpr int lo(int k) { return plane_of(128 * k); }
+    __host__ __device__ static constexpr int hi(int k) { return plane_of(128 * k + 127 < TOTAL ? 128 * k + 127 : TOTAL - 1); }
+    __host__ __device__ static constexpr int count_hi_le(int pl) { int n = 0; for (int k = 0; k < NPT; ++k) n += hi(k) <= pl ? 1 : 0; return n; }
+    static constexpr int NA = count_hi_le(0);                     // pieces that hold plane A only
+    static constexpr int PRO = count_hi_le(1);                    // ... planes A / B only: loaded ahead (prologue, next chunk)
+    static constexpr int NB = PRO - NA;
+    static constexpr int NOWN = NPT - PRO;                        // pieces with C / D cells: loaded in their own chunk's period
+    // K-step (0..8 of a chunk's period) in which piece k is issued.  A pieces (next chunk): steps 5, 6; B pieces (next chunk):
+    // steps 7, 8; own-period pieces: one per step from step 0.
+    __host__ __device__ static constexpr int pstep(int k) {
+        return k < NA ? 5 + (2 * k) / NA : (k < PRO ? 7 + (2 * (k - NA)) / NB : k - PRO);
+    }
+    __host__ __device__ static constexpr int pieces_at(int s) { int n = 0; for (int k = 0; k < NPT; ++k) n += pstep(k) == s ? 1 : 0; return n; }
+    // Validity of that schedule (see the hazard notes in the kernel): a plane last read in step L may be overwritten from
+    // step L + 2 on; a piece issued in step s has landed for every wave at the end of step s + 2.
+    __host__ __device__ static constexpr bool schedule_ok() {
+        constexpr int first[4] = {0, 4, 6, 8}, last[4] = {3, 5, 7, 8};
+        for (int k = 0; k < NPT; ++k) {
+            const int s = pstep(k);
+            if (k < PRO) {            // carries the NEXT chunk: period steps 9 + first[lo] is the deadline
+                if (s < last[hi(k)] + 2 || s > 8 || s + 3 > 9 + first[lo(k)]) return false;
+            } else {                  // carries its own chunk; the plane was last read in the previous period
+                if (s + 9 < last[hi(k)] + 2 || s + 3 > first[lo(k)]) return false;
+            }
+        }
+        for (int s = 0; s < 9; ++s)
+            if (pieces_at(s) > 2) return false;
+        return NOWN <= 5 && NA >= 1 && NB >= 1;
+    }
+    static_assert(schedule_ok(), "patch refill schedule violates a WAR / RAW window");
+    static constexpr int WST = CT * 64;                           // one weight stage (32-deep K-step)
+    static constexpr int PIECE = 512 * 16;
+    static constexpr int P_OFF = 2 * WST;                         // [W0 | W1 | pieces ...]
+    static constexpr int E_OFF = P_OFF + PRO * PIECE;             // epilogue staging: the own-period pieces, padding, W2
+    static constexpr int E_BYTES = 65536;
+    static constexpr int END_PIECES = P_OFF + NPT * PIECE;
+    static constexpr int W2_OFF = (END_PIECES + WST > E_OFF + E_BYTES ? END_PIECES : E_OFF + E_BYTES - WST);
+    static constexpr int BN_OFF = W2_OFF + WST;
+    static constexpr int LDS_BYTES = BN_OFF + 2 * S2_BN_MAX * 4 + 128;  // + the two image-row tables of the dynamic-exit instantiation
+    static_assert(BN_OFF - E_OFF >= E_BYTES, "epilogue staging area");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __host__ __device__ static constexpr int wstage_off(int st) { return st == 2 ? W2_OFF : st * WST; }
+    // tile pixel p -> image of the tile and output coordinates: the 16 pixels of one MFMA tile are a 4 x 4 block
+    __host__ __device__ static constexpr int p_img(int p) { return p / (TW * TW); }
+    __host__ __device__ static constexpr int p_ox(int p) { return 4 * ((p >> 4) % (TW / 4)) + (p & 3); }
+    __host__ __device__ static constexpr int p_oy(int p) { return 4 * (((p >> 4) / (TW / 4)) % (TW / 4)) + ((p >> 2) & 3); }
+    static constexpr int BR = TW / 4, BI = BR * BR;
+    // cell of the j-th 4 x 4 block of a wave (its 8 blocks start at a multiple of 8) relative to the wave's first one, plane pl
+    __host__ __device__ static constexpr int cell_delta(int pl, int j) {
+        return (j / BI) * rows(pl) * cols(pl) + 4 * ((j % BI) / BR) * cols(pl) + 4 * ((j % BI) % BR);
+    }
+};
+
+// step s of a chunk's period -> plane, cell shift (dy, dx) inside the plane, tap index ky * 3 + kx (weight offset)
+__host__ __device__ constexpr int s2_plane(int s) { return s < 4 ? 0 : (s < 6 ? 1 : (s < 8 ? 2 : 3)); }
+__host__ __device__ constexpr int s2_dy(int s) { return (s == 2 || s == 3 || s == 5) ? 1 : 0; }
+__host__ __device__ constexpr int s2_dx(int s) { return (s == 1 || s == 3 || s == 7) ? 1 : 0; }
+__host__ __device__ constexpr int s2_tap(int s) {
+    constexpr int t[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
+    return t[s];
+}
+
+template <int TW, bool BF, bool IMAP>
+__global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_tiles) {
+    using G = S2Geom<TW>;
+    constexpr int CT = G::CT, IMGS = G::IMGS, NPT = G::NPT, PRO = G::PRO;
+    constexpr int TI = 4, TP = 8;
+    typedef float accv __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
+    char* const pbuf = smem + G::P_OFF;
+    float* const bn_scale = (float*)(smem + G::BN_OFF);
+    float* const bn_bias = bn_scale + S2_BN_MAX;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
+
+    const int n_ctiles = a.Cout / CT;
+    const int n_ptiles = (a.N + IMGS - 1) / IMGS;
+    const int Ktot = 9 * a.Cin;
+    const int nC = a.Cin / 32;
+    const int split = a.wgt_b ? a.split : a.Cout;
+
+    // folded-BN table of the whole launch (an ordinary global load inside the epilogue would make hipcc drain the LDS-DMA)
+    for (int c = tid; c < a.Cout; c += 512) {
+        const bool second = c >= split;
+        const float* sp = second ? a.scale_b : a.scale;
+        const float* bp = second ? a.bias_b : a.bias;
+        const int cc = second ? c - split : c;
+        bn_scale[c] = (sp ? sp[cc] : 1.f) * a.out_mul;
+        bn_bias[c] = bp ? bp[cc] : 0.f;
+    }
+    __syncthreads();   // (no LDS-DMA in flight yet: the plain barrier and its waits are fine here)
+
+    // ---- per-lane fragment geometry (tile-independent) ----
+    // weights: row (g*128 + wc*64 + l16 + 16 i), chunk kq at position kq ^ 2 ((row >> 2) & 1) = kq ^ 2 ((l16 >> 2) & 1)
+    const int a_off = (g * 128 + wc * 64 + l16) * 64 + ((kq ^ (((l16 >> 2) & 1) << 1)) << 4);
+    // pixels: lane (by, bx) = (l16 >> 2, l16 & 3) of each 4 x 4 block; plane row parity of the cell = (by + dy) & 1
+    const int by = l16 >> 2, bx = l16 & 3;
+    const int pbase = wp * 128;                                   // first tile pixel of this wave
+    // (a tap with dy = 1 reads the cell one plane row further down: + cols * 64 as an immediate, and the chunk sits at the
+    // other position of its pair: the same per-lane address with bit 5 flipped)
+    int boff[4];
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+        const int wave_cell = G::cell0(pl) + (G::p_img(pbase) * G::rows(pl) + G::p_oy(pbase)) * G::cols(pl) + G::p_ox(pbase);
+        boff[pl] = G::P_OFF + (wave_cell + by * G::cols(pl) + bx) * 64 + ((kq ^ ((by & 1) << 1)) << 4);
+    }
+
+    // ---- per-thread DMA sources ----
+    // Every DMA is a buffer_load ... lds through a per-tile buffer descriptor (wave-uniform, SGPRs) with a 32-bit per-lane byte
+    // offset: no 64-bit address arithmetic or pointer selects in the loop, and a lane whose offset lies beyond the descriptor's
+    // size loads ZEROS — the padding ring of the patch, the cells behind a plane, the images of a last tile beyond N.
+    // patch: piece q = tid + 512 k -> cell q >> 2 of the piece array, position q & 3 holds chunk (q & 3) ^ 2 (y & 1).  What a
+    // piece reads is the same for every tile up to the tile's first image: pre[k] = byte offset of the piece's source
+    // relative to image n0 of the input (2 (img * H*W*Cin + (iy * W + ix) * Cin + chunk * 8)), computed ONCE per kernel; the
+    // descriptor of a tile starts at its image n0 and ends behind its last image.  (IMAP: the images of a tile are not
+    // consecutive rows — pre[k] = img << 24 | in-image ELEMENT offset, the rows come from a per-tile LDS table and the
+    // descriptor covers the whole tensor.)
+    const unsigned HWC = (unsigned)a.H * a.W * a.Cin;             // (launcher: N <= in_mod, in_mod * HWC < 2^31, HWC < 2^24)
+    constexpr unsigned OOB = 0xfffffff0u;                         // beyond every descriptor (a tile's <= 16 images; IMAP: the tensor, < 2^32 - 16 bytes)
+    unsigned pre[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int q = tid + 512 * k;
+        const int cell = q >> 2, pos = q & 3;
+        const int pl = G::lo(k) == G::hi(k) ? G::lo(k) : (cell < G::cell0(G::hi(k)) ? G::lo(k) : G::hi(k));
+        const int pyl = pl < 2 ? 1 : 0, pxl = (pl == 0 || pl == 2) ? 1 : 0;
+        const int RQ = (TW + pyl) * (TW + pxl), Q = TW + pxl;
+        const int lc = cell - (pl == 0 ? 0 : (pl == 1 ? G::cell0(1) : (pl == 2 ? G::cell0(2) : G::cell0(3))));
+        const int img = lc / RQ, rm = lc - img * RQ;
+        const int y = rm / Q, x = rm - y * Q;
+        const int iy = 2 * y - pyl, ix = 2 * x - pxl;
+        const bool ok = lc < IMGS * RQ && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned inoff = (unsigned)((iy * a.W + ix) * a.Cin + ((pos ^ ((y & 1) << 1)) << 3));
+        pre[k] = !ok ? OOB : (IMAP ? ((unsigned)img << 24) | inoff : 2u * ((unsigned)img * HWC + inoff));
+    }
+    // IMAP: tensor row of each image of a tile (-1 beyond N), two tables: the epilogue of tile i reads table i & 1 while the
+    // prologue of tile i + 1 is issued from table (i + 1) & 1
+    int* const row_tabs = (int*)(smem + G::BN_OFF + 2 * S2_BN_MAX * 4);
+    int tsel = 0;
+    // weights: piece q = tid + 512 i -> row (tid >> 2) + 128 i, position tid & 3 holds chunk (tid & 3) ^ 2 ((row >> 2) & 1);
+    // one descriptor per 128-row half of the channel tile (a pair's second conv has its own weight tensor)
+    const unsigned woff = 2u * ((unsigned)(tid >> 2) * Ktot + (((tid & 3) ^ (((tid >> 4) & 1) << 1)) << 3));
+    const unsigned wbytes = 2u * 128u * Ktot;
+    __amdgpu_buffer_rsrc_t rs_w0, rs_w1, rs_in;
+    int ch0 = 0, n0 = 0;
+
+    // (the K offset of a step — tap and channel chunk, wave-uniform — rides in the instruction's SGPR offset: the per-lane
+    // offsets stay loop-invariant, one VGPR each, and nothing is added per DMA)
+#define BLDS16(RSRC, VOFF, SOFF, LDSPTR) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((RSRC), (__attribute__((address_space(3))) void*)(LDSPTR), 16, (VOFF), (SOFF), 0, 0)
+#define ISSUE_W(KOFF, ST)                                                                                    \
+    {                                                                                                        \
+        const unsigned so_ = __builtin_amdgcn_readfirstlane(2u * (unsigned)(KOFF));                          \
+        BLDS16(rs_w0, woff, so_, smem + G::wstage_off(ST) + (0 * 512 + wave * 64) * 16);                     \
+        BLDS16(rs_w1, woff, so_, smem + G::wstage_off(ST) + (1 * 512 + wave * 64) * 16);                     \
+    }
+#define ISSUE_P(K, C0)                                                                                       \
+    {                                                                                                        \
+        unsigned o_ = pre[K];                                                                                \
+        if constexpr (IMAP) {                                                                                \
+            const int row_ = row_tabs[tsel * 16 + ((pre[K] >> 24) & 15)];                                    \
+            o_ = (pre[K] == OOB || row_ < 0) ? OOB : 2u * ((unsigned)row_ * HWC + (pre[K] & 0xffffffu));     \
+        }                                                                                                    \
+        BLDS16(rs_in, o_, __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0)), pbuf + ((K) * 512 + wave * 64) * 16); \
+    }
+    // Tile VB: its buffer descriptors; its first two weight stages and the pieces that hold planes A / B only (chunk 0) are
+    // issued: everything the first K-steps read.
+#define SETUP_TILE(VB)                                                                                       \
+    {                                                                                                        \
+        int ptile_, ctile_;                                                                                  \
+        xcd_tile_map((VB), n_ptiles, n_ctiles, ptile_, ctile_, a.xcd_split);                                 \
+        ch0 = ctile_ * CT;                                                                                   \
+        n0 = ptile_ * IMGS;                                                                                  \
+        const _Float16* w0_ = ch0 < split ? a.wgt + (size_t)ch0 * Ktot : a.wgt_b + (size_t)(ch0 - split) * Ktot; \
+        const _Float16* w1_ = ch0 + 128 < split ? a.wgt + (size_t)(ch0 + 128) * Ktot : a.wgt_b + (size_t)(ch0 + 128 - split) * Ktot; \
+        rs_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)w0_, 0, wbytes, 0x00020000);                        \
+        rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)w1_, 0, wbytes, 0x00020000);                        \
+        if constexpr (IMAP) {                                                                                \
+            rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 2u * (unsigned)a.in_mod * HWC, 0x00020000); \
+        } else {                                                                                             \
+            const int nimg_ = a.N - n0 < IMGS ? a.N - n0 : IMGS;                                             \
+            rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n0 * HWC), 0, 2u * (unsigned)nimg_ * HWC, 0x00020000); \
+        }                                                                                                    \
+        ISSUE_W(0, 0);                                                                                       \
+        if constexpr (IMAP) {                                                                                \
+            tsel ^= 1;                                                                                       \
+            if (tid < IMGS) row_tabs[tsel * 16 + tid] = n0 + tid < a.N ? a.imap[n0 + tid] : -1;              \
+            __syncthreads();   /* (drains W(0) too: the dynamic-exit path only) */                           \
+        }                                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < PRO; ++k) ISSUE_P(k, 0);                                       \
+        if (9 * nC > 1) ISSUE_W(s2_tap(1) * a.Cin, 1);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+
+#define RAW_BARRIER()                                  \
+    {                                                  \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_sched_barrier(0);             \
+    }
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+    // What may still be in flight when K-step S of a chunk ends: the weight tile of the step after next (2 DMA instructions,
+    // issued this step) and the patch pieces issued this step and the step before; everything older — in particular the next
+    // step's weights and every piece issued two or more steps ago — has landed.  In the last chunk no next-chunk piece (steps
+    // 5-8) and no weights beyond the tile's last step (steps 7, 8) are issued.
+#define END_OF_STEP_WAIT(S)                                                                                    \
+    {                                                                                                          \
+        constexpr int prev_ = (S) == 0 ? 8 : (S) - 1;                                                          \
+        constexpr int full_ = 2 + G::pieces_at(S) + G::pieces_at(prev_);                                       \
+        constexpr int lastn_ = ((S) < 7 ? 2 : 0) + ((S) <= 4 ? G::pieces_at(S) : 0) + ((S) >= 1 && (S) <= 5 ? G::pieces_at(prev_) : 0); \
+        if (!last) { WAIT_VM(full_); }                                                                         \
+        else { WAIT_VM(lastn_); }                                                                              \
+    }
+    // One K-step = step S of the chunk's period (one tap x this chunk's 32 channels).  Two phases (LOAD part, barrier, MFMA part,
+    // barrier); the two wave groups run one barrier apart.  Weight stage = S % 3 (9 steps per chunk: the index repeats).
+    // Intervals between barriers, global step T: group 0 LOAD 4T+2k, MFMA 4T+2k+1; group 1 one later.
+    //   WAR  weight stage (T+2)%3 was last read in 4T-3 (group 1, phase 0 of T-1; retired by its lgkmcnt(0) in 4T-2): refilled
+    //        from 4T on.  A patch plane last read in step L (group 1's phase-1 reads retire in 4L+4) is refilled from step L+2.
+    //   RAW  in interval 4T+3 every wave waits (counted vmcnt) until only the DMA of steps T and the pieces of T-1 are in flight.
+#define S2_STEP(S)                                                                                             \
+    {                                                                                                          \
+        constexpr int pl_ = s2_plane(S), dy_ = s2_dy(S), dx_ = s2_dx(S);                                       \
+        const char* ws_ = smem + G::wstage_off((S) % 3) + a_off;                                               \
+        const char* pb_ = smem + (dy_ * G::cols(pl_) + dx_) * 64 + (boff[pl_] ^ (dy_ << 5));                   \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+            if (kk == 0) {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+                bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, 4 * kk + j) * 64);                            \
+            if (kk == 0) {                                                                                     \
+                /* weights of the step after next: step S+2 of this chunk, or steps 0 / 1 of the next one */   \
+                if ((S) < 7) { ISSUE_W(s2_tap((S) + 2) * a.Cin + c32, ((S) + 2) % 3); }                        \
+                else if (!last) { ISSUE_W(s2_tap((S) - 7) * a.Cin + c32 + 32, ((S) + 2) % 3); }                \
+                _Pragma("unroll") for (int k = 0; k < NPT; ++k)                                                \
+                    if (G::pstep(k) == (S)) {                                                                  \
+                        if (k >= PRO) { ISSUE_P(k, c32); }                                                     \
+                        else if (!last) { ISSUE_P(k, c32 + 32); }                                              \
+                    }                                                                                          \
+            }                                                                                                  \
+            if (kk == 1 && g == 1) END_OF_STEP_WAIT(S);        /* interval 4T+3, group 1: LOAD part */         \
+            RAW_BARRIER();                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+            __builtin_amdgcn_s_setprio(1);                                                                     \
+            _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+                    acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);                  \
+            __builtin_amdgcn_s_setprio(0);                                                                     \
+            if (kk == 1 && g == 0) END_OF_STEP_WAIT(S);        /* interval 4T+3, group 0: MFMA part */         \
+            RAW_BARRIER();                                                                                     \
+        }                                                                                                      \
+    }
+
+    int vb = blockIdx.x;
+    SETUP_TILE(vb);
+    bool stores16 = false;                                 // the tile before this one issued exactly 16 stores per thread
+    while (vb < n_tiles) {
+        const int cur_ch0 = ch0, cur_n0 = n0, cur_tsel = tsel;
+        accv acc[TI][TP];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+        // weight stages 0, 1 and the A / B pieces of chunk 0 have landed.  The previous tile's 16 output stores per thread were
+        // issued BEHIND them (vmcnt retires in order): a full tile leaves them in flight, a ragged one (some stores skipped:
+        // the count is not known) and the dynamic-exit form drain everything.
+        if (IMAP || !stores16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        RAW_BARRIER();
+        if (g == 1) RAW_BARRIER();                         // stagger
+        half8 af[TI], bf[4];
+        for (int chunk = 0; chunk < nC; ++chunk) {
+            const bool last = chunk + 1 == nC;
+            const int c32 = chunk * 32;
+            S2_STEP(0) S2_STEP(1) S2_STEP(2) S2_STEP(3) S2_STEP(4) S2_STEP(5) S2_STEP(6) S2_STEP(7) S2_STEP(8)
+        }
+        if (g == 0) RAW_BARRIER();                         // both groups aligned: every wave is done with the stages and the patch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // ---- next tile's first weight stages and A / B pieces; they land during the epilogue below ----
+        const int nvb = vb + (int)gridDim.x;
+        if (nvb < n_tiles) SETUP_TILE(nvb);
+
+        // ---- epilogue of the current tile: BN + ReLU on the accumulators, fp16 through LDS, 32 KB per channel half,
+        //      two rounds of 128 pixels (conv_igemm_wide_persist's, with this kernel's tile-pixel order) ----
+        {
+            char* const E = smem + G::E_OFF + g * 32768;
+            const int tl = tid & 255;
+            const int chl = cur_ch0 + 128 * g;              // launch-wide channel of this half's channel 0 (BN table index)
+            _Float16* outp = a.out;
+            int oc = a.Cout, chg = chl;
+            if (a.wgt_b) {
+                if (chl >= split) { outp = a.out_b; oc = a.Cout - split; chg = chl - split; }
+                else oc = split;
+            }
+            const int k = tl & 15;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr) lds_barrier();                      // round 0's reads are done
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c4 = chl + wc * 64 + 16 * i + 4 * kq;
+                    const f32x4_e sc = *(const f32x4_e*)(bn_scale + c4), bi = *(const f32x4_e*)(bn_bias + c4);
+                    const int cq = wc * 8 + 2 * i + (kq >> 1);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int p = wp * 64 + jj * 16 + l16;                   // pixel inside the round
+                        half4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][4 * rr + jj][e] * sc[e] + bi[e];
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            o[e] = a16_from_f32<BF>(v);
+                        }
+                        *(half4*)(E + p * 256 + ((cq ^ l16) << 4) + (((kq ^ jj) & 1) << 3)) = o;
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {            // (two batches of four: the next tile's DMA sources stay in registers)
+                    half8_e o8[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int pl = (tl >> 4) + 16 * (4 * hb + it);
+                        o8[it] = *(const half8_e*)(E + pl * 256 + ((k ^ (pl & 15)) << 4));
+                    }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int pl = (tl >> 4) + 16 * (4 * hb + it);
+                        const int p = (pl >> 6) * 128 + rr * 64 + (pl & 63);     // tile pixel
+                        int n = cur_n0 + G::p_img(p);
+                        if constexpr (IMAP) n = row_tabs[cur_tsel * 16 + G::p_img(p)];      // tensor row, -1 beyond N
+                        else if (n >= a.N) n = -1;
+                        if (n < 0) continue;
+                        half8_e v = o8[it];
+                        if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+                        *(half8_e*)(outp + ((size_t)n * (TW * TW) + G::p_oy(p) * TW + G::p_ox(p)) * oc + chg + 8 * k) = v;
+                    }
+                }
+            }
+        }
+        stores16 = cur_n0 + IMGS <= a.N;
+        vb = nvb;
+    }
+#undef S2_STEP
+#undef END_OF_STEP_WAIT
+#undef WAIT_VM
+#undef RAW_BARRIER
+#undef SETUP_TILE
+#undef ISSUE_P
+#undef ISSUE_W
+}
+
+int& opt_conv_s2() { static int v = 1; return v; }
+
+// Shapes this kernel takes: 3x3 / stride 2 / pad 1, 32x32 -> 16x16, 16x16 -> 8x8 or 8x8 -> 4x4, Cout % 256 == 0 (both convs of
+// a pair together), BN + ReLU epilogue.
+bool conv_takes_s2_kernel(int ksize, int stride, int pad, int cin, int cout, int h, int w, int ho, int wo) {
+    return ksize == 3 && stride == 2 && pad == 1 && cin % 32 == 0 && cout % 256 == 0 && cout <= S2_BN_MAX && ho == wo &&
+           (ho == 16 || ho == 8 || ho == 4) && h == 2 * ho && w == 2 * wo;
+}
+
+template <int TW>
+static int launch_s2(const ConvArgs& a, int n_cu, hipStream_t s) {
+    using G = S2Geom<TW>;
+    const long tiles = (long)((a.N + G::IMGS - 1) / G::IMGS) * (a.Cout / 256);
+    if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
+    const dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(512);
+#define S2_LAUNCH(BF_, IMAP_) hipLaunchKernelGGL((conv3x3_s2_kernel<TW, BF_, IMAP_>), grid, block, 0, s, a, (int)tiles)
+    if (a.imap) { if (a.bf16) S2_LAUNCH(true, true); else S2_LAUNCH(false, true); }
+    else { if (a.bf16) S2_LAUNCH(true, false); else S2_LAUNCH(false, false); }
+#undef S2_LAUNCH
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
+// BMI_ERR_UNSUPPORTED -> the caller goes on to conv_igemm_wide / conv_igemm.  The minimum-grid rule looks at the engine's
+// FULL-CHUNK image count (ConvArgs::n_ref), never at the samples of this launch, like conv3x3_pw's: a t-shard runs the same
+// kernel as the single-rank run and gets the same bits ("conv_s2" = 2 drops the rule: tests).
+int launch_conv3x3_s2(const ConvArgs& a_in, hipStream_t s) {
+    if (!opt_conv_s2() || a_in.in_bits || a_in.in2 || a_in.partial || !conv_epilogue_is_plain(a_in)) return BMI_ERR_UNSUPPORTED;
+    if (!conv_takes_s2_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout, a_in.H, a_in.W, a_in.Ho, a_in.Wo)) return BMI_ERR_UNSUPPORTED;
+    ConvArgs a = a_in;
+    if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
+    if (a.wgt_b && (!a.out_b || a.split <= 0 || a.split >= a.Cout || a.split % 128 != 0)) return BMI_ERR_INVALID;
+    // 32-bit byte offsets inside a buffer descriptor: a tile's own images (always), the whole tensor for the dynamic-exit form
+    if (a.imap && (size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;
+    if (a.in_mod < a.N && !a.imap) return BMI_ERR_UNSUPPORTED;      // (a plain conv on a deterministic input runs once per batch: N == in_mod)
+    if ((size_t)a.H * a.W * a.Cin >= (1u << 24)) return BMI_ERR_UNSUPPORTED;
+    static const int n_cu = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+        return cu > 0 ? cu : 256;
+    }();
+    if (opt_conv_s2() != 2) {
+        const int imgs = 256 / (a.Ho * a.Wo), n_sel = a.n_ref > 0 ? a.n_ref : a.N;
+        if ((long)((n_sel + imgs - 1) / imgs) * (a.Cout / 256) < 3 * n_cu / 4) return BMI_ERR_UNSUPPORTED;
+    }
+    a.xcd_split = xcd_split_for(a.Cout / 256, (size_t)a.Cout * 9 * a.Cin * 2);
+    return a.Ho == 16 ? launch_s2<16>(a, n_cu, s) : (a.Ho == 8 ? launch_s2<8>(a, n_cu, s) : launch_s2<4>(a, n_cu, s));
+}

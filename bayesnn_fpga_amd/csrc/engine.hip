@@ -122,6 +122,11 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int* family) {
         const int rc = launch_conv1x1_stream(a, s);
         if (rc != BMI_ERR_UNSUPPORTED) return rc;
     }
+    {
+        *family = BMI_CONV_FAMILY_S2;
+        const int rc = launch_conv3x3_s2(a, s);
+        if (rc != BMI_ERR_UNSUPPORTED) return rc;
+    }
     if (opt_conv_wide()) {
         *family = BMI_CONV_FAMILY_WIDE;
         const int rc = launch_conv_igemm_wide(a, s);
@@ -188,6 +193,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_pw") == 0) {
         if (value < 0 || value > 2) return BMI_ERR_INVALID;
         opt_conv_pw() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "conv_s2") == 0) {
+        if (value < 0 || value > 2) return BMI_ERR_INVALID;
+        opt_conv_s2() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_wide") == 0) {
@@ -674,7 +684,10 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 p.out_b = (_Float16*)(ws + e->tensors[op.pair_d.out].offset);
                 p.split = op.cout;
                 p.Cout = op.cout + op.pair_cout;
-                const int rc = launch_conv_igemm_wide(p, s);
+                int rc = launch_conv3x3_s2(p, s);
+                prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
+                if (rc != BMI_ERR_UNSUPPORTED) return rc;
+                rc = launch_conv_igemm_wide(p, s);
                 prof.tag(BMI_CONV_FAMILY_WIDE, flops, bytes);
                 if (rc != BMI_ERR_UNSUPPORTED) return rc;
                 ConvArgs q = a;          // not taken after all: two plain launches
@@ -937,7 +950,8 @@ int bmi_conv_pair_fwd(const void* in, const void* weight_a, const float* scale_a
     a.M = n * a.Ho * a.Wo;
     a.B = n; a.out_mul = 1.f;
     a.site = resolve_site(nullptr, 0, 0);
-    return launch_conv_igemm_wide(a, (hipStream_t)stream);
+    const int rc = launch_conv3x3_s2(a, (hipStream_t)stream);      // the engine's order: conv3x3_s2 where it applies, else conv_igemm_wide
+    return rc != BMI_ERR_UNSUPPORTED ? rc : launch_conv_igemm_wide(a, (hipStream_t)stream);
 }
 
 int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2, const void* weight2, const float* bias,

@@ -92,6 +92,8 @@ int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s);  // 256x256 tiles;
 bool conv_takes_wide_kernel(int cin, int cout);
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s);   // BMI_ERR_UNSUPPORTED -> use conv_igemm
 int launch_conv3x3_pw(const ConvArgs& a, hipStream_t s);      // 8x8 / 4x4 maps, Cout % 256 == 0; BMI_ERR_UNSUPPORTED -> conv3x3_patch
+int launch_conv3x3_s2(const ConvArgs& a, hipStream_t s);      // 3x3 stride-2 convs, plain epilogue (pair mode too); BMI_ERR_UNSUPPORTED -> conv_igemm_wide
+bool conv_takes_s2_kernel(int ksize, int stride, int pad, int cin, int cout, int h, int w, int ho, int wo);
 int launch_conv(const ConvArgs& a, hipStream_t s, int* family = nullptr);   // picks the kernel; *family = BMI_CONV_FAMILY_*
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int bf16, hipStream_t s);
@@ -119,6 +121,7 @@ int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
 int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
 int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
 int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
+int& opt_conv_s2();            // 1: plain 3x3 stride-2 convs run in conv3x3_s2 (2 = without its minimum-grid rule: tests), 0: conv_igemm_wide
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
 int& opt_splitk();             // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch
 int& opt_dense_exact();        // 1: hidden dense layers on the exact-f32 MFMA instead of the split-fp16 form

@@ -56,29 +56,48 @@ class FullAnalysis:
             self.sdn_get_detailed_results()
 
     # -- device side -------------------------------------------------------------------------
+    def _batch_call(self):
+        """(T, seed, cnt0) of the next batch, then the bookkeeping the reference's T forwards would have done.
+        Masksembles layers keep ONE counter per layer that carries over from batch to batch and from evaluate() into
+        this run (SA/utils.py:165-169, :228-230): pass i of this batch uses mask (cnt + i) mod M with the layers'
+        CURRENT cnt.  (The Philox sample index restarts at 0 for every batch; the batch index is part of the seed.)"""
+        ml = self.model.mask_layers()
+        call = (self.mc_passes, self.seed + self._batch_index, ml[0].cnt if ml else 0)
+        self.model.advance(self.mc_passes)
+        return call
+
     def _predict(self, b_x):
         """T folded passes on the GPU -> dict of float64 numpy arrays [E,B,C]."""
         eng = self.model.engine(b_x.device, max_batch=b_x.shape[0])
-        # Masksembles layers keep ONE counter per layer that carries over from batch to batch and from evaluate() into
-        # this run (SA/utils.py:165-169, :228-230): pass i of this batch uses mask (cnt + i) mod M with the layers'
-        # CURRENT cnt.  (The Philox sample index restarts at 0 for every batch; the batch index is part of the seed.)
-        ml = self.model.mask_layers()
-        r = eng.predict(b_x, self.mc_passes, seed=self.seed + self._batch_index, t_begin=0, cnt0=ml[0].cnt if ml else 0)
-        self.model.advance(self.mc_passes)
+        T, seed, cnt0 = self._batch_call()
+        r = eng.predict(b_x, T, seed=seed, t_begin=0, cnt0=cnt0)
         return {k: v.cpu().numpy() for k, v in r.items()}
+
+    def _make_pipe(self, device, max_batch):
+        """Two engines / streams for the batch loop, with the model's engine settings (``model.engine_dtype``, an explicit
+        chunk size of its cached engine) like ``model.engine()`` would build them."""
+        from ..engine import BatchesInFlight
+        old = getattr(self, "_pipe", None)
+        if old is not None:
+            old.synchronize()        # a batch may still be queued on the engines that are about to be destroyed
+        dtype = getattr(self.model, "engine_dtype", None) or "f16"
+        cached = getattr(self.model, "_engines", {}).get(f"{device}/{dtype}")
+        chunk = cached.chunk_samples if cached is not None and cached.chunk_explicit else None
+        self._pipe = BatchesInFlight(self.model, device, n=2, max_batch=max_batch, dtype=dtype, chunk_samples=chunk)
+        return self._pipe
 
     def _predict_async(self, b_x):
         """The same call queued on one of two engines / streams (engine.BatchesInFlight): returns the DEVICE tensors; the caller
         converts them after it has queued the next batch, so that batch's launch-bound prefix and this batch's host-side
         collation both overlap the GPU work.  Results are bit for bit those of _predict."""
-        from ..engine import BatchesInFlight
-        if getattr(self, "_pipe", None) is None or self._pipe.device != b_x.device or self._pipe.engines[0].max_batch < b_x.shape[0]:
-            self._pipe = BatchesInFlight(self.model, b_x.device, n=2, max_batch=b_x.shape[0])
-        ml = self.model.mask_layers()
-        T, seed, cnt0 = self.mc_passes, self.seed + self._batch_index, (ml[0].cnt if ml else 0)
-        r = self._pipe.submit(lambda eng: eng.predict(b_x, T, seed=seed, t_begin=0, cnt0=cnt0), inputs=(b_x,))
-        self.model.advance(self.mc_passes)
-        return r, self._pipe.last_stream
+        pipe = getattr(self, "_pipe", None)
+        if pipe is None or pipe.device != b_x.device or pipe.engines[0].max_batch < b_x.shape[0]:
+            # sized once from the loader's batch size where it says so (a smaller last batch reuses the engines)
+            want = max(b_x.shape[0], int(getattr(getattr(self, "_cur_loader", None), "batch_size", 0) or 0))
+            pipe = self._make_pipe(b_x.device, want)
+        T, seed, cnt0 = self._batch_call()
+        r = pipe.submit(lambda eng: eng.predict(b_x, T, seed=seed, t_begin=0, cnt0=cnt0), inputs=(b_x,))
+        return r, pipe.last_stream
 
     def _predict_deferred(self, b_x):
         """Queues the batch and returns a zero-argument function that waits for it and gives _predict's numpy dict."""
@@ -103,14 +122,8 @@ class FullAnalysis:
         return output, output_sm, prob_mean, ens_out, ens_sm
 
     def _get_output(self, b_x):
-        r = self._predict(b_x)
-        self.last_var = r["var"]
-        logit_mean, prob_mean = r["logit_mean"], r["mean"]
-        output = [torch.from_numpy(a) for a in logit_mean]
-        output_sm = [torch.from_numpy(a) for a in prob_mean]
-        ens_out = [torch.from_numpy(a) for a in exit_ensembles(logit_mean)]
-        ens_sm = [torch.from_numpy(a) for a in exit_ensembles(prob_mean)]
-        return output, output_sm, prob_mean, ens_out, ens_sm
+        """The reference's 5-tuple (results_analyzer.py:236-270) for one batch."""
+        return self._outputs_from(self._predict(b_x))
 
     # -- host collation ------------------------------------------------------------------------
     @staticmethod
@@ -139,7 +152,10 @@ class FullAnalysis:
         labels = np.zeros((n, C))
         trackers = [[(set(), set(), {}, {}) for _ in range(n_exits)] for _ in range(2)]
         off = 0
+        if getattr(self, "_pipe", None) is not None:
+            self._pipe.synchronize()
         self._pipe = None            # engines snapshot the weights when they are built: a fresh pair per collection run
+        self._cur_loader = loader
 
         def queued(it):
             """(result getter, labels) of each batch, one batch behind the one being queued (two batches in flight)."""

@@ -14,8 +14,9 @@ engine.BatchesInFlight): the launch-bound once-per-batch prefix of step k+1 runs
 does all of its own work inside the timed region and its results are bit for bit the one-stream ones.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3          # starts its 8 rank processes itself (fresh children, torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
-        bench.py --gpus 8 --steps 10 --warmup 3
+        bench.py --gpus 8 --steps 10 --warmup 3             # or under a launcher: RANK / LOCAL_RANK / WORLD_SIZE from the env
 
 Prints ONE JSON line (rank 0).  `roofline` is the DOMINANT kernel family of the step (the conv family with the largest
 share of the step time: conv3x3_pw / conv_igemm_wide / conv3x3_patch / conv_igemm): algorithmic FLOPs (or, where the HBM
@@ -113,7 +114,7 @@ def hbm_traffic(workload, launches_per_step, family=None):
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     if not os.path.exists(path):
         return None, None
-    allk = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw", "conv1x1_stream"))}
+    allk = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw", "conv3x3_s2", "conv1x1_stream"))}
     n_all = sum(v["launches"] for v in allk.values())
     if n_all == 0 or n_all % launches_per_step:
         return None, None                   # collected for another batch / T / chunking: do not quote it
@@ -231,13 +232,35 @@ def cpu_baseline(wl, batch, T, seed):
     return batch * T / dt, best, r["mean"], sweep
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: start the N rank processes ourselves — fresh children through
+    torch.distributed.run, one per GPU, rendezvous on 127.0.0.1 — relay their output (rank 0 prints the JSON line) and exit
+    with their code.  Nothing in THIS process has touched the GPU (no torch.cuda call, no HIP call), and it never re-execs
+    itself: the children are ordinary subprocesses."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes needs it on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
     if a.share_gpu and a.backend == "nccl":
         raise SystemExit("--share-gpu is the 1-GPU dry run of the N>1 path and needs --backend gloo")
     if not torch.cuda.is_available():

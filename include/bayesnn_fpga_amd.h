@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BMI_VERSION 200
+#define BMI_VERSION 300
 
 #define BMI_OK 0
 #define BMI_ERR_INVALID (-22)      /* EINVAL: bad descriptor / argument            */
@@ -152,6 +152,9 @@ const char* bmi_error_string(int code);
  *   "conv_stream"                           0 | 1 | 2 (= 1 without the minimum-grid rule and for plain launches too: tests) | 3 (= 1 with the
  *                                           256-pixel tile: A/B): HBM-bound 1x1 convs (Cin <= 512; with a residual, or Cout % 256 != 0) run
  *                                           in conv1x1_stream (128 x 128 tile, three or four workgroups per CU) instead of conv_igemm_wide
+ *   "conv_s2"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-2 convs with a BN + ReLU epilogue on
+ *                                           32x32 / 16x16 / 8x8 maps with Cout % 256 == 0 (a pair's channels together) run in conv3x3_s2 (input
+ *                                           patch resident in LDS as four parity planes, persistent) instead of conv_igemm_wide
  *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
  *   "splitk"                                0 | 1, read by bmi_plan: 3x3 convs of the once-per-batch prefix whose grid is <= 64 tiles (VGG's convs on
  *                                           2x2 maps) run split-K: one workgroup per (tile, tap), fp32 partial sums, a finishing pass
@@ -219,7 +222,8 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
 #define BMI_CONV_FAMILY_IGEMM 2 /* conv_igemm_kernel */
 #define BMI_CONV_FAMILY_PW 3    /* conv3x3_pw_kernel */
 #define BMI_CONV_FAMILY_STREAM 4 /* conv1x1_stream_kernel */
-#define BMI_CONV_FAMILIES 5
+#define BMI_CONV_FAMILY_S2 5    /* conv3x3_s2_kernel */
+#define BMI_CONV_FAMILIES 6
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
                               double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]);
 

@@ -28,7 +28,7 @@ def test_bench_prints_the_contract_line():
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and rf["unit"] == "TFLOP/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 300 and rf["kernel"] in rf["by_kernel"]
     assert rf["all_conv_launches"]["frac"] > 0.3 and rf["whole_step"]["frac"] > 0.3
-    assert set(rf["by_kernel"]) >= {"conv3x3_patch_kernel", "conv_igemm_wide_kernel"}
+    assert set(rf["by_kernel"]) >= {"conv3x3_patch_kernel", "conv3x3_pw_kernel", "conv3x3_s2_kernel"}
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_mean_diff_gpu_vs_cpu"] < 1e-3
 
@@ -66,9 +66,45 @@ def test_two_rank_bench_equals_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_rejects_mismatched_world_size():
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell (no launcher, no WORLD_SIZE): bench.py starts its two rank processes
+    itself as fresh children and relays rank 0's ONE JSON line and the exit code.  Dry run on one GPU (gloo, both ranks on
+    cuda:0); the reduced mean equals the 1-rank run to 1e-12."""
+    import numpy as np
+    common = ["--steps", "1", "--warmup", "0", "--T", "8", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    f1, f2 = str(tmp_path / "m1.npy"), str(tmp_path / "m2.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--dump-mean", f1],
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", *common,
+                         "--dump-mean", f2], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    lines2 = [ln for ln in r2.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines2) == 1, "exactly one JSON line (rank 0) for the whole job"
+    d2 = json.loads(lines2[0])
+    assert d2["n_gpus"] == 2 and d2["steps"] == 1
+    np.testing.assert_allclose(np.load(f2), np.load(f1), rtol=0, atol=1e-12)
+
+
+def test_bench_self_launch_starts_n_ranks_without_a_launcher():
+    """CPU box: the launch mechanics alone.  `bench.py --gpus 2` with no WORLD_SIZE in the environment must start two rank
+    processes (each then refuses to run without a GPU: the HIP path has no CPU fallback) and pass their failure on."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by test_bench_launches_its_own_ranks on a GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert out.count("bench.py needs an MI355X") == 2, out[-3000:]
+
+
+def test_bench_rejects_a_launcher_whose_world_size_differs():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 

@@ -54,6 +54,27 @@ def test_device_exit_equals_posthoc_rule_on_the_full_run(name):
             assert (got == 3).all() and act[2] == B
 
 
+@pytest.mark.parametrize("B,chunk", [(1, None), (4, None), (11, None), (45, 6)])
+def test_device_exit_on_small_batches(B, chunk):
+    """Batches whose full-chunk grid is too small for conv3x3_pw (B <= 11 with the default chunk, or an explicit small chunk)
+    run the fused-shortcut conv2 of layer3 / layer4 in conv3x3_patch; after the first tested exit the launches carry a row
+    table and need that kernel's IMAP instantiations on 8x8 and 4x4 maps too (round-2 advisor finding: BMI_ERR_UNSUPPORTED
+    at B = 1).  A threshold that keeps some images active past every tested exit."""
+    T, seed = 6, 5
+    m = build_seeded(ResNet18MCEarlyExit, KWS["mc_block_exit"])
+    synthetic_weights_(m, 0)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B, chunk_samples=chunk)
+    x = synthetic_images(B, seed=33).to(DEV)
+    p_full = eng.predict(x, T, seed=seed)["mean"].cpu().numpy()
+    conf = p_full.max(-1)
+    for thr in (float(conf[1:3].max()) + 1e-6, float(np.median(conf[2])), float(conf[1].min()) - 1e-6):
+        want = cex.exit_layer(p_full.copy(), thr)
+        r = eng.predict_with_exit(x, T, thr, seed=seed)
+        np.testing.assert_array_equal(r["exit_layer"].cpu().numpy(), want)
+        np.testing.assert_allclose(r["best_preds"].cpu().numpy(), p_full[want, np.arange(B)], rtol=0, atol=1e-13)
+    assert (cex.exit_layer(p_full.copy(), float(conf[1:3].max()) + 1e-6) == 3).all()     # the first threshold sent nobody out early
+
+
 def test_dynamic_exit_needs_all_samples_in_one_chunk():
     m = build_seeded(ResNet18MCEarlyExit, KWS["mc_block_exit"])
     synthetic_weights_(m, 0)

@@ -468,10 +468,12 @@ def test_mask_apply_lane_shared_philox(p, in_stoch):
 
 
 @pytest.mark.parametrize("name,n", [("D3", 2111), ("D4", 4500), ("P4", 9001)])
-def test_conv_wide_persistent_kernel(name, n):
+def test_conv_wide_persistent_kernel(name, n, request):
     """More than 2 tiles per CU: the plain wide-tile launches run the persistent kernel (one workgroup per CU walks over
     the tiles, the next tile's first K-step lands during the epilogue).  Ragged last tile, bit-exact repeatability."""
     cin, cout, H, k, s, p = SHAPES[name]
+    _lib.set_option("conv_s2", 0)                # (the plain 3x3 stride-2 launches are conv3x3_s2's by default: tests/test_conv3x3_s2.py)
+    request.addfinalizer(lambda: _lib.set_option("conv_s2", 1))
     x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, n, 17, False)
     ho = (H + 2 * p - k) // s + 1
     tiles = -(-n * ho * ho // 256) * (cout // 256)
@@ -484,8 +486,10 @@ def test_conv_wide_persistent_kernel(name, n):
     assert torch.equal(out, gh.run_conv(x, w, scale, bias, None, True, s, p, n, n, 1))
 
 
-def test_conv_pair_persistent_kernel():
+def test_conv_pair_persistent_kernel(request):
     lib = _lib.lib()
+    _lib.set_option("conv_s2", 0)                # conv_igemm_wide's pair mode (conv3x3_s2's: tests/test_conv3x3_s2.py)
+    request.addfinalizer(lambda: _lib.set_option("conv_s2", 1))
     cin, ca, cb, H, k, s, p, n = 64, 128, 128, 32, 3, 2, 1, 600          # 600 tiles of 256 pixels
     g = _gen(8)
     x = torch.randn(n, H, H, cin, generator=g).to(torch.float16).to(DEV)

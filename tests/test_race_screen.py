@@ -39,9 +39,25 @@ def test_repeat_launches_are_bit_identical_under_memory_traffic(mfma_shape):
     for k in ("mfma_shape_patch", "mfma_shape_wide"):
         _lib.set_option(k, mfma_shape)
     _lib.set_option("conv_pw", 1)
+    _lib.set_option("conv_s2", 0)                # the plain stride-2 shapes of this list screen conv_igemm_wide; conv3x3_s2 below
     try:
         bad = race_screen.screen(SHAPES, rounds=24, verbose=True)
     finally:
         for k in ("mfma_shape_patch", "mfma_shape_wide"):
             _lib.set_option(k, 0)
+        _lib.set_option("conv_s2", 1)
+    assert bad == 0, f"{bad} launches differed from the first launch of the same inputs"
+
+
+# conv3x3_s2 (persistent, patch planes refilled in place behind counted waits): fewer tiles than CUs, a few tiles per CU, many;
+# one to four channel tiles; 2, 4 and 8 channel chunks
+S2_SHAPES = [
+    (64, 256, 32, 3, 2, 1, 230), (64, 256, 32, 3, 2, 1, 1500), (128, 256, 16, 3, 2, 1, 1000), (128, 512, 16, 3, 2, 1, 3001),
+    (256, 512, 8, 3, 2, 1, 1800), (256, 1024, 8, 3, 2, 1, 5003), (256, 512, 8, 3, 2, 1, 12000),
+]
+
+
+def test_s2_repeat_launches_are_bit_identical_under_memory_traffic():
+    import race_screen
+    bad = race_screen.screen(S2_SHAPES, rounds=24, verbose=True)
     assert bad == 0, f"{bad} launches differed from the first launch of the same inputs"

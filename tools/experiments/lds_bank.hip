@@ -27,6 +27,12 @@ __device__ int addr_of(int tid) {
         case 14: { int ch = tid & 7, row = tid >> 3; return row * 128 + ((ch ^ (row & 7)) << 4); }
         case 15: { int row = tid & 31, ch = tid >> 5; return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }   // lanes walk rows
         case 16: { int row = tid & 31, ch = tid >> 5; return row * 144 + ch * 16; }
+        // 64-byte rows, 16x16x32 fragments (lane = l16 + 16 kq: row / 4x4-block pixel l16, 16-byte chunk kq) — conv3x3_pw
+        case 20: { int l16 = lane & 15, kq = lane >> 4; return l16 * 64 + (((kq + (l16 >> 2)) & 3) << 4); }                  // weights, round-2 rotation
+        case 21: { int l16 = lane & 15, kq = lane >> 4; return l16 * 64 + ((kq ^ (((l16 >> 2) & 1) << 1)) << 4); }           // weights, xor 2*(row>>2 & 1)
+        case 22: { int l16 = lane & 15, kq = lane >> 4; return ((l16 >> 2) * 12 + (l16 & 3) + 13) * 64 + (((kq + (l16 >> 2) + 1) & 3) << 4); }   // patch tap (1,1), rotation
+        case 23: { int l16 = lane & 15, kq = lane >> 4; int y = (l16 >> 2) + 1; return (y * 12 + (l16 & 3) + 1) * 64 + ((kq ^ ((y & 1) << 1)) << 4); }   // patch tap (1,1), xor 2*(y & 1)
+        case 24: { int l16 = lane & 15, kq = lane >> 4; int y = (l16 >> 2) + 1; return (y * 9 + (l16 & 3) + 1) * 64 + ((kq ^ ((y & 1) << 1)) << 4); }    // the same on an odd pitch (9 cells)
     }
     return 0;
 }
@@ -58,6 +64,7 @@ int main() {
     (void)hipMalloc(&d, 1024 * 256 * 4);
 #define RUN(V, W) hipLaunchKernelGGL((probe<V, W>), dim3(256), dim3(256), 0, 0, d);
     RUN(0, false) RUN(1, false) RUN(2, false) RUN(3, false) RUN(4, false) RUN(5, false) RUN(6, false) RUN(7, false)
+    RUN(20, false) RUN(21, false) RUN(22, false) RUN(23, false) RUN(24, false)
     RUN(10, true) RUN(11, true) RUN(12, true) RUN(13, true) RUN(14, true) RUN(15, true) RUN(16, true)
     (void)hipDeviceSynchronize();
     printf("done\n");
