@@ -46,6 +46,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 #define S2_BN_MAX 1024
 
+// Timing probes (tools/ab_build.py name:-DS2_ABL_...=1; wrong results by construction, never in the product build): which part of a
+// tile's life the time goes to.
+#ifndef S2_ABL_NOPATCH
+#define S2_ABL_NOPATCH 0     // no patch DMA (the main loop reads whatever is in LDS)
+#endif
+#ifndef S2_ABL_NOSTORE
+#define S2_ABL_NOSTORE 0     // the epilogue runs but stores nothing
+#endif
+#ifndef S2_ABL_NOEPI
+#define S2_ABL_NOEPI 0       // no epilogue at all (one accumulator element per lane is stored so the MFMAs stay live)
+#endif
+
 // TW = OUTPUT map size (TW x TW; the input map is 2 TW x 2 TW): 16, 8 or 4.
 template <int TW>
 struct S2Geom {
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             const int row_ = row_tabs[tsel * 16 + ((pre[K] >> 24) & 15)];                                    \
             o_ = (pre[K] == OOB || row_ < 0) ? OOB : 2u * ((unsigned)row_ * HWC + (pre[K] & 0xffffffu));     \
         }                                                                                                    \
-        BLDS16(rs_in, o_, __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0)), pbuf + ((K) * 512 + wave * 64) * 16); \
+        if (!S2_ABL_NOPATCH) BLDS16(rs_in, o_, __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0)), pbuf + ((K) * 512 + wave * 64) * 16); \
     }
     // Tile VB: its buffer descriptors; its first two weight stages and the pieces that hold planes A / B only (chunk 0) are
     // issued: everything the first K-steps read.
@@ -359,7 +371,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 
         // ---- epilogue of the current tile: BN + ReLU on the accumulators, fp16 through LDS, 32 KB per channel half,
         //      two rounds of 128 pixels (conv_igemm_wide_persist's, with this kernel's tile-pixel order) ----
-        {
+        if (S2_ABL_NOEPI) {
+            float sum_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) sum_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (sum_ == 12345.678f) a.out[tid] = (_Float16)sum_;
+        } else {
             char* const E = smem + G::E_OFF + g * 32768;
             const int tl = tid & 255;
             const int chl = cur_ch0 + 128 * g;              // launch-wide channel of this half's channel 0 (BN table index)
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                         int n = cur_n0 + G::p_img(p);
                         if constexpr (IMAP) n = row_tabs[cur_tsel * 16 + G::p_img(p)];      // tensor row, -1 beyond N
                         else if (n >= a.N) n = -1;
-                        if (n < 0) continue;
+                        if (n < 0 || S2_ABL_NOSTORE) continue;
                         half8_e v = o8[it];
                         if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
                         *(half8_e*)(outp + ((size_t)n * (TW * TW) + G::p_oy(p) * TW + G::p_ox(p)) * oc + chg + 8 * k) = v;

@@ -161,7 +161,8 @@ class FullAnalysis:
             """(result getter, labels) of each batch, one batch behind the one being queued (two batches in flight)."""
             pending = None
             for self._batch_index, batch in enumerate(it):
-                b_x = batch[0].to(self.device)
+                b_x = batch[0].to(self.device, non_blocking=True)     # asynchronous from a pinned loader batch; ordered before the
+                                                                      # batch's launches by submit()'s wait on this stream
                 nxt = (self._predict_deferred(b_x), batch[1].cpu().numpy().astype(np.int64))
                 if pending is not None:
                     yield pending

@@ -95,6 +95,9 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches in flight: consecutive steps alternate between this many engines / streams (engine.BatchesInFlight), so "
                          "the once-per-batch prefix of step k+1 runs beside the suffix of step k; 1 = one stream")
+    ap.add_argument("--graph", action="store_true",
+                    help="each batch step (zero, prefix, suffix chunks, finalize) is ONE hipGraph replay (engine.BatchesInFlight.predict_graphed): "
+                         "takes the launch floor out of the launch-bound small-model configs (VGG-11); single rank only")
     ap.add_argument("--dump-mean", default="", help="rank 0 writes the final predictive mean [E,B,C] float64 to this .npy (tests)")
     return ap.parse_args()
 
@@ -309,8 +312,13 @@ def main():
         accumulate_sharded(lambda buf, t0, n: e.accumulate(x, buf, t0, n, a.seed), S, T)
         return e.finalize(S, T)
 
+    if a.graph and world > 1:
+        raise SystemExit("--graph captures a whole single-rank batch step; the sharded path issues its all-reduce eagerly")
+
     def step():
         # one step = one batch through the whole path; consecutive steps alternate between the engines / streams of `pipe`
+        if a.graph:
+            return pipe.predict_graphed(x, T, a.seed)
         i = pipe.slot()
         return pipe.submit(lambda e: one_batch(e, Ss[i]))
 
@@ -365,7 +373,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
-                       "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight,
+                       "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight, "hipgraph": bool(a.graph),
                        "sharding": f"T over {world} rank(s), one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
             "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),
@@ -393,7 +401,8 @@ def main():
             dom_traffic, _ = (hbm_traffic(a.workload, max(alg_launches, 1), dom) if traffic is not None else (None, None))
             hbm_bound = d["bound"] == "hbm"
             line["roofline"] = {
-                "bound": d["bound"], "kernel": dom,
+                "bound": d["bound"], "kernel": dom, "dominant_by": "hip_event_ms (the conv family with the most device time in the profiled step; "
+                                                                   "quote whole_step.frac when comparing rounds)",
                 "achieved": d["hbm_gbs_algorithmic"] if hbm_bound else d["achieved"],
                 "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": d["hbm_frac"] if hbm_bound else d["frac"],

@@ -183,6 +183,29 @@ def test_hipgraph_capture_and_replay():
             assert torch.equal(out_static[k], eager[k]), k
 
 
+def test_batches_in_flight_graphed_equals_eager():
+    """BatchesInFlight.predict_graphed: a batch step as one hipGraph replay per slot — VGG-11 (the launch-bound config) and
+    ResNet-18, two slots, repeated batches, a smaller last batch (captured on first sight), another seed (its own graph):
+    every result equals the eager engine.predict bit for bit."""
+    from bayesnn_fpga_amd.engine import BatchesInFlight
+    from bayesnn_fpga_amd.models.extra import VGG11MC
+    for cls, kw, T in ((VGG11MC, dict(num_bayes_layer=3, dropout_p=0.25, out_dim=10), 5),
+                       (ResNet18MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10), 3)):
+        model = _product(cls, kw)
+        B = 6
+        pipe = BatchesInFlight(model, torch.device(DEV), n=2, max_batch=B)
+        eager = model.engine(torch.device(DEV), max_batch=B)
+        xs = [synthetic_images(B, seed=40 + i).to(DEV) for i in range(5)] + [synthetic_images(4, seed=50).to(DEV)]
+        for i, x in enumerate(xs):
+            seed = 7 if i != 3 else 8
+            out = pipe.predict_graphed(x, T, seed)
+            pipe.last_stream.synchronize()
+            want = eager.predict(x, T, seed=seed)
+            for k in ("mean", "var", "logit_mean"):
+                assert torch.equal(out[k], want[k]), (cls.__name__, i, k)
+        assert len(pipe._graphs[0]) + len(pipe._graphs[1]) == 4       # (B, seed 7) on both slots, (B, seed 8), (4, seed 7)
+
+
 def test_engine_regrowth_rederives_the_default_chunk():
     """model.engine() grown from a small to a larger batch must not carry the small batch's samples-per-chunk over
     (that multiplied the workspace: 226 GiB at B=32 after a B=8 engine); an explicit chunk size sticks."""

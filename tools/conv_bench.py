@@ -21,6 +21,9 @@ SHAPES = {  # Cin, Cout, H, k, stride, pad
     "S2": (128, 128, 16, 3, 1, 1), "D3": (128, 256, 16, 3, 2, 1), "P3": (128, 256, 16, 1, 2, 0),
     "S3": (256, 256, 8, 3, 1, 1), "D4": (256, 512, 8, 3, 2, 1), "P4": (256, 512, 8, 1, 2, 0),
     "S4": (512, 512, 4, 3, 1, 1),
+    # the stride-2 launches of the ResNet-18 multi-exit suffix as the engine issues them (layerN[0].conv1 + the exit head's first
+    # conv as one pair launch = twice the channels)
+    "D2p": (64, 256, 32, 3, 2, 1), "D3p": (128, 512, 16, 3, 2, 1), "D4p": (256, 1024, 8, 3, 2, 1),
     # Bottleneck 1x1 convs of ResNet-50 (HBM-bound): expand (with residual in the network) and reduce
     "E2": (128, 512, 16, 1, 1, 0), "E3": (256, 1024, 8, 1, 1, 0), "E4": (512, 2048, 4, 1, 1, 0),
     "Q1": (256, 128, 32, 1, 1, 0), "R2": (512, 128, 16, 1, 1, 0), "R3": (1024, 256, 8, 1, 1, 0), "R4": (2048, 512, 4, 1, 1, 0),
@@ -43,7 +46,7 @@ def main():
     a = ap.parse_args()
     lib = _lib.lib()
     dev = "cuda:0"
-    names = [s for s in a.only.split(",") if s] or [k for k in SHAPES if k[0] not in "EQR"]
+    names = [s for s in a.only.split(",") if s] or [k for k in SHAPES if k[0] not in "EQR" and not k.endswith("p")]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     total_t = total_f = 0.0
     for name in names:
