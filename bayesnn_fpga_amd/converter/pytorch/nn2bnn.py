@@ -9,10 +9,19 @@
   does not import: ``test.ThreeLayerNet`` is missing, :5); this mirror implements the evident intent,
   ``sum(pred) / len(pred)``.
 
-What the engine accepts after conversion: a (nested) ``nn.Sequential`` CNN on 3x32x32 inputs made of
-Conv2d [+BatchNorm2d] [+ReLU], MaxPool2d(2), AdaptiveAvgPool2d(1) / AvgPool2d over the whole map, Flatten, Linear
-(+ReLU), Dropout (identity in eval).  The mask of a wrapped Conv2d lands BEFORE its BatchNorm (an "inner" site of the
-C ABI, include/bayesnn_fpga_amd.h), the last Linear's mask multiplies the logits.  Anything else raises TypeError.
+What the engine accepts after conversion:
+
+* the package's own ResNet mirrors (``models.resnet18``: ``ResNet18Base``, the early-exit and MC variants) — the converter
+  recurses through them exactly as the reference's recurses through its own (``_convert_model`` on ``ResNet18Base``,
+  SA/models/resnet18/resnet18.py:189-204, is the pinned case): every conv of every BasicBlock, the 1x1 shortcut convs (which
+  then keep their own launch instead of riding in conv2) and the exit-head convs get a per-(image, channel) site between conv
+  and BatchNorm, every classifier an elementwise site on its logits (``engine.build_resnet_graph``);
+* a (nested) ``nn.Sequential`` CNN on 3x32x32 inputs made of Conv2d [+BatchNorm2d] [+ReLU], MaxPool2d(2),
+  AdaptiveAvgPool2d(1) / AvgPool2d over the whole map, Flatten, Linear (+ReLU), Dropout (identity in eval).
+
+The mask of a wrapped Conv2d lands BEFORE its BatchNorm (an "inner" site of the C ABI, include/bayesnn_fpga_amd.h), the last
+Linear's mask multiplies the logits.  Any other hand-written ``forward`` raises TypeError (compiling arbitrary Python needs a
+tracer, which is outside the path).
 """
 import torch
 from torch import nn
@@ -54,7 +63,9 @@ class MCDropout(EngineModelMixin, nn.Module):
         self.model = _convert_model(model, p)
         self.nSamples = nSamples
         self.p = p
-        self.n_exits = 1
+        self.resnet = getattr(self.model, "family", None) == "resnet"
+        self.multi_exit = bool(self.resnet and getattr(self.model, "multi_exit", True))
+        self.n_exits = 4 if self.multi_exit else 1
         linears = [m for m in self.model.modules() if isinstance(m, nn.Linear)]
         if not linears:
             raise TypeError("the engine needs a model that ends in nn.Linear")
@@ -65,18 +76,26 @@ class MCDropout(EngineModelMixin, nn.Module):
         return "nSamples: {}\nprobability: {}".format(self.nSamples, self.p)
 
     def forward(self, x):
+        """Training mode: one stochastic pass; eval mode: the mean of ``nSamples`` passes.  A converted ResNet mirror returns
+        what its reference forward returns — a LIST of logits, one per exit (``[out]`` for ``ResNet18Base``, :204) —, a
+        converted Sequential the logits tensor."""
         if self.training:
-            return EngineModelMixin.forward(self, x)[0]
+            out = EngineModelMixin.forward(self, x)
+            return out if self.resnet else out[0]
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise RuntimeError("bayesnn_fpga_amd models run on an MI355X through the HIP engine; got a CPU tensor "
                                "(there is no CPU fallback)")
         eng = self.engine(x.device, max_batch=x.shape[0])
         r = eng.predict(x, self.nSamples, seed=self.mc_seed, t_begin=self.mc_pass)
         self.advance(self.nSamples)
-        return r["logit_mean"][0].to(torch.float32)
+        mean = [r["logit_mean"][e].to(torch.float32) for e in range(self.n_exits)]
+        return mean if self.resnet else mean[0]
 
     # ---- graph of the converted model (engine.GraphBuilder) ------------------------------------------------
     def build_graph(self, g):
+        if self.resnet:
+            from ...engine import build_resnet_graph
+            return build_resnet_graph(self.model, g)
         if not isinstance(self.model, nn.Sequential):
             raise TypeError("the engine compiles converted nn.Sequential CNNs; got " + type(self.model).__name__)
         mods = _leaves(self.model)

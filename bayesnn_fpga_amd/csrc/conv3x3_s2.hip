@@ -20,7 +20,7 @@
 //   tile       = IMGS whole output maps (256 pixels: 1 map of 16x16, 4 of 8x8, 16 of 4x4) x 256 output channels
 //   waves      = 2 channel halves (g) x [2 (channels) x 2 (pixels)], wave tile 64 ch x 128 px = 4 x 8 tiles of v_mfma_f32_16x16x32;
 //                the 16 pixels of an MFMA tile are a 4 x 4 block of output pixels (conv3x3_pw's tile-pixel order)
-//   LDS        = [W0 | W1 | patch pieces | (pad) | W2] + BN table: three weight stages [256 ch][32 k] (64-byte rows), the patch as
+//   LDS        = [W0 | W1 (| W2) | patch pieces | (pad) | last stage] + BN table: three or four weight stages [256 ch][32 k] (64-byte rows), the patch as
 //                NPT pieces of 128 cells x 64 B (piece = one DMA instruction per thread), planes back to back with plane A
 //                padded to whole pieces.  132-152 KB: one 512-thread workgroup per CU.
 //   64-B rows  = four rows share a 256-byte bank window.  ds_read_b128 is served in four lane groups {0-3, 12-15, 20-27},
@@ -44,7 +44,20 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-#define S2_BN_MAX 1024
+#ifndef S2_STORE_SC1
+#define S2_STORE_SC1 1       // 1: the output tile leaves with write-through stores that do not stay in the XCD's L2 (sc1): a 32-channel
+                             // chunk is half (a quarter) of an input pixel's 128-byte lines, whose other half is asked for 9 K-steps later, and
+                             // the 128 KB of output per tile were pushing those lines out of the 4 MB L2 in between.  rocprofv3 FETCH_SIZE over
+                             // the six stride-2 launches of the headline step 16.3 -> 14.3 GB (conv_igemm_wide: 17.9), wall time unchanged
+                             // (the re-fetches are Infinity-Cache hits): profiles/experiments/r3_s2_sc1_stores.log
+#endif
+#ifndef S2_PIECE_PHASE
+#define S2_PIECE_PHASE 1     // phase of a K-step whose LOAD part issues the step's patch pieces (phase 0 carries 8 fragment reads and
+                             // the 2 weight DMAs, phase 1 only 4 reads)
+#endif
+#ifndef S2_NST_BIG
+#define S2_NST_BIG 3         // weight stages on the 32x32 / 16x16 input maps (3 | 4: four measured 1-2 % slower, below; the 8x8 maps have LDS for 3)
+#endif
 
 // Timing probes (tools/ab_build.py name:-DS2_ABL_...=1; wrong results by construction, never in the product build): which part of a
 // tile's life the time goes to.
@@ -59,8 +72,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #endif
 
 // TW = OUTPUT map size (TW x TW; the input map is 2 TW x 2 TW): 16, 8 or 4.
-template <int TW>
+// NST = weight stages: the weights of K-step T + NST - 1 are issued in step T.  vmcnt retires in order, so waiting for the NEXT
+// step's weights also waits for every patch piece issued before them: a piece issued in step s must have landed by the end of
+// step s + NST - 1 whether its plane is needed by then or not.  With 3 stages that is 2 K-steps (~1.4 us) for an HBM round
+// trip.  Timing probes (profiles/experiments/r3_s2_ablation.log) showed the 32x32 / 16x16 classes 15-20 % faster WITHOUT the
+// patch DMA, which suggested that window; a fourth stage (one more K-step, built and kept behind -DS2_NST_BIG=4) measured
+// 1-2 % SLOWER on all three classes (same-box A/B, r3_s2_stages_phase.log): the window is not what they wait for.
+template <int TW, int NST_ = (TW == 4 ? 3 : S2_NST_BIG)>
 struct S2Geom {
+    static constexpr int NST = NST_;
+    static_assert(NST == 3 || NST == 4, "weight stages");
+    static constexpr int BN_MAX = TW == 4 ? 1024 : 512;           // channels of the launch (both convs of a pair): the BN table
     static constexpr int CT = 256, PX = 256, IMGS = PX / (TW * TW);
     static_assert(IMGS >= 1 && IMGS * TW * TW == PX, "whole output maps per tile");
     // planes in tap-use order: 0 = A (odd input rows, odd columns), 1 = B (odd, even), 2 = C (even, odd), 3 = D (even, even).
@@ -84,41 +106,60 @@ struct S2Geom {
     static constexpr int PRO = count_hi_le(1);                    // ... planes A / B only: loaded ahead (prologue, next chunk)
     static constexpr int NB = PRO - NA;
     static constexpr int NOWN = NPT - PRO;                        // pieces with C / D cells: loaded in their own chunk's period
-    // K-step (0..8 of a chunk's period) in which piece k is issued.  A pieces (next chunk): steps 5, 6; B pieces (next chunk):
-    // steps 7, 8; own-period pieces: one per step from step 0.
+    // K-step (0..8 of a chunk's period) in which piece k is issued.  A pieces (next chunk): steps 5, 6 (step 5 with four
+    // stages: they must have landed NST - 1 steps later, before step 0); B pieces (next chunk): steps 7, 8; own-period pieces:
+    // one per step from step 0.
     __host__ __device__ static constexpr int pstep(int k) {
-        return k < NA ? 5 + (2 * k) / NA : (k < PRO ? 7 + (2 * (k - NA)) / NB : k - PRO);
+        return k < NA ? (NST == 3 ? 5 + (2 * k) / NA : 5) : (k < PRO ? 7 + (2 * (k - NA)) / NB : k - PRO);
     }
     __host__ __device__ static constexpr int pieces_at(int s) { int n = 0; for (int k = 0; k < NPT; ++k) n += pstep(k) == s ? 1 : 0; return n; }
     // Validity of that schedule (see the hazard notes in the kernel): a plane last read in step L may be overwritten from
-    // step L + 2 on; a piece issued in step s has landed for every wave at the end of step s + 2.
+    // step L + 2 on; a piece issued in step s has landed for every wave at the end of step s + NST - 1.
     __host__ __device__ static constexpr bool schedule_ok() {
         constexpr int first[4] = {0, 4, 6, 8}, last[4] = {3, 5, 7, 8};
         for (int k = 0; k < NPT; ++k) {
             const int s = pstep(k);
             if (k < PRO) {            // carries the NEXT chunk: period steps 9 + first[lo] is the deadline
-                if (s < last[hi(k)] + 2 || s > 8 || s + 3 > 9 + first[lo(k)]) return false;
+                if (s < last[hi(k)] + 2 || s > 8 || s + NST > 9 + first[lo(k)]) return false;
             } else {                  // carries its own chunk; the plane was last read in the previous period
-                if (s + 9 < last[hi(k)] + 2 || s + 3 > first[lo(k)]) return false;
+                if (s + 9 < last[hi(k)] + 2 || s + NST > first[lo(k)] || s > 4) return false;
             }
         }
         for (int s = 0; s < 9; ++s)
-            if (pieces_at(s) > 2) return false;
+            if (pieces_at(s) > 3) return false;
         return NOWN <= 5 && NA >= 1 && NB >= 1;
     }
     static_assert(schedule_ok(), "patch refill schedule violates a WAR / RAW window");
+    // DMA instructions of step s of a chunk (`last`: the tile's last chunk — no next-chunk pieces, no weights beyond the tile)
+    __host__ __device__ static constexpr bool w_issued(int s, bool last) { return s + NST - 1 <= 8 || !last; }
+    __host__ __device__ static constexpr int p_issued(int s, bool last) { return (s <= 4 || !last) ? pieces_at(s) : 0; }
+    // What may still be in flight when step S ends: everything issued BEHIND the weights of step S + 1 (which were issued first
+    // thing in step S - (NST - 2)): that step's pieces, then weights + pieces of the steps up to S.  (Steps before 0 are the
+    // previous chunk's, never a last one; in a tile's first chunk they do not exist and the count is merely generous: the
+    // prologue has waited for everything the first NST - 1 steps read.)
+    __host__ __device__ static constexpr int wait_n(int S, bool last) {
+        int n = 0;
+        for (int j = S - (NST - 2); j <= S; ++j) {
+            const bool prev = j < 0;
+            const int sj = prev ? j + 9 : j;
+            const bool lastj = last && !prev;
+            if (j > S - (NST - 2)) n += w_issued(sj, lastj) ? 2 : 0;
+            n += p_issued(sj, lastj);
+        }
+        return n;
+    }
     static constexpr int WST = CT * 64;                           // one weight stage (32-deep K-step)
     static constexpr int PIECE = 512 * 16;
-    static constexpr int P_OFF = 2 * WST;                         // [W0 | W1 | pieces ...]
-    static constexpr int E_OFF = P_OFF + PRO * PIECE;             // epilogue staging: the own-period pieces, padding, W2
+    static constexpr int P_OFF = (NST - 1) * WST;                 // [W0 | W1 (| W2) | pieces ... | (pad) | last stage | BN]
+    static constexpr int E_OFF = P_OFF + PRO * PIECE;             // epilogue staging: the own-period pieces, padding, the last stage
     static constexpr int E_BYTES = 65536;
     static constexpr int END_PIECES = P_OFF + NPT * PIECE;
-    static constexpr int W2_OFF = (END_PIECES + WST > E_OFF + E_BYTES ? END_PIECES : E_OFF + E_BYTES - WST);
-    static constexpr int BN_OFF = W2_OFF + WST;
-    static constexpr int LDS_BYTES = BN_OFF + 2 * S2_BN_MAX * 4 + 128;  // + the two image-row tables of the dynamic-exit instantiation
+    static constexpr int WL_OFF = (END_PIECES + WST > E_OFF + E_BYTES ? END_PIECES : E_OFF + E_BYTES - WST);
+    static constexpr int BN_OFF = WL_OFF + WST;
+    static constexpr int LDS_BYTES = BN_OFF + 2 * BN_MAX * 4 + 128;     // + the two image-row tables of the dynamic-exit instantiation
     static_assert(BN_OFF - E_OFF >= E_BYTES, "epilogue staging area");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    __host__ __device__ static constexpr int wstage_off(int st) { return st == 2 ? W2_OFF : st * WST; }
+    __host__ __device__ static constexpr int wstage_off(int st) { return st == NST - 1 ? WL_OFF : st * WST; }
     // tile pixel p -> image of the tile and output coordinates: the 16 pixels of one MFMA tile are a 4 x 4 block
     __host__ __device__ static constexpr int p_img(int p) { return p / (TW * TW); }
     __host__ __device__ static constexpr int p_ox(int p) { return 4 * ((p >> 4) % (TW / 4)) + (p & 3); }
@@ -142,13 +183,13 @@ __host__ __device__ constexpr int s2_tap(int s) {
 template <int TW, bool BF, bool IMAP>
 __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_tiles) {
     using G = S2Geom<TW>;
-    constexpr int CT = G::CT, IMGS = G::IMGS, NPT = G::NPT, PRO = G::PRO;
+    constexpr int CT = G::CT, IMGS = G::IMGS, NPT = G::NPT, PRO = G::PRO, NST = G::NST;
     constexpr int TI = 4, TP = 8;
     typedef float accv __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     char* const pbuf = smem + G::P_OFF;
     float* const bn_scale = (float*)(smem + G::BN_OFF);
-    float* const bn_bias = bn_scale + S2_BN_MAX;
+    float* const bn_bias = bn_scale + G::BN_MAX;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     }
     // IMAP: tensor row of each image of a tile (-1 beyond N), two tables: the epilogue of tile i reads table i & 1 while the
     // prologue of tile i + 1 is issued from table (i + 1) & 1
-    int* const row_tabs = (int*)(smem + G::BN_OFF + 2 * S2_BN_MAX * 4);
+    int* const row_tabs = (int*)(smem + G::BN_OFF + 2 * G::BN_MAX * 4);
     int tsel = 0;
     // weights: piece q = tid + 512 i -> row (tid >> 2) + 128 i, position tid & 3 holds chunk (tid & 3) ^ 2 ((row >> 2) & 1);
     // one descriptor per 128-row half of the channel tile (a pair's second conv has its own weight tensor)
@@ -271,7 +312,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             __syncthreads();   /* (drains W(0) too: the dynamic-exit path only) */                           \
         }                                                                                                    \
         _Pragma("unroll") for (int k = 0; k < PRO; ++k) ISSUE_P(k, 0);                                       \
-        if (9 * nC > 1) ISSUE_W(s2_tap(1) * a.Cin, 1);                                                       \
+        ISSUE_W(s2_tap(1) * a.Cin, 1);                                                                       \
+        if constexpr (NST == 4) ISSUE_W(s2_tap(2) * a.Cin, 2);                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
 
@@ -290,11 +332,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     // 5-8) and no weights beyond the tile's last step (steps 7, 8) are issued.
 #define END_OF_STEP_WAIT(S)                                                                                    \
     {                                                                                                          \
-        constexpr int prev_ = (S) == 0 ? 8 : (S) - 1;                                                          \
-        constexpr int full_ = 2 + G::pieces_at(S) + G::pieces_at(prev_);                                       \
-        constexpr int lastn_ = ((S) < 7 ? 2 : 0) + ((S) <= 4 ? G::pieces_at(S) : 0) + ((S) >= 1 && (S) <= 5 ? G::pieces_at(prev_) : 0); \
-        if (!last) { WAIT_VM(full_); }                                                                         \
-        else { WAIT_VM(lastn_); }                                                                              \
+        if (!last) { WAIT_VM(G::wait_n(S, false)); }                                                           \
+        else { WAIT_VM(G::wait_n(S, true)); }                                                                  \
     }
     // One K-step = step S of the chunk's period (one tap x this chunk's 32 channels).  Two phases (LOAD part, barrier, MFMA part,
     // barrier); the two wave groups run one barrier apart.  Weight stage = S % 3 (9 steps per chunk: the index repeats).
@@ -304,8 +343,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     //   RAW  in interval 4T+3 every wave waits (counted vmcnt) until only the DMA of steps T and the pieces of T-1 are in flight.
 #define S2_STEP(S)                                                                                             \
     {                                                                                                          \
-        constexpr int pl_ = s2_plane(S), dy_ = s2_dy(S), dx_ = s2_dx(S);                                       \
-        const char* ws_ = smem + G::wstage_off((S) % 3) + a_off;                                               \
+        constexpr int pl_ = s2_plane(S), dy_ = s2_dy(S), dx_ = s2_dx(S), sn_ = (S) + NST - 1;                  \
+        /* stage read by this step / filled for step S + NST - 1: compile-time with three stages (9 steps per chunk), */ \
+        /* (chunk + S) & 3 with four (9 = 1 mod 4) */                                                          \
+        const int st_r_ = NST == 3 ? (S) % 3 : ((chunk + (S)) & 3), st_w_ = NST == 3 ? ((S) + 2) % 3 : ((chunk + (S) + 3) & 3); \
+        const char* ws_ = smem + G::wstage_off(st_r_) + a_off;                                                 \
         const char* pb_ = smem + (dy_ * G::cols(pl_) + dx_) * 64 + (boff[pl_] ^ (dy_ << 5));                   \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
             if (kk == 0) {                                                                                     \
@@ -314,9 +356,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
                 bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, 4 * kk + j) * 64);                            \
             if (kk == 0) {                                                                                     \
-                /* weights of the step after next: step S+2 of this chunk, or steps 0 / 1 of the next one */   \
-                if ((S) < 7) { ISSUE_W(s2_tap((S) + 2) * a.Cin + c32, ((S) + 2) % 3); }                        \
-                else if (!last) { ISSUE_W(s2_tap((S) - 7) * a.Cin + c32 + 32, ((S) + 2) % 3); }                \
+                /* weights of step S + NST - 1: of this chunk, or of the first steps of the next one */        \
+                if (sn_ <= 8) { ISSUE_W(s2_tap(sn_ <= 8 ? sn_ : 0) * a.Cin + c32, st_w_); }                    \
+                else if (!last) { ISSUE_W(s2_tap(sn_ > 8 ? sn_ - 9 : 0) * a.Cin + c32 + 32, st_w_); }          \
+            }                                                                                                  \
+            if (kk == S2_PIECE_PHASE) {                                                                        \
                 _Pragma("unroll") for (int k = 0; k < NPT; ++k)                                                \
                     if (G::pstep(k) == (S)) {                                                                  \
                         if (k >= PRO) { ISSUE_P(k, c32); }                                                     \
@@ -429,7 +473,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                         if (n < 0 || S2_ABL_NOSTORE) continue;
                         half8_e v = o8[it];
                         if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
-                        *(half8_e*)(outp + ((size_t)n * (TW * TW) + G::p_oy(p) * TW + G::p_ox(p)) * oc + chg + 8 * k) = v;
+                        _Float16* dst_ = outp + ((size_t)n * (TW * TW) + G::p_oy(p) * TW + G::p_ox(p)) * oc + chg + 8 * k;
+                        if (S2_STORE_SC1) {
+                            typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst_), "v"(__builtin_bit_cast(u32x4_, v)) : "memory");
+                        } else {
+                            *(half8_e*)dst_ = v;
+                        }
                     }
                 }
             }
@@ -451,7 +501,7 @@ int& opt_conv_s2() { static int v = 1; return v; }
 // Shapes this kernel takes: 3x3 / stride 2 / pad 1, 32x32 -> 16x16, 16x16 -> 8x8 or 8x8 -> 4x4, Cout % 256 == 0 (both convs of
 // a pair together), BN + ReLU epilogue.
 bool conv_takes_s2_kernel(int ksize, int stride, int pad, int cin, int cout, int h, int w, int ho, int wo) {
-    return ksize == 3 && stride == 2 && pad == 1 && cin % 32 == 0 && cout % 256 == 0 && cout <= S2_BN_MAX && ho == wo &&
+    return ksize == 3 && stride == 2 && pad == 1 && cin % 32 == 0 && cout % 256 == 0 && cout <= (ho == 4 ? 1024 : 512) && ho == wo &&
            (ho == 16 || ho == 8 || ho == 4) && h == 2 * ho && w == 2 * wo;
 }
 

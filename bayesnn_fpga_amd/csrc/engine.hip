@@ -70,6 +70,7 @@ struct bmi_engine_s {
     int max_batch = 0, chunk = 0;
     size_t ws_bytes = 0, exit_off = 0;   // exit_off: 2 active-image lists + a counter (dynamic early exit)
     size_t splitk_off = 0;               // fp32 partial sums of the split-K prefix convs
+    int image_offset = 0;                // batch index of the current call's image 0 (bmi_forward_mcd_images), else 0
     // profiling
     bool profiling = false;
     double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0}, fam_bytes[BMI_CONV_FAMILIES] = {0};
@@ -78,11 +79,12 @@ struct bmi_engine_s {
     std::vector<hipEvent_t> pool;
 };
 
-SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0) {
+SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0, uint64_t elem_off) {
     SiteArgs s;
     std::memset(&s, 0, sizeof(s));
     s.scale = 1.f;
     if (!site) return s;
+    s.elem_off = elem_off;
     s.kind = site->kind;
     s.site_id = site->site_id;
     s.seed_lo = (uint32_t)seed;
@@ -629,6 +631,12 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
            double* S1, double* S2, double* SL, hipStream_t s, const int* imap = nullptr, int Bc = 0, const int* rows = nullptr) {
     const bmi_op_desc& d = op.d;
     const TensorInfo& tin = e->tensors[d.in];
+    // image-partitioned launch (bmi_forward_mcd_images): element index of image 0 in the index space of a site on a tensor with
+    // `per_image` elements per image (elementwise) / `channels` (per-(image, channel) draws)
+    const int b0 = e->image_offset;
+    auto site_off = [&](const bmi_site& st, size_t per_image, size_t channels) -> uint64_t {
+        return (uint64_t)b0 * (st.kind == BMI_SITE_CHANNEL ? channels : per_image);
+    };
     const int n_rows = imap ? (N / Bc) * B : N;     // rows of a stochastic tensor (original folded layout)
     if (imap && d.kind != BMI_OP_CONV && d.kind != BMI_OP_HEAD) return BMI_ERR_UNSUPPORTED;
     ProfScope prof(e, d.kind == OP_MASKBITS ? BMI_OP_MASK : d.kind, s);
@@ -658,7 +666,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.ksize = d.ksize; a.stride = d.stride; a.pad = d.pad; a.relu = d.relu;
             a.M = N * op.ho * op.wo;
             a.B = B; a.t0 = t0;
-            a.site = resolve_site(&d.site, seed, cnt0);
+            a.site = resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)op.ho * op.wo * op.cout, (size_t)op.cout));
             if (d.site_pos == BMI_SITE_POS_INNER && d.site.kind != BMI_SITE_NONE) { a.site_inner = 1; a.bias_post = d.bias_post; }
             a.out_mul = op.out_mul;
             if (d.in2 >= 0) {
@@ -710,7 +718,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         }
         case OP_MASKBITS:
             return launch_mask_bits((uint8_t*)(ws + e->tensors[d.out].offset), N, tin.h * tin.w, tin.c,
-                                    resolve_site(&d.site, seed, cnt0), B, t0, s);
+                                    resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)tin.h * tin.w * tin.c, (size_t)tin.c)), B, t0, s);
         case BMI_OP_MASK: {
             EltArgs a;
             std::memset(&a, 0, sizeof(a));
@@ -718,7 +726,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.in = (const _Float16*)(ws + tin.offset);
             a.out = ws + e->tensors[d.out].offset;
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
-            a.site = resolve_site(&d.site, seed, cnt0);
+            a.site = resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)tin.h * tin.w * tin.c, (size_t)tin.c));
             if (d.site_pos == BMI_SITE_POS_INNER) { a.bias_post = d.bias_post; a.relu = d.relu; }
             return launch_mask_apply(a, s);
         }
@@ -728,7 +736,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         case BMI_OP_DENSE:
             return launch_dense_f32(ws + tin.offset, tin.f32 ? 1 : (e->bf16 ? 2 : 0), (const float*)d.weight, d.bias,
                                     (float*)(ws + e->tensors[d.out].offset), N, tin.stoch ? N : B, tin.c, op.cout, d.relu,
-                                    resolve_site(&d.site, seed, cnt0), B, t0, s);
+                                    resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)op.cout, (size_t)op.cout)), B, t0, s);
         case BMI_OP_HEAD: {
             // pool + site + Linear + softmax + the chunk's moment sums in one launch (head_fused.hip)
             HeadArgs a;
@@ -740,8 +748,9 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.HW = tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = imap ? N / Bc : N / B;
             a.w = (const float*)d.weight; a.bias = d.bias; a.C = e->out_dim;
             const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
-            a.site = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0);
+            a.site = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0, site_off(d.site, (size_t)tin.c, (size_t)tin.c));
             a.site_logits = resolve_site(on_logits ? &d.site : nullptr, seed, cnt0);
+            a.b0 = b0;
             const size_t eo = (size_t)d.out * B * e->out_dim;
             a.S1 = S1 + eo; a.S2 = S2 + eo; a.SL = SL + eo;
             return launch_head_fused(a, s);
@@ -753,6 +762,31 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
 }  // namespace
 
 extern "C" {
+
+int bmi_forward_mcd_images(bmi_handle h, const float* x_nchw, int32_t batch, int32_t image_offset, int32_t t_begin,
+                           int32_t t_count, uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL,
+                           void* workspace, size_t workspace_bytes, bmi_stream stream) {
+    if (!h || image_offset < 0) return BMI_ERR_INVALID;
+    if (image_offset > 0) {
+        // a site's index offset must be a whole number of Philox calls at every bit width (64 elements): per-image element counts
+        // of every site tensor — conv / mask outputs, pooled features, dense outputs — are checked here, once per call
+        for (const std::vector<OpInfo>* ops : {&h->prefix, &h->suffix})
+            for (const OpInfo& op : *ops) {
+                const bmi_op_desc& d = op.d;
+                if (d.site.kind != BMI_SITE_ELEMENTWISE && d.site.kind != BMI_SITE_CHANNEL) continue;
+                if (d.kind == BMI_OP_HEAD && d.site_pos == BMI_SITE_POS_INNER) continue;      // logits site: the kernel adds b0 itself
+                const TensorInfo& tin = h->tensors[d.in];
+                const size_t unit = d.kind == BMI_OP_HEAD ? (size_t)tin.c
+                                    : d.kind == BMI_OP_DENSE || d.site.kind == BMI_SITE_CHANNEL ? (size_t)op.cout
+                                    : (size_t)op.ho * op.wo * op.cout;
+                if (((size_t)image_offset * unit) % 64 != 0) return BMI_ERR_UNSUPPORTED;
+            }
+    }
+    h->image_offset = image_offset;
+    const int rc = bmi_forward_mcd(h, x_nchw, batch, t_begin, t_count, seed, mask_cnt0, S1, S2, SL, workspace, workspace_bytes, stream);
+    h->image_offset = 0;
+    return rc;
+}
 
 int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_begin, int32_t t_count, uint64_t seed,
                     int32_t mask_cnt0, double* S1, double* S2, double* SL, void* workspace, size_t workspace_bytes,

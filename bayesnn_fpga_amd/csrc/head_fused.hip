@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArg
                     }
 #pragma unroll 1
                 for (int c4 = 4 * hh; c4 < C; c4 += 8) {
-                    const uint64_t elem = (uint64_t)b * C + c4;          // any alignment: b * C need not be a multiple of 4
+                    const uint64_t elem = (uint64_t)(b + a.b0) * C + c4;  // any alignment: b * C need not be a multiple of 4 (b0: first image of an image-partitioned launch)
                     const uint32_t sh = (uint32_t)(elem & 7);
                     uint32_t keep = site_keep8(a.site_logits, elem & ~(uint64_t)7, t) >> sh;
                     if (sh > 4) keep |= site_keep8(a.site_logits, (elem & ~(uint64_t)7) + 8, t) << (8 - sh);   // the quad straddles two calls

@@ -83,6 +83,8 @@ struct HeadArgs {   // fused exit head (head_fused.hip)
     int Bc;
     SiteArgs site;        // on the pooled [B, K] features
     SiteArgs site_logits; // ELEMENTWISE dropout on the [B, C] logits, or NONE
+    int b0;               // batch index of this launch's image 0 (bmi_forward_mcd_images), for the logits site: b0 * C is not a
+                          // multiple of a Philox call, so it cannot ride in site_logits.elem_off
     double *S1, *S2, *SL; // this exit's [B][C] moment accumulators
 };
 int launch_head_fused(const HeadArgs& a, hipStream_t s);
@@ -129,7 +131,7 @@ int& opt_epilogue_lite();      // 1: BN + residual + ReLU + 2-bit elementwise-si
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);
 
-SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0);
+SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0, uint64_t elem_off = 0);
 
 #define BMI_CHECK_LAUNCH()                                  \
     do {                                                    \

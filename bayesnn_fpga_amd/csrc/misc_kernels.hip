@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void mask_apply_shared_kernel(EltArgs a) {
     for (long sb = wave0; sb < n_sb; sb += n_waves) {
         const long tl = sb / sb_per_sample, sbs = sb - tl * sb_per_sample;
         const uint32_t t = (uint32_t)(a.t0 + tl);
-        const uint64_t g = (uint64_t)sbs * 64 + lane;                          // this lane's call
+        const uint64_t g = (uint64_t)sbs * 64 + lane + (a.site.elem_off >> (7 - LB));   // this lane's call
         const philox4 mine = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), t, (uint32_t)a.site.site_id, a.site.seed_lo,
                                            a.site.seed_hi);
 #pragma unroll
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void mask_apply_lb1_kernel(EltArgs a) {
     const long n_items = sb_per_sample * n_tchunks;
     for (long it = wave0; it < n_items; it += n_waves) {
         const long tci = it / sb_per_sample, sbs = it - tci * sb_per_sample;
-        const uint64_t g = (uint64_t)sbs * 64 + lane;                          // this lane's call
+        const uint64_t g = (uint64_t)sbs * 64 + lane + (a.site.elem_off >> 6);   // this lane's call (2 bits per element: 64 per call)
         const int t_lo = (int)tci * tchunk, t_hi = min(T, t_lo + tchunk);
         half8 x[8];
         if (a.in_mod == a.B) {

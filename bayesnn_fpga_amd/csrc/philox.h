@@ -52,6 +52,11 @@ struct SiteArgs {
     int num_masks;
     int cnt0;
     uint32_t seed_lo, seed_hi;
+    // Element index of this LAUNCH's image 0 in the site's index space: 0 for a whole batch; b0 * (elements per image of the
+    // site's tensor) when a launch covers images b0.. of the batch only (bmi_forward_mcd_images: a rank's share of an
+    // image-partitioned batch).  A multiple of 64 elements (one Philox call at 2 bits per element): the fields inside a call do
+    // not move.  Added where the call index is formed — philox_site_call below and the two mask kernels that form it themselves.
+    uint64_t elem_off;
 };
 
 // log2 of the bits drawn per element for drop probability p
@@ -108,6 +113,7 @@ BMI_HD uint32_t philox_keep8(const philox4& r, uint32_t elem0, int log2_bits, ui
 // Philox call index of element elem0 and the call itself
 BMI_HD philox4 philox_site_call(const SiteArgs& s, uint64_t elem0, uint32_t t) {
     // g = elem0 >> sh as two 32-bit halves (a variable 64-bit shift made hipcc park elem0 in scratch)
+    elem0 += s.elem_off;
     const uint32_t sh = 7u - (uint32_t)s.log2_bits;                  // 3 .. 6
     const uint32_t lo = (uint32_t)elem0, hi = (uint32_t)(elem0 >> 32);
     return philox4x32_10((lo >> sh) | (hi << (32u - sh)), hi >> sh, t, (uint32_t)s.site_id, s.seed_lo, s.seed_hi);

@@ -171,40 +171,72 @@ def _can_fuse_shortcut(t_in, blk):
             and ds.in_channels % 64 == 0 and ds.kernel_size == (1, 1) and ds.stride == (2, 2) and ds.bias is None)
 
 
+def _converted(m):
+    """``(layer, wrapper | None)`` for a layer the torch "nn2bnn" converter may have wrapped (converter/pytorch/Dropouts.py:
+    BayesianDropout* own the layer as ``.layer`` and drop its OUTPUT in every mode)."""
+    if m is not None and type(m).__name__.startswith("BayesianDropout") and hasattr(m, "layer"):
+        return m.layer, m
+    return m, None
+
+
 def build_resnet_graph(model, g):
-    """Op sequence of the ResNet family forwards (reference resnet18.py:302-346 / :246-258 / :195-204)."""
+    """Op sequence of the ResNet family forwards (reference resnet18.py:302-346 / :246-258 / :195-204).
+
+    Also compiles a mirror that went through the converter (``nn2bnn._convert_model``: every Conv2d wrapped in
+    BayesianDropout2D, every Linear in BayesianDropout — Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45): a wrapped conv
+    carries a per-(image, channel) site BETWEEN the conv and its BatchNorm (an inner site of the C ABI), a wrapped Linear an
+    elementwise site on its logits; site ids follow the CALL order of the reference forward (BasicBlock.forward :32-48: conv1,
+    conv2, then the downsample conv), and a shortcut conv that carries a site keeps its own launch."""
     x = g.tensor(32, 32, 3)                                   # tensor 0: network input (fp32 NCHW)
-    x = g.conv(x, model.conv1, model.bn1, relu=False, stem=True)   # no ReLU after the stem (:303)
+    stem, stem_w = _converted(model.conv1)
+    x = g.conv(x, stem, model.bn1, relu=False, stem=True,       # no ReLU after the stem (:303)
+               site=g.site(stem_w, channelwise=True), site_inner=stem_w is not None)
     multi = getattr(model, "multi_exit", True)
     dropout_exit = getattr(model, "dropout_exit", False)
     exit_sites = {1: "exit1_dropout", 2: "exit2_dropout", 3: "exit3_dropout"}
+
+    def head(y, linear, index, feature_site_module):
+        lin, lin_w = _converted(linear)
+        if lin_w is not None and feature_site_module is not None:
+            raise TypeError("a converted classifier (dropout on the logits) on top of an exit dropout is not on the accelerated path")
+        if lin_w is not None:
+            g.head(y, lin, index, site=g.site(lin_w), site_on_logits=True)
+        else:
+            g.head(y, lin, index, site=g.site(feature_site_module))
+
     for si in range(1, 5):
         stage, stage_site = _unwrap(getattr(model, f"layer{si}"))
         blocks = list(stage)
         for bi, blk in enumerate(blocks):
             blk, blk_site = _unwrap(blk)
             site_mod = blk_site if blk_site is not None else (stage_site if bi == len(blocks) - 1 else None)
-            a = g.conv(x, blk.conv1, blk.bn1, relu=True)
-            # site ids follow call order: a block's site is allocated when the block finishes
-            if blk.downsample is not None and _can_fuse_shortcut(g.tensors[a], blk):
-                x = g.conv(a, blk.conv2, blk.bn2, relu=True, site=g.site(site_mod),
-                           shortcut=(x, blk.downsample[0], blk.downsample[1]))
+            c1, w1 = _converted(blk.conv1)
+            c2, w2 = _converted(blk.conv2)
+            ds, wd = _converted(blk.downsample[0]) if blk.downsample is not None else (None, None)
+            if w2 is not None and site_mod is not None:
+                raise TypeError("a converted conv (site before its BatchNorm) under a block / stage dropout is not on the accelerated path")
+            a = g.conv(x, c1, blk.bn1, relu=True, site=g.site(w1, channelwise=True), site_inner=w1 is not None)
+            # site ids follow call order: a block's site is allocated when the block finishes; conv2's before the shortcut's
+            site2 = g.site(w2, channelwise=True) if w2 is not None else g.site(site_mod)
+            if ds is not None and wd is None and w2 is None and _can_fuse_shortcut(g.tensors[a], blk):
+                x = g.conv(a, c2, blk.bn2, relu=True, site=site2, shortcut=(x, ds, blk.downsample[1]))
             else:
                 res = x
-                if blk.downsample is not None:
-                    res = g.conv(x, blk.downsample[0], blk.downsample[1], relu=False)
-                x = g.conv(a, blk.conv2, blk.bn2, relu=True, residual=res, site=g.site(site_mod))
+                if ds is not None:
+                    res = g.conv(x, ds, blk.downsample[1], relu=False, site=g.site(wd, channelwise=True), site_inner=wd is not None)
+                x = g.conv(a, c2, blk.bn2, relu=True, residual=res, site=site2, site_inner=w2 is not None)
         if multi and si < 4:
             # exit head si: relu -> conv s2 -> bn chain, relu, avg-pool, [exit dropout], linear
             # (F.relu on a stage output is idempotent: it is already >= 0 and masks keep the sign)
             y = x
             n_conv = 4 - si
             for j in range(1, n_conv + 1):
-                y = g.conv(y, getattr(model, f"ex{si}conv{j}"), getattr(model, f"ex{si}bn{j}"), relu=True)
+                ec, ew = _converted(getattr(model, f"ex{si}conv{j}"))
+                y = g.conv(y, ec, getattr(model, f"ex{si}bn{j}"), relu=True, site=g.site(ew, channelwise=True), site_inner=ew is not None)
             sm = getattr(model, exit_sites[si], None) if dropout_exit else None
-            g.head(y, getattr(model, f"ex{si}linear"), si - 1, site=g.site(sm))
+            head(y, getattr(model, f"ex{si}linear"), si - 1, sm)
     sm = getattr(model, "exit_dropout", None) if dropout_exit else None
-    g.head(x, model.linear, (model_exits(model) - 1), site=g.site(sm))
+    head(x, model.linear, (model_exits(model) - 1), sm)
 
 
 def model_exits(model):
@@ -353,17 +385,19 @@ class MCDEngine(CompiledGraph):
         """Zeroed float64 accumulators S1 = sum p, S2 = sum p^2, SL = sum logit, each [E, B, C]."""
         return torch.zeros(3, self.n_exits, batch, self.out_dim, dtype=torch.float64, device=self.device)
 
-    def accumulate(self, x, S, t_begin, t_count, seed=0, cnt0=0):
-        """Adds samples t_begin .. t_begin+t_count-1 of batch ``x`` into the moment buffer ``S``."""
+    def accumulate(self, x, S, t_begin, t_count, seed=0, cnt0=0, image_offset=0):
+        """Adds samples t_begin .. t_begin+t_count-1 of batch ``x`` into the moment buffer ``S``.
+        ``image_offset``: ``x`` (and ``S``) are images image_offset.. of a larger batch — the masks are drawn at the images'
+        indices in the whole batch (bmi_forward_mcd_images: one rank's share of a batch partitioned by images)."""
         x = self._check_x(x)
         B = x.shape[0]
         if tuple(S.shape) != (3, self.n_exits, B, self.out_dim) or S.dtype != torch.float64 or not S.is_contiguous():
             raise ValueError("moment buffer must be contiguous float64 [3, E, B, C]")
         with torch.cuda.device(self.device):
-            rc = self.lib.bmi_forward_mcd(self.handle, x.data_ptr(), B, int(t_begin), int(t_count),
-                                          int(seed) & 0xFFFFFFFFFFFFFFFF, int(cnt0), S[0].data_ptr(), S[1].data_ptr(),
-                                          S[2].data_ptr(), self.workspace.data_ptr(), self.workspace_bytes, self._stream())
-        _lib.check(rc, "bmi_forward_mcd")
+            rc = self.lib.bmi_forward_mcd_images(self.handle, x.data_ptr(), B, int(image_offset), int(t_begin), int(t_count),
+                                                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(cnt0), S[0].data_ptr(), S[1].data_ptr(),
+                                                 S[2].data_ptr(), self.workspace.data_ptr(), self.workspace_bytes, self._stream())
+        _lib.check(rc, "bmi_forward_mcd_images")
         return S
 
     def finalize(self, S, t_total):

@@ -4,7 +4,8 @@ One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  S
 independent given (seed, site, t) — the Philox counter carries t — so rank g runs
 t in [lo_g, hi_g) on the same batch with the same seed, and the ONLY exchange is one all-reduce
 (sum) of the float64 moment buffer [3, E, B, C] per batch (KBs: latency-bound, never link-bound;
-SURVEY.md §8.5).  The deterministic prefix is recomputed per rank (cheaper than broadcasting it).
+SURVEY.md §8.5).  The deterministic prefix is recomputed per rank (cheaper than broadcasting it).  With fewer samples than
+ranks the batch is partitioned by IMAGES instead (``partition`` / ``accumulate_partitioned``): no rank idles.
 The reference has no counterpart: it is single-device (SA/train/train_utils.py:10-11).
 """
 import torch
@@ -36,8 +37,42 @@ def accumulate_sharded(accumulate_fn, S, T, group=None, t_begin=0):
     return S
 
 
+def partition(T, B, rank, world):
+    """What rank ``rank`` of ``world`` runs of a batch of B images x T Monte-Carlo samples: ``("samples", lo, hi)`` — the
+    sample range [lo, hi) on all images — while there are at least as many samples as ranks, else ``("images", lo, hi)`` —
+    ALL T samples on images [lo, hi): the fallback of SURVEY.md §8.5 ("partition by images, pure DP") for T < G, where a
+    sample split would leave ranks idle (T = 4 on 8 GPUs: half of them) and every rank would still recompute the whole
+    once-per-batch prefix.  Either way the shares are disjoint and their moment buffers add up to the one-rank result."""
+    if T >= world:
+        return ("samples",) + shard_range(T, rank, world)
+    return ("images",) + shard_range(B, rank, world)
+
+
+def accumulate_partitioned(engine, x, S, T, seed=0, cnt0=0, group=None):
+    """This rank's share of batch ``x`` x T samples ADDED into the moment buffer ``S`` [3, E, B, C], then ONE all-reduce (sum)
+    over the group.  Shares by samples when T >= world size (``accumulate_sharded``), by images otherwise: the rank runs
+    ``engine.accumulate(x[lo:hi], ..., image_offset=lo)`` — masks drawn at the images' indices in the whole batch
+    (bmi_forward_mcd_images) — into its rows of S; the other ranks' rows stay zero until the all-reduce."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    kind, lo, hi = partition(T, x.shape[0], rank, world)
+    if kind == "samples":
+        return accumulate_sharded(lambda buf, t0, n: engine.accumulate(x, buf, t0, n, seed, cnt0), S, T, group)
+    if hi > lo:
+        part = S.new_zeros(3, S.shape[1], hi - lo, S.shape[3])
+        engine.accumulate(x[lo:hi].contiguous(), part, 0, T, seed, cnt0, image_offset=lo)
+        S[:, :, lo:hi] += part
+    if world > 1:
+        dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
+    return S
+
+
 def predict_sharded(engine, x, T, seed=0, cnt0=0, group=None):
-    """mean / var / logit_mean of T samples with the samples sharded over the process group."""
+    """mean / var / logit_mean of T samples with the work partitioned over the process group (by samples, or by images
+    when there are fewer samples than ranks)."""
     S = engine.new_moments(x.shape[0])
-    accumulate_sharded(lambda buf, t0, n: engine.accumulate(x, buf, t0, n, seed, cnt0), S, T, group)
+    accumulate_partitioned(engine, x, S, T, seed, cnt0, group)
     return engine.finalize(S, T)

@@ -286,7 +286,7 @@ def main():
         dist.all_reduce(_probe)
         torch.cuda.synchronize()
 
-    from bayesnn_fpga_amd.sharding import accumulate_sharded, shard_range
+    from bayesnn_fpga_amd.sharding import accumulate_partitioned, partition
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
     from bayesnn_fpga_amd.train.metrics import ece_hist_binary
 
@@ -302,14 +302,15 @@ def main():
     pipe = BatchesInFlight(model, dev, n=a.in_flight, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
     eng = pipe.engines[0]
     x = synthetic_images(B, seed=1234).to(dev)
-    t_lo, t_hi = shard_range(T, rank, world)
+    share = partition(T, B, rank, world)       # ("samples", lo, hi) while T >= world, else ("images", lo, hi): nobody idles
+    t_lo, t_hi = (share[1], share[2]) if share[0] == "samples" else (0, T)
     Ss = [e.new_moments(B) for e in pipe.engines]
 
     def one_batch(e, S):
         S.zero_()
-        # the library's N>1 path (bayesnn_fpga_amd/sharding.py): this rank's t-shard into S, then ONE all-reduce (RCCL
+        # the library's N>1 path (bayesnn_fpga_amd/sharding.py): this rank's share into S, then ONE all-reduce (RCCL
         # over xGMI) of the [3,E,B,C] float64 buffer; a single rank skips the collective
-        accumulate_sharded(lambda buf, t0, n: e.accumulate(x, buf, t0, n, a.seed), S, T)
+        accumulate_partitioned(e, x, S, T, a.seed)
         return e.finalize(S, T)
 
     if a.graph and world > 1:
@@ -352,11 +353,12 @@ def main():
         value = samples / dt
         my_T = t_hi - t_lo
         # conv FLOPs of rank 0's profiled step: prefix convs once + suffix convs x its samples
-        conv_flops = 2.0 * B * ((eng.prefix_macs) + my_T * (eng.suffix_macs - eng.head_macs - eng.dense_macs))
+        my_B = B if share[0] == "samples" else share[2] - share[1]      # images of rank 0's profiled step
+        conv_flops = 2.0 * my_B * ((eng.prefix_macs) + my_T * (eng.suffix_macs - eng.head_macs - eng.dense_macs))
         conv_ms, conv_launches = prof.get("conv_igemm", (0.0, 0))
-        conv_flops -= 2.0 * B * eng.stem_macs        # the 3-channel stem runs in its own direct kernel
+        conv_flops -= 2.0 * my_B * eng.stem_macs     # the 3-channel stem runs in its own direct kernel
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        alg_bytes, _ = eng.conv_traffic_model(B, my_T)
+        alg_bytes, _ = eng.conv_traffic_model(my_B, my_T)
         alg_launches = int(conv_launches)            # launches actually made (paired convs are one launch)
         traffic, traffic_src = (hbm_traffic(a.workload, max(alg_launches, 1))
                                 if (world == 1 and not a.batch and not a.T and not a.chunk) else (None, None))
@@ -374,7 +376,8 @@ def main():
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
                        "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight, "hipgraph": bool(a.graph),
-                       "sharding": f"T over {world} rank(s), one float64 all-reduce per batch"},
+                       "sharding": (f"T over {world} rank(s)" if share[0] == "samples" else f"images over {world} ranks (T < ranks)") +
+                                   ", one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
             "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),
             "tflops_naive_equiv": round(2.0 * (eng.prefix_macs + eng.suffix_macs) * samples / dt / 1e12, 2),

@@ -191,6 +191,17 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
                     uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL, void* workspace,
                     size_t workspace_bytes, bmi_stream stream);
 
+/* The same for images image_offset .. image_offset+batch-1 of a LARGER batch: `x_nchw` and S1/S2/SL hold this share only
+ * ([batch] rows), while every dropout mask is drawn at the image's index in the whole batch — so the shares of a batch
+ * partitioned by IMAGES over several GPUs (the fallback of SURVEY.md §8.5 when there are fewer Monte-Carlo samples than
+ * ranks: every rank runs all T samples on its images, nobody idles) reproduce the rows of the one-GPU run.  A site's
+ * index offset must be a whole number of Philox calls (image_offset x elements per image % 64 == 0: true for every tensor
+ * of the CNN families here), else BMI_ERR_UNSUPPORTED.  Masksembles masks do not depend on the image.  No reference
+ * counterpart (single device: SA/train/train_utils.py:10-11). */
+int bmi_forward_mcd_images(bmi_handle h, const float* x_nchw, int32_t batch, int32_t image_offset, int32_t t_begin,
+                           int32_t t_count, uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL,
+                           void* workspace, size_t workspace_bytes, bmi_stream stream);
+
 /* Confidence-threshold early exiting ON the device — what the reference only models after the fact
  * (FullAnalysis.confidence_exiting / is_confident / flop_saver, SA/train/results_analyzer.py:606-630, :638-677, :725-733):
  * runs samples 0 .. t_count-1 of the batch stage by stage; after the head of exit e (first_exit <= e < n_exits-1; the

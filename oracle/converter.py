@@ -8,7 +8,8 @@ Philox convention (oracle/philox.py) instead of ATen's; sites are numbered in ca
 ``ConvertedNet`` is the wrapper of nn2bnn.py:7-30 in the calling convention of oracle/mcd.py: one stochastic pass
 per call, the model's logits as a one-element list (the wrapper's eval-mode mean over nSamples is
 ``mcd.mcd_predict(...)["logit_mean"][0]``).
-Pinned by tests/golden/converter_cnn.npz, produced by the reference's own Dropouts.py + nn2bnn._convert_model.
+Pinned by tests/golden/converter_cnn.npz and converter_resnet18base.npz (the reference's own ResNet18Base, SA/models/resnet18/
+resnet18.py:189-204, through its own converter), produced by the reference's own Dropouts.py + nn2bnn._convert_model.
 """
 from torch import nn
 
@@ -48,4 +49,5 @@ class ConvertedNet(nn.Module):
 
     def forward(self, x, seed=None, t=None):
         self.ctx.begin_forward(seed, t)
-        return [self.model(x)]
+        out = self.model(x)              # the restated ResNets return the list of logits their reference forward returns
+        return out if isinstance(out, list) else [out]

@@ -28,7 +28,7 @@ def test_oracle_converter_matches_reference():
     o = ConvertedNet(net, float(g["p"]))
     x = synthetic_images(int(g["B"]), seed=1234)
     logits = mcd.mcd_passes(o, x, int(g["T"]), int(g["seed"]))[0]
-    np.testing.assert_allclose(logits, g["logits"], atol=1e-6)
+    np.testing.assert_allclose(logits, g["logits"], atol=1e-5)           # (fp32 CPU convolutions: 1e-6 on the box that made the fixture)
     assert np.abs(g["logits"][0] - g["logits"][1]).max() > 1e-2          # the passes do differ
 
 
@@ -103,3 +103,73 @@ def test_gpu_converted_cnn_chunking_invariance():
     S = [m.engine(x.device, max_batch=9, chunk_samples=c).accumulate(x, m.engine(x.device).new_moments(9), 0, 6, 77).cpu()
          for c in (1, 4)]
     torch.testing.assert_close(S[0], S[1], rtol=1e-12, atol=1e-12)
+
+
+# ---- the converter on a ResNet: the reference's _convert_model applied to the reference's own ResNet18Base -------------------
+def _seeded_base(cls):
+    torch.manual_seed(0)
+    net = cls(n_exits=1, out_dim=10)
+    return net
+
+
+def test_oracle_converted_resnet18base_matches_reference():
+    from oracle.resnet18 import ResNet18Base as OracleBase
+    g = load_golden("converter_resnet18base.npz")
+    net = _seeded_base(OracleBase)
+    assert state_checksum(net.state_dict()) == str(g["init_checksum"])
+    synthetic_weights_(net, 0)
+    assert state_checksum(net.state_dict()) == str(g["weights_checksum"])
+    o = ConvertedNet(net, float(g["p"])).eval()
+    x = synthetic_images(int(g["B"]), seed=1234)
+    logits = mcd.mcd_passes(o, x, int(g["T"]), int(g["seed"]))[0]
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-5)
+    assert o.ctx.site == int(g["sites_per_pass"]) == 21            # stem + 16 block convs + 3 shortcut convs + classifier
+
+
+def test_mirror_converts_resnet18base_like_the_reference():
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18Base
+    g = load_golden("converter_resnet18base.npz")
+    net = _seeded_base(ResNet18Base)
+    assert state_checksum(net.state_dict()) == str(g["init_checksum"])
+    m = MCDropout(net, nSamples=4, p=float(g["p"]))
+    wrappers = [type(w).__name__ for w in m.model.modules() if isinstance(w, (BayesianDropout, BayesianDropout2D))]
+    assert wrappers == list(g["wrapper_classes"]) and len(wrappers) == 30
+    assert list(m.model.state_dict().keys()) == list(g["keys"])
+    assert m.n_exits == 1 and m.out_dim == 10
+    cg = CompiledGraph(m, "cpu", 8, 2)
+    sites = [op["site"]["site_id"] for op in cg.graph.ops if op.get("site")]
+    assert sorted(sites) == list(range(21))                        # the 21 sites of one reference forward, call order
+    kinds = [op["kind"] for op in cg.graph.ops]
+    assert kinds.count(2) == 19 and cg.n_exits == 1                # 16 block convs + 3 un-fused shortcut convs (the stem is kind 1)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+@pytest.mark.gpu
+def test_gpu_converted_resnet18base_against_reference_golden():
+    """north_star's "converter/pytorch dropout insertion" on a network with residuals and shortcut convs: the package's
+    ResNet18Base through the package's _convert_model, compiled by the engine (inner channel sites under a residual add,
+    shortcut convs un-fused), against per-pass logits of the reference's ResNet18Base through the reference's converter."""
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18Base
+    g = load_golden("converter_resnet18base.npz")
+    B, T, seed, p = int(g["B"]), int(g["T"]), int(g["seed"]), float(g["p"])
+    net = _seeded_base(ResNet18Base)
+    synthetic_weights_(net, 0)
+    m = MCDropout(net, nSamples=T, p=p).to("cuda:0")
+    m.mc_seed = seed
+    x = synthetic_images(B, seed=1234).to("cuda:0")
+    m.train()                                                   # training mode: one stochastic pass per call, [logits]
+    passes = np.stack([m(x)[0].cpu().numpy()[None] for _ in range(T)])
+    ref = g["logits"]
+    assert passes.shape == ref.shape
+    np.testing.assert_allclose(passes, ref, rtol=0, atol=6e-2)      # 20 fp16 layers under identical masks; logits up to 16
+    zero = ref == 0                                             # dropped logits are exactly zero, nothing else is
+    assert zero.any() and np.array_equal(passes == 0, zero)
+    ref_probs = torch.softmax(torch.from_numpy(ref), -1).numpy().astype(np.float64)
+    r = m.engine(x.device, max_batch=B).predict(x, T, seed=seed)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref_probs.mean(0), rtol=0, atol=2e-3)
+    m.eval()
+    m.mc_pass = 0
+    mean_logits = m(x)                                          # eval mode: sum(pred) / len(pred) over nSamples, per exit
+    assert isinstance(mean_logits, list) and len(mean_logits) == 1
+    np.testing.assert_allclose(mean_logits[0].cpu().numpy(), ref.mean(0)[0], rtol=0, atol=3e-2)

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from bayesnn_fpga_amd.sharding import accumulate_sharded, shard_range
+from bayesnn_fpga_amd.sharding import accumulate_partitioned, accumulate_sharded, partition, shard_range
 
 
 def test_shard_range_partitions():
@@ -109,3 +109,62 @@ def test_two_rank_gloo_masksembles_shards_the_mask_indices(tmp_path):
         _oracle_accumulate(model, x, 42)(Sh, t0, 2)
         halves.append(Sh.numpy())
     assert np.abs(halves[0] - halves[1]).max() > 1e-3
+
+
+# ---- fewer samples than ranks: the batch is partitioned by IMAGES (SURVEY.md §8.5 fallback) -----------------------------------
+def test_partition_switches_to_images_below_one_sample_per_rank():
+    assert partition(100, 250, 3, 8) == ("samples",) + shard_range(100, 3, 8)
+    assert partition(8, 250, 7, 8) == ("samples", 7, 8)                   # BASELINE config 3: one mask per GPU
+    spans = [partition(4, 250, r, 8) for r in range(8)]
+    assert all(k == "images" for k, _, _ in spans) and spans[0][1] == 0 and spans[-1][2] == 250
+    assert all(a[2] == b[1] for a, b in zip(spans, spans[1:])) and max(hi - lo for _, lo, hi in spans) == 32
+
+
+class _OracleEngine:
+    """Stands in for MCDEngine in accumulate_partitioned: the CPU oracle on the WHOLE batch, of which it returns the rows the
+    call asked for — eval-mode rows are independent and the masks are a function of the image's index in the whole batch,
+    which is what bmi_forward_mcd_images guarantees on the device (tests/test_gpu_model.py pins that)."""
+
+    def __init__(self, model, x_full, seed):
+        self.fn, self.x_full = _oracle_accumulate(model, x_full, seed), x_full
+
+    def accumulate(self, x, S, t_begin, t_count, seed=0, cnt0=0, image_offset=0):
+        assert torch.equal(x, self.x_full[image_offset:image_offset + x.shape[0]])
+        full = torch.zeros(3, S.shape[1], self.x_full.shape[0], S.shape[3], dtype=torch.float64)
+        self.fn(full, t_begin, t_count)
+        S += full[:, :, image_offset:image_offset + x.shape[0]]
+        return S
+
+
+def _worker_images(rank, world, port, T, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from bayesnn_fpga_amd.synthetic import synthetic_images
+    model = _build(KW_MC)
+    x = synthetic_images(3, seed=1234)
+    S = torch.zeros(3, 4, 3, 10, dtype=torch.float64)
+    accumulate_partitioned(_OracleEngine(model, x, 42), x, S, T, seed=42)
+    if rank == 0:
+        np.save(out_path, S.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_image_partition_equals_single_rank(tmp_path):
+    T = 1                                          # fewer samples than ranks: rank 0 takes images [0, 2), rank 1 image 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "S.npy")
+    mp.spawn(_worker_images, args=(2, port, T, out), nprocs=2, join=True)
+    S2 = np.load(out)
+    from bayesnn_fpga_amd.synthetic import synthetic_images
+    model = _build(KW_MC)
+    x = synthetic_images(3, seed=1234)
+    S1 = torch.zeros(3, 4, 3, 10, dtype=torch.float64)
+    accumulate_partitioned(_OracleEngine(model, x, 42), x, S1, T, seed=42)      # no process group: one rank, all samples
+    np.testing.assert_allclose(S2, S1.numpy(), rtol=1e-12, atol=1e-12)
+    assert np.allclose(S2[0].sum(-1), 1.0, atol=1e-6)

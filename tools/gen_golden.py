@@ -324,6 +324,71 @@ def converter_cnn():
         nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(256, 10))
 
 
+def _import_ref_converter():
+    """The reference's Dropouts.py / nn2bnn.py.  nn2bnn.py imports a file that is not in the repository
+    (``test.ThreeLayerNet``, :5): an empty module of that name is registered so that the import statement passes;
+    nothing of it is used."""
+    conv_dir = "/root/reference/Hardware_Artifact/converter/pytorch"
+    sys.path.insert(0, conv_dir)
+    saved_test = sys.modules.get("test"), sys.modules.get("test.ThreeLayerNet")
+    t = types.ModuleType("test")
+    tl = types.ModuleType("test.ThreeLayerNet")
+    tl.ThreeLayerNet = None
+    t.ThreeLayerNet = tl
+    sys.modules["test"], sys.modules["test.ThreeLayerNet"] = t, tl
+    import Dropouts as ref_dropouts
+    import nn2bnn as ref_nn2bnn
+    for k, v in zip(("test", "test.ThreeLayerNet"), saved_test):
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    sys.path.remove(conv_dir)
+    return ref_dropouts, ref_nn2bnn
+
+
+def gen_converter_resnet():
+    """The reference's nn2bnn._convert_model (Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45) applied to the reference's
+    own ResNet18Base (SA/models/resnet18/resnet18.py:189-204): every Conv2d — the stem, both convs of every BasicBlock, the
+    1x1 shortcut convs, the (unused) exit-head convs — becomes BayesianDropout2D, every Linear BayesianDropout; T passes of
+    the converted model's own forward.  Patched: only F.dropout / F.dropout2d (the Bernoulli source)."""
+    from models.resnet18.resnet18 import ResNet18Base
+    ref_dropouts, ref_nn2bnn = _import_ref_converter()
+
+    def d2(x, p=0.5, training=True, inplace=False):
+        assert training
+        return philox_dropout(CTX, x, p, channelwise=True)
+
+    B, T, seed, p = 3, 4, 77, 0.25
+    torch.manual_seed(0)
+    net = ResNet18Base(n_exits=1, out_dim=10)
+    init = state_checksum(net.state_dict())
+    synthetic_weights_(net, 0)
+    wsum = state_checksum(net.state_dict())
+    model = ref_nn2bnn._convert_model(net, p)
+    classes = [type(m).__name__ for m in model.modules() if isinstance(m, ref_dropouts._DropoutBase)]
+    x = synthetic_images(B, seed=1234)
+    model.eval()
+    outs = []
+    orig = ref_dropouts.F.dropout, ref_dropouts.F.dropout2d
+    ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = _patched_dropout, d2
+    try:
+        with torch.no_grad():
+            for tt in range(T):
+                CTX.begin_forward(seed, tt)
+                out = model(x)
+                assert isinstance(out, list) and len(out) == 1
+                outs.append(out[0].numpy()[None])
+                sites_per_pass = CTX.site
+    finally:
+        ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = orig
+    logits = np.stack(outs)                      # [T, 1, B, C]
+    np.savez(os.path.join(OUT, "converter_resnet18base.npz"), logits=logits, B=B, T=T, seed=seed, p=p, init_checksum=init,
+             weights_checksum=wsum, wrapper_classes=np.array(classes), keys=np.array(list(model.state_dict().keys())),
+             sites_per_pass=sites_per_pass)
+    print("converter_resnet18base", logits.shape, len(classes), "wrappers,", sites_per_pass, "sites per pass", float(np.abs(logits).max()))
+
+
 def gen_converter():
     """Hardware_Artifact/converter/pytorch: the reference's own Dropouts.py classes and nn2bnn._convert_model applied
     to a small CNN.  nn2bnn.py imports a file that is not in the repository (``test.ThreeLayerNet``, :5): an empty
@@ -386,8 +451,13 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "converter":
         gen_converter()
+        gen_converter_resnet()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "converter_resnet":
+        gen_converter_resnet()
         sys.exit(0)
     gen_converter()
+    gen_converter_resnet()
     gen_philox()
     gen_masksembles()
     gen_metrics()
