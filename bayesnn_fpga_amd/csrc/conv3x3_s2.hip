@@ -476,7 +476,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                         _Float16* dst_ = outp + ((size_t)n * (TW * TW) + G::p_oy(p) * TW + G::p_ox(p)) * oc + chg + 8 * k;
                         if (S2_STORE_SC1) {
                             typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst_), "v"(__builtin_bit_cast(u32x4_, v)) : "memory");
+                            // (hipcc does not model an asm store: without the trailing s_nop its next instruction may overwrite the data
+                            // registers before the store has read them — cdna_hip_programming.md §5.7 item 1; the first build without it
+                            // failed every model-level parity test)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst_), "v"(__builtin_bit_cast(u32x4_, v)) : "memory");
                         } else {
                             *(half8_e*)dst_ = v;
                         }

@@ -140,9 +140,14 @@ typedef struct bmi_model_desc {
 int bmi_version(void);
 const char* bmi_error_string(int code);
 
-/* Process-wide switches: kernel selection (speed only, never results; used for same-process A/B measurement and by the
- * tests to cover both code paths) and the element type of the unit-test entry points.  Returns BMI_ERR_INVALID for an
- * unknown name / value.  Names:
+/* Process-wide switches: kernel selection (used for same-process A/B measurement and by the tests to cover both code
+ * paths) and the element type of the unit-test entry points.  Results are equal TO ROUNDING across them, not always bit for
+ * bit: "mfma_shape_*" and "epilogue_lite" leave every bit alone; "conv_pw", "conv_s2", "conv_stream" and "conv_wide" move a
+ * conv to a kernel family that sums its K dimension in another order, "splitk" adds nine fp32 partial sums separately,
+ * "dense_exact" swaps the split-fp16 product for the exact-f32 MFMA.  (Kernel selection itself looks at the conv's shape
+ * and the engine's planned batch x chunk only, so two runs of one engine — whole, sharded, partial chunks — agree bit for
+ * bit up to the order in which float64 moment sums of more than 64 samples meet.)  Returns BMI_ERR_INVALID for an unknown
+ * name / value.  Names:
  *   "mfma_shape_patch", "mfma_shape_wide"   16 | 32: MFMA instruction shape of conv3x3_patch / conv_igemm_wide
  *                                           (v_mfma_f32_16x16x32_f16 | v_mfma_f32_32x32x16_f16); 0 = built-in default
  *   "xcd_split"                             0 | 1 | 2 | 4: channel-tile classes of the XCD-aware tile order (0 = chosen from

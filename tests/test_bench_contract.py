@@ -87,6 +87,46 @@ def test_bench_launches_its_own_ranks(tmp_path):
     np.testing.assert_allclose(np.load(f2), np.load(f1), rtol=0, atol=1e-12)
 
 
+@pytest.mark.gpu
+def test_config5_t512_two_rank_dry_run(tmp_path):
+    """BASELINE configs[4] as written — ResNet-50 multi-exit, T = 512 sharded over the ranks — executed end to end in dry run:
+    two ranks on one GPU over gloo (256 samples each), a 40-image batch so that it stays a test.  The sharded mean equals the
+    one-rank T = 512 run to 1e-12 (512 samples meet in the float64 sums in another order)."""
+    import numpy as np
+    common = ["--workload", "resnet50_me", "--T", "512", "--batch", "40", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    f1, f2 = str(tmp_path / "m1.npy"), str(tmp_path / "m2.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--dump-mean", f1],
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", *common,
+                         "--dump-mean", f2], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    d2 = json.loads([ln for ln in r2.stdout.strip().split("\n") if ln.startswith("{")][0])
+    assert d2["n_gpus"] == 2 and d2["config"]["T"] == 512 and d2["config"]["batch"] == 40
+    m1, m2 = np.load(f1), np.load(f2)
+    assert m1.shape == (4, 40, 10)
+    np.testing.assert_allclose(m2, m1, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m1.sum(-1), 1.0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fewer_samples_than_ranks_partitions_the_images(tmp_path):
+    """T = 1 on two ranks: the batch is partitioned by IMAGES (sharding.partition), every rank works, and the result is the
+    one-rank one to fp16 rounding of the activations (the halves run at another batch size: other kernels)."""
+    import numpy as np
+    common = ["--T", "1", "--batch", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    f1, f2 = str(tmp_path / "m1.npy"), str(tmp_path / "m2.npy")
+    for n, f, extra in ((1, f1, []), (2, f2, ["--backend", "gloo", "--share-gpu"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *extra, *common, "--dump-mean", f],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][0])
+        assert ("images over 2 ranks" in d["config"]["sharding"]) == (n == 2)
+    np.testing.assert_allclose(np.load(f2), np.load(f1), rtol=0, atol=2e-3)
+
+
 def test_bench_self_launch_starts_n_ranks_without_a_launcher():
     """CPU box: the launch mechanics alone.  `bench.py --gpus 2` with no WORLD_SIZE in the environment must start two rank
     processes (each then refuses to run without a GPU: the HIP path has no CPU fallback) and pass their failure on."""
