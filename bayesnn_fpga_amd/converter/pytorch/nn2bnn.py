@@ -11,6 +11,9 @@
 
 What the engine accepts after conversion:
 
+* the package's own VGG-19 mirrors (``models.vgg19``): conv -> [site] -> BN -> ReLU, an elementwise site behind every
+  MaxPool2d, the classifier's site on its logits (``build_vgg_graph``; pinned case: the reference's ``VGG19`` through its
+  own ``_convert_model``);
 * the package's own ResNet mirrors (``models.resnet18``: ``ResNet18Base``, the early-exit and MC variants) — the converter
   recurses through them exactly as the reference's recurses through its own (``_convert_model`` on ``ResNet18Base``,
   SA/models/resnet18/resnet18.py:189-204, is the pinned case): every conv of every BasicBlock, the 1x1 shortcut convs (which
@@ -63,9 +66,10 @@ class MCDropout(EngineModelMixin, nn.Module):
         self.model = _convert_model(model, p)
         self.nSamples = nSamples
         self.p = p
-        self.resnet = getattr(self.model, "family", None) == "resnet"
+        fam = getattr(self.model, "family", None)
+        self.resnet = fam in ("resnet", "vgg")       # one of the package's own mirrors: its forward returns a LIST of logits
         self.multi_exit = bool(self.resnet and getattr(self.model, "multi_exit", True))
-        self.n_exits = 4 if self.multi_exit else 1
+        self.n_exits = (4 if fam == "resnet" else 5) if self.multi_exit else 1
         linears = [m for m in self.model.modules() if isinstance(m, nn.Linear)]
         if not linears:
             raise TypeError("the engine needs a model that ends in nn.Linear")
@@ -93,9 +97,12 @@ class MCDropout(EngineModelMixin, nn.Module):
 
     # ---- graph of the converted model (engine.GraphBuilder) ------------------------------------------------
     def build_graph(self, g):
-        if self.resnet:
+        if getattr(self.model, "family", None) == "resnet":
             from ...engine import build_resnet_graph
             return build_resnet_graph(self.model, g)
+        if getattr(self.model, "family", None) == "vgg":
+            from ...models.vgg19.vgg19 import build_vgg_graph
+            return build_vgg_graph(self.model, g)
         if not isinstance(self.model, nn.Sequential):
             raise TypeError("the engine compiles converted nn.Sequential CNNs; got " + type(self.model).__name__)
         mods = _leaves(self.model)

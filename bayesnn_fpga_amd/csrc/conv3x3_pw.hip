@@ -116,6 +116,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
         _Pragma("unroll") for (int i = 0; i < G::WROWS; ++i)                                     \
             GLDS16(wsrc[i] + (KOFF), wst + (ST) * G::WST + (i * 512 + wave * 64) * 16);          \
     }
+#define ISSUE_W_HALF(KOFF, ST, I) GLDS16(wsrc[I] + (KOFF), wst + (ST) * G::WST + ((I) * 512 + wave * 64) * 16)
+#ifndef PW_WSPLIT
+#define PW_WSPLIT 0          // 1: a wave's two weight DMA instructions of a K-step go out in the two phases (one each)
+#endif
     ISSUE_W(0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // sub-patch: piece q = tid + 512 i -> cell q >> 2, position q & 3 holds chunk pos ^ 2 (y & 1); element offset of its
@@ -193,11 +197,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
                 bf[j] = *(const half8*)(pb_ + boff[ky_] + G::cell_delta(4 * kk + j) * 64);                     \
-            if (kk == 0) {                                                                                     \
+            if (kk == 0 && !PW_WSPLIT) {                                                                       \
                 /* weights of the step after next: (tap + 2) of this chunk, or taps 0 / 1 of the next one */   \
                 if ((TAP) < 7) { ISSUE_W(((TAP) + 2) * a.Cin + c32, ((TAP) + 2) % 3); }                        \
                 else if (!last) { ISSUE_W(((TAP) - 7) * a.Cin + c32 + 32, ((TAP) + 2) % 3); }                  \
                 if ((TAP) >= 1 && (TAP) <= G::ITER_P && !last) { ISSUE_P((TAP) - 1, c32 + 32, nb); }           \
+            }                                                                                                  \
+            if (PW_WSPLIT) {                                                                                   \
+                if ((TAP) < 7) { ISSUE_W_HALF(((TAP) + 2) * a.Cin + c32, ((TAP) + 2) % 3, kk); }               \
+                else if (!last) { ISSUE_W_HALF(((TAP) - 7) * a.Cin + c32 + 32, ((TAP) + 2) % 3, kk); }         \
+                if (kk == 1 && (TAP) >= 1 && (TAP) <= G::ITER_P && !last) { ISSUE_P((TAP) - 1, c32 + 32, nb); } \
             }                                                                                                  \
             if (kk == 1 && g == 1) END_OF_STEP_WAIT(TAP);      /* interval 4T+3, group 1: LOAD part */         \
             RAW_BARRIER();                                                                                     \
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
 #undef END_OF_STEP_WAIT
 #undef WAIT_VM
 #undef ISSUE_W
+#undef ISSUE_W_HALF
 #undef ISSUE_P
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

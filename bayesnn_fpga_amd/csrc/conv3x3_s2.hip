@@ -44,6 +44,9 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef S2_WSPLIT
+#define S2_WSPLIT 0          // 1: a wave issues its two weight DMA instructions of a K-step in the two phases (one each) instead of both in phase 0
+#endif
 #ifndef S2_STORE_SC1
 #define S2_STORE_SC1 1       // 1: the output tile leaves with write-through stores that do not stay in the XCD's L2 (sc1): a 32-channel
                              // chunk is half (a quarter) of an input pixel's 128-byte lines, whose other half is asked for 9 K-steps later, and
@@ -272,11 +275,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     // offsets stay loop-invariant, one VGPR each, and nothing is added per DMA)
 #define BLDS16(RSRC, VOFF, SOFF, LDSPTR) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds((RSRC), (__attribute__((address_space(3))) void*)(LDSPTR), 16, (VOFF), (SOFF), 0, 0)
-#define ISSUE_W(KOFF, ST)                                                                                    \
+#define ISSUE_W_HALF(KOFF, ST, I)                                                                            \
     {                                                                                                        \
         const unsigned so_ = __builtin_amdgcn_readfirstlane(2u * (unsigned)(KOFF));                          \
-        BLDS16(rs_w0, woff, so_, smem + G::wstage_off(ST) + (0 * 512 + wave * 64) * 16);                     \
-        BLDS16(rs_w1, woff, so_, smem + G::wstage_off(ST) + (1 * 512 + wave * 64) * 16);                     \
+        if ((I) == 0) BLDS16(rs_w0, woff, so_, smem + G::wstage_off(ST) + (0 * 512 + wave * 64) * 16);       \
+        else BLDS16(rs_w1, woff, so_, smem + G::wstage_off(ST) + (1 * 512 + wave * 64) * 16);                \
+    }
+#define ISSUE_W(KOFF, ST)                                                                                    \
+    {                                                                                                        \
+        ISSUE_W_HALF(KOFF, ST, 0);                                                                           \
+        ISSUE_W_HALF(KOFF, ST, 1);                                                                           \
     }
 #define ISSUE_P(K, C0)                                                                                       \
     {                                                                                                        \
@@ -355,10 +363,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
                 bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, 4 * kk + j) * 64);                            \
-            if (kk == 0) {                                                                                     \
-                /* weights of step S + NST - 1: of this chunk, or of the first steps of the next one */        \
-                if (sn_ <= 8) { ISSUE_W(s2_tap(sn_ <= 8 ? sn_ : 0) * a.Cin + c32, st_w_); }                    \
-                else if (!last) { ISSUE_W(s2_tap(sn_ > 8 ? sn_ - 9 : 0) * a.Cin + c32 + 32, st_w_); }          \
+            if (kk == 0 || S2_WSPLIT) {                                                                        \
+                /* weights of step S + NST - 1: of this chunk, or of the first steps of the next one (S2_WSPLIT: the two */ \
+                /* DMA instructions of a wave in the two phases of the step) */                                \
+                if (!S2_WSPLIT) {                                                                              \
+                    if (sn_ <= 8) { ISSUE_W(s2_tap(sn_ <= 8 ? sn_ : 0) * a.Cin + c32, st_w_); }                \
+                    else if (!last) { ISSUE_W(s2_tap(sn_ > 8 ? sn_ - 9 : 0) * a.Cin + c32 + 32, st_w_); }      \
+                } else {                                                                                       \
+                    if (sn_ <= 8) { ISSUE_W_HALF(s2_tap(sn_ <= 8 ? sn_ : 0) * a.Cin + c32, st_w_, kk); }       \
+                    else if (!last) { ISSUE_W_HALF(s2_tap(sn_ > 8 ? sn_ - 9 : 0) * a.Cin + c32 + 32, st_w_, kk); } \
+                }                                                                                              \
             }                                                                                                  \
             if (kk == S2_PIECE_PHASE) {                                                                        \
                 _Pragma("unroll") for (int k = 0; k < NPT; ++k)                                                \
@@ -497,6 +511,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #undef SETUP_TILE
 #undef ISSUE_P
 #undef ISSUE_W
+#undef ISSUE_W_HALF
 }
 
 int& opt_conv_s2() { static int v = 1; return v; }

@@ -71,6 +71,7 @@ struct bmi_engine_s {
     size_t ws_bytes = 0, exit_off = 0;   // exit_off: 2 active-image lists + a counter (dynamic early exit)
     size_t splitk_off = 0;               // fp32 partial sums of the split-K prefix convs
     int image_offset = 0;                // batch index of the current call's image 0 (bmi_forward_mcd_images), else 0
+    size_t head_off = 0;                 // float64 partial sums of a head launch's 32-sample groups (joined in group order)
     // profiling
     bool profiling = false;
     double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0}, fam_bytes[BMI_CONV_FAMILIES] = {0};
@@ -581,6 +582,8 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
         sk_bytes = std::max(sk_bytes, align_up((size_t)op.nsplit * M * op.cout * sizeof(float), 256));
     }
     off += sk_bytes;
+    h->head_off = off;
+    off += align_up((size_t)((chunk_samples + 31) / 32) * 3 * max_batch * h->out_dim * sizeof(double), 256);
     h->ws_bytes = off;
     h->max_batch = max_batch;
     h->chunk = chunk_samples;
@@ -753,6 +756,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.b0 = b0;
             const size_t eo = (size_t)d.out * B * e->out_dim;
             a.S1 = S1 + eo; a.S2 = S2 + eo; a.SL = SL + eo;
+            a.part = (double*)(ws + e->head_off);
             return launch_head_fused(a, s);
         }
     }

@@ -6,8 +6,9 @@
 //
 //   workgroup   = one image b of the batch x one group of 32 of the launch's samples, 256 threads (one workgroup per image
 //                 walking all groups left 250 workgroups of latency-bound work on 256 CUs: 2x slower than the three kernels
-//                 it replaced); the groups of an image meet in S1/S2/SL[b][:] by hardware float64 atomic adds (<= 4 per
-//                 address and launch at T = 100).
+//                 it replaced); the groups of an image leave float64 partial sums in a workspace scratch that head_join_kernel
+//                 adds into S1/S2/SL[b][:] in group order (round 3: bit-reproducible; round 2 used hardware float64 atomics,
+//                 whose order varied from run to run).
 //   phase A     = pooling, coalesced: wave w pools columns (samples) w, w+4, .. of the group, lane = one 8-channel group
 //                 (16 B per pixel row: 64 lanes cover a 512-channel row = 1 KB contiguous), ReLU + mean in fp32, the
 //                 feature-side site (MC dropout / Masksembles1D on the [B, K] tensor), then fp32 into LDS
@@ -323,13 +324,41 @@ __global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArg
                 }
                 if (ts == 0 && c < C) {
                     const size_t o = (size_t)b * C + c;
-                    unsafeAtomicAdd(a.S1 + o, s1);
-                    unsafeAtomicAdd(a.S2 + o, s2);
-                    unsafeAtomicAdd(a.SL + o, sl);
+                    if (a.part) {                           // several groups per image: partial sums, joined in group order by head_join_kernel
+                        const size_t plane = (size_t)a.B * C;
+                        double* const pp = a.part + (size_t)g * 3 * plane + o;
+                        pp[0] = s1; pp[plane] = s2; pp[2 * plane] = sl;
+                    } else if (gridDim.y == 1) {            // the only writer of this address in the launch
+                        a.S1[o] += s1; a.S2[o] += s2; a.SL[o] += sl;
+                    } else {                                // (single-kernel entry point without a scratch: order varies from run to run)
+                        unsafeAtomicAdd(a.S1 + o, s1);
+                        unsafeAtomicAdd(a.S2 + o, s2);
+                        unsafeAtomicAdd(a.SL + o, sl);
+                    }
                 }
             }
         }
     }
+}
+
+// Joins the per-group partial sums of an image in GROUP ORDER into the caller's accumulators: with hardware float64 atomics the
+// groups met in whatever order the workgroups finished, and the last bit of the sums of more than 64 samples changed from run to
+// run (round-2 verdict); an ordered "last arriver adds all" reduction inside the head kernel needed agent-scope fences that doubled
+// it.  This is one more launch of B x C threads per exit and chunk (~3 us), only when a launch carries more than 32 samples.
+__global__ __launch_bounds__(256) void head_join_kernel(const double* __restrict__ part, int groups, int B, int C, const int* imap, int Bc,
+                                                        double* S1, double* S2, double* SL) {
+    const int rows = imap ? Bc : B;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const int row = i / C, c = i - row * C;
+    const int b = imap ? imap[row] : row;
+    const size_t o = (size_t)b * C + c, plane = (size_t)B * C;
+    double s1 = 0.0, s2 = 0.0, sl = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        const double* pp = part + (size_t)g * 3 * plane + o;
+        s1 += pp[0]; s2 += pp[plane]; sl += pp[2 * plane];
+    }
+    S1[o] += s1; S2[o] += s2; SL[o] += sl;
 }
 
 template <int RT>
@@ -349,7 +378,10 @@ static void launch_rt(const HeadArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((head_fused_kernel<RT, 0>), grid, block, 0, s, a);
 }
 
-int launch_head_fused(const HeadArgs& a, hipStream_t s) {
+int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
+    HeadArgs a = a_in;
+    const int groups = (a.tc + 31) / 32;
+    if (groups <= 1) a.part = nullptr;             // one group per image: the workgroup adds into S1 / S2 / SL itself
     if (!a.in || !a.w || !a.bias || !a.S1 || !a.S2 || !a.SL) return BMI_ERR_INVALID;
     if (a.B <= 0 || a.tc <= 0 || a.in_mod <= 0 || a.HW <= 0 || a.C <= 0 || a.in_kind < 0 || a.in_kind > 2) return BMI_ERR_INVALID;
     if (a.in_mod != a.B && a.in_mod != a.B * a.tc) return BMI_ERR_INVALID;
@@ -363,5 +395,11 @@ int launch_head_fused(const HeadArgs& a, hipStream_t s) {
         default: launch_rt<4>(a, s); break;
     }
     BMI_CHECK_LAUNCH();
+    if (a.part) {
+        const int n = (a.imap ? a.Bc : a.B) * a.C;
+        hipLaunchKernelGGL(head_join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, groups, a.B, a.C, a.imap, a.Bc, a.S1,
+                           a.S2, a.SL);
+        BMI_CHECK_LAUNCH();
+    }
     return BMI_OK;
 }

@@ -86,6 +86,8 @@ struct HeadArgs {   // fused exit head (head_fused.hip)
     int b0;               // batch index of this launch's image 0 (bmi_forward_mcd_images), for the logits site: b0 * C is not a
                           // multiple of a Philox call, so it cannot ride in site_logits.elem_off
     double *S1, *S2, *SL; // this exit's [B][C] moment accumulators
+    double* part;         // scratch [ceil(tc / 32)][3][B][C] for the per-group partial sums of a launch with more than 32 samples, or
+                          // null (hardware atomics then: the single-kernel entry point)
 };
 int launch_head_fused(const HeadArgs& a, hipStream_t s);
 

@@ -479,9 +479,8 @@ class BatchesInFlight:
     """`n` independent engines of one model (own workspace, own device copy of the weights) on `n` streams: consecutive batches
     alternate between them, so the launch-bound once-per-batch prefix of batch k+1 (five ~50 us launches on B images) runs
     beside the sample-folded suffix of batch k instead of in front of it.  Nothing changes inside a batch — every per-sample
-    value is bit for bit the single-stream one; the float64 moment sums can differ in the last bit where more than two
-    32-sample groups of an image meet by atomic adds (T > 64), exactly as they do from one single-stream run to the next —
-    only the order in which the GPU sees the launches of neighbouring batches.  Measured on
+    value and every float64 moment sum is bit for bit the single-stream one (the 32-sample groups of an image are joined
+    in group order) — only the order in which the GPU sees the launches of neighbouring batches changes.  Measured on
     one MI355X (tools/experiments/two_batches.py), 1 -> 2 batches in flight: VGG-11 T=30 0.368 -> 0.297 ms per batch, ResNet-18
     Masksembles T=8 2.52 -> 2.23 ms, ResNet-18 multi-exit at T=13 (one rank's share of eight) 3.77 -> 3.34 ms, at T=100 24.19 ->
     23.76 ms.

@@ -152,23 +152,47 @@ def _split_classifier(seq):
 
 
 def build_vgg_graph(model, g):
-    """Op sequence of VGG19EarlyExit.forward (reference :290-324) / VGG.forward (:107-119)."""
+    """Op sequence of VGG19EarlyExit.forward (reference :290-324) / VGG.forward (:107-119).
+
+    Also compiles a mirror that went through the torch converter (``nn2bnn._convert_model``, Hardware_Artifact/converter/
+    pytorch/nn2bnn.py:32-45): a wrapped Conv2d carries a per-(image, channel) site between the conv and its BatchNorm, a wrapped
+    MaxPool2d an elementwise site on its output, a wrapped classifier an elementwise site on its logits; site ids in call order."""
+    from ...engine import _converted
     x = g.tensor(32, 32, 3)
     multi = model.multi_exit
     n_out = 5 if multi else 1
     first = True
+
+    def conv(x, wrapped, bn, stem=False):
+        m, w = _converted(wrapped)
+        return g.conv(x, m, bn, relu=True, stem=stem, site=g.site(w, channelwise=True), site_inner=w is not None)
+
+    def head(y, classifier, index):
+        site, lin = _split_classifier(classifier)
+        lin, w = _converted(lin)
+        if w is not None and site is not None:
+            raise TypeError("a converted classifier (dropout on the logits) on top of an exit dropout is not on the accelerated path")
+        if w is not None:
+            g.head(y, lin, index, site=g.site(w), site_on_logits=True)
+        else:
+            g.head(y, lin, index, site=g.site(site))
+
     for bi, block in enumerate(model.blocks):
         mods = list(block)
         i = 0
         while i < len(mods):
-            m = mods[i]
+            m, w = _converted(mods[i])
             if isinstance(m, nn.Conv2d):
                 bn = mods[i + 1] if isinstance(mods[i + 1], nn.BatchNorm2d) else None
-                x = g.conv(x, m, bn, relu=True, stem=first)      # conv(+bias) -> BN -> ReLU
+                if w is not None and bn is None:
+                    raise TypeError("a converted conv needs its BatchNorm (the site sits between the two)")
+                x = conv(x, mods[i], bn, stem=first)             # conv(+bias) -> [site] -> BN -> ReLU
                 first = False
                 i += 3 if bn is not None else 2
             elif isinstance(m, nn.MaxPool2d):
                 x = g.maxpool(x)
+                if w is not None:
+                    x = g.mask(x, g.site(w))
                 i += 1
             else:
                 raise TypeError(f"unexpected module {type(m).__name__} in a VGG block")
@@ -177,11 +201,8 @@ def build_vgg_graph(model, g):
             y = x
             fe = list(getattr(model, f"ex{bi + 1}featureextractor"))
             for j in range(0, len(fe), 3):
-                y = g.conv(y, fe[j], fe[j + 1], relu=True)
-            site, lin = _split_classifier(getattr(model, f"ex{bi + 1}linear"))
-            g.head(y, lin, bi, site=g.site(site))
+                y = conv(y, fe[j], fe[j + 1])
+            head(y, getattr(model, f"ex{bi + 1}linear"), bi)
         elif multi and bi == 3:
-            site, lin = _split_classifier(model.ex4linear)
-            g.head(x, lin, 3, site=g.site(site))                  # avg_pool2d(out, 2) on the 2x2 block-4 output
-    site, lin = _split_classifier(model.classifier)
-    g.head(x, lin, n_out - 1, site=g.site(site))
+            head(x, model.ex4linear, 3)                           # avg_pool2d(out, 2) on the 2x2 block-4 output
+    head(x, model.classifier, n_out - 1)

@@ -173,3 +173,53 @@ def test_gpu_converted_resnet18base_against_reference_golden():
     mean_logits = m(x)                                          # eval mode: sum(pred) / len(pred) over nSamples, per exit
     assert isinstance(mean_logits, list) and len(mean_logits) == 1
     np.testing.assert_allclose(mean_logits[0].cpu().numpy(), ref.mean(0)[0], rtol=0, atol=3e-2)
+
+
+# ---- ... and to the reference's own VGG19 (SA/models/vgg19/vgg19.py:186-192) ------------------------------------------------
+def test_oracle_converted_vgg19_matches_reference():
+    from oracle.vgg19 import VGG19 as OracleVGG
+    g = load_golden("converter_vgg19.npz")
+    net = _seeded_base(OracleVGG)
+    assert state_checksum(net.state_dict()) == str(g["init_checksum"])
+    synthetic_weights_(net, 0)
+    assert state_checksum(net.state_dict()) == str(g["weights_checksum"])
+    o = ConvertedNet(net, float(g["p"])).eval()
+    x = synthetic_images(int(g["B"]), seed=1234)
+    logits = mcd.mcd_passes(o, x, int(g["T"]), int(g["seed"]))[0]
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-4)          # logits up to 80
+    assert o.ctx.site == int(g["sites_per_pass"]) == 22               # 16 convs + 5 max-pools + the classifier
+
+
+def test_mirror_converts_vgg19_like_the_reference():
+    from bayesnn_fpga_amd.models.vgg19.vgg19 import VGG19
+    g = load_golden("converter_vgg19.npz")
+    net = _seeded_base(VGG19)
+    assert state_checksum(net.state_dict()) == str(g["init_checksum"])
+    m = MCDropout(net, nSamples=4, p=float(g["p"]))
+    wrappers = [type(w).__name__ for w in m.model.modules() if isinstance(w, (BayesianDropout, BayesianDropout2D))]
+    assert wrappers == list(g["wrapper_classes"]) and len(wrappers) == 43       # incl. the second references in non_sequentialized_blocks
+    assert list(m.model.state_dict().keys()) == list(g["keys"])
+    cg = CompiledGraph(m, "cpu", 8, 2)
+    sites = [op["site"]["site_id"] for op in cg.graph.ops if op.get("site")]
+    assert sorted(sites) == list(range(22)) and cg.n_exits == 1
+
+
+@pytest.mark.gpu
+def test_gpu_converted_vgg19_against_reference_golden():
+    from bayesnn_fpga_amd.models.vgg19.vgg19 import VGG19
+    g = load_golden("converter_vgg19.npz")
+    B, T, seed, p = int(g["B"]), int(g["T"]), int(g["seed"]), float(g["p"])
+    net = _seeded_base(VGG19)
+    synthetic_weights_(net, 0)
+    m = MCDropout(net, nSamples=T, p=p).to("cuda:0")
+    m.mc_seed = seed
+    x = synthetic_images(B, seed=1234).to("cuda:0")
+    m.train()
+    passes = np.stack([m(x)[0].cpu().numpy()[None] for _ in range(T)])
+    ref = g["logits"]
+    np.testing.assert_allclose(passes, ref, rtol=0, atol=4e-3 * float(np.abs(ref).max()))       # fp16 activations, logits up to 80
+    zero = ref == 0
+    assert zero.any() and np.array_equal(passes == 0, zero)
+    ref_probs = torch.softmax(torch.from_numpy(ref), -1).numpy().astype(np.float64)
+    r = m.engine(x.device, max_batch=B).predict(x, T, seed=seed)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref_probs.mean(0), rtol=0, atol=2e-2)    # (peaky softmax of logits ~80)

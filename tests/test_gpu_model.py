@@ -208,6 +208,26 @@ def test_image_partitioned_shares_reproduce_the_whole_batch(kw):
     torch.testing.assert_close(r["mean"], eng.finalize(S, T)["mean"], rtol=0, atol=1e-12)
 
 
+def test_repeated_runs_are_bit_identical():
+    """T = 100 (four 32-sample groups per image and exit): the float64 moment sums of the groups are joined in group order
+    (head_join_kernel), not by hardware atomics in arrival order — every run gives the same bits, also beside other work."""
+    model = _product(ResNet18MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    B, T = 16, 100
+    x = synthetic_images(B, seed=4).to(DEV)
+    eng = model.engine(torch.device(DEV), max_batch=B)
+    first = eng.accumulate(x, eng.new_moments(B), 0, T, 9).clone()
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for i in range(6):
+        with torch.cuda.stream(side):
+            junk.add_(1)                                       # perturb the timing
+        again = eng.accumulate(x, eng.new_moments(B), 0, T, 9)
+        torch.cuda.synchronize()
+        assert torch.equal(again, first), i
+    two = eng.accumulate(x, eng.accumulate(x, eng.new_moments(B), 0, 64, 9), 64, 36, 9)    # two calls: another grouping, 1e-12
+    torch.testing.assert_close(two, first, rtol=1e-12, atol=1e-12)
+
+
 def test_batches_in_flight_graphed_equals_eager():
     """BatchesInFlight.predict_graphed: a batch step as one hipGraph replay per slot — VGG-11 (the launch-bound config) and
     ResNet-18, two slots, repeated batches, a smaller last batch (captured on first sight), another seed (its own graph):

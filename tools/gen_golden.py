@@ -389,6 +389,47 @@ def gen_converter_resnet():
     print("converter_resnet18base", logits.shape, len(classes), "wrappers,", sites_per_pass, "sites per pass", float(np.abs(logits).max()))
 
 
+def gen_converter_vgg():
+    """The same for the reference's VGG19 (SA/models/vgg19/vgg19.py:186-192; VGG.forward :107-119): 16 wrapped convs (site before
+    the BatchNorm), 5 wrapped MaxPool2d (elementwise), the wrapped classifier (logits).  The converter also wraps the second
+    references to the same layers in ``non_sequentialized_blocks`` (unused by the forward)."""
+    from models.vgg19.vgg19 import VGG19
+    ref_dropouts, ref_nn2bnn = _import_ref_converter()
+
+    def d2(x, p=0.5, training=True, inplace=False):
+        assert training
+        return philox_dropout(CTX, x, p, channelwise=True)
+
+    B, T, seed, p = 3, 4, 55, 0.25
+    torch.manual_seed(0)
+    net = VGG19(n_exits=1, out_dim=10)
+    init = state_checksum(net.state_dict())
+    synthetic_weights_(net, 0)
+    wsum = state_checksum(net.state_dict())
+    model = ref_nn2bnn._convert_model(net, p)
+    classes = [type(m).__name__ for m in model.modules() if isinstance(m, ref_dropouts._DropoutBase)]
+    x = synthetic_images(B, seed=1234)
+    model.eval()
+    outs = []
+    orig = ref_dropouts.F.dropout, ref_dropouts.F.dropout2d
+    ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = _patched_dropout, d2
+    try:
+        with torch.no_grad():
+            for tt in range(T):
+                CTX.begin_forward(seed, tt)
+                out = model(x)
+                assert isinstance(out, list) and len(out) == 1
+                outs.append(out[0].numpy()[None])
+                sites_per_pass = CTX.site
+    finally:
+        ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = orig
+    logits = np.stack(outs)                      # [T, 1, B, C]
+    np.savez(os.path.join(OUT, "converter_vgg19.npz"), logits=logits, B=B, T=T, seed=seed, p=p, init_checksum=init,
+             weights_checksum=wsum, wrapper_classes=np.array(classes), keys=np.array(list(model.state_dict().keys())),
+             sites_per_pass=sites_per_pass)
+    print("converter_vgg19", logits.shape, len(classes), "wrappers,", sites_per_pass, "sites per pass", float(np.abs(logits).max()))
+
+
 def gen_converter():
     """Hardware_Artifact/converter/pytorch: the reference's own Dropouts.py classes and nn2bnn._convert_model applied
     to a small CNN.  nn2bnn.py imports a file that is not in the repository (``test.ThreeLayerNet``, :5): an empty
@@ -452,12 +493,17 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "converter":
         gen_converter()
         gen_converter_resnet()
+        gen_converter_vgg()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "converter_resnet":
         gen_converter_resnet()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "converter_vgg":
+        gen_converter_vgg()
+        sys.exit(0)
     gen_converter()
     gen_converter_resnet()
+    gen_converter_vgg()
     gen_philox()
     gen_masksembles()
     gen_metrics()
