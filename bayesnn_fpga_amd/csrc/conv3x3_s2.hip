@@ -44,15 +44,22 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef S2_DRAIN_STORES
+#define S2_DRAIN_STORES 0    // 1 (diagnostic): every tile starts with vmcnt(0)
+#endif
 #ifndef S2_WSPLIT
 #define S2_WSPLIT 0          // 1: a wave issues its two weight DMA instructions of a K-step in the two phases (one each) instead of both in phase 0
 #endif
 #ifndef S2_STORE_SC1
-#define S2_STORE_SC1 1       // 1: the output tile leaves with write-through stores that do not stay in the XCD's L2 (sc1): a 32-channel
+#define S2_STORE_SC1 0       // 1: the output tile leaves with write-through stores that do not stay in the XCD's L2 (sc1, inline asm).  A 32-channel
                              // chunk is half (a quarter) of an input pixel's 128-byte lines, whose other half is asked for 9 K-steps later, and
-                             // the 128 KB of output per tile were pushing those lines out of the 4 MB L2 in between.  rocprofv3 FETCH_SIZE over
-                             // the six stride-2 launches of the headline step 16.3 -> 14.3 GB (conv_igemm_wide: 17.9), wall time unchanged
-                             // (the re-fetches are Infinity-Cache hits): profiles/experiments/r3_s2_sc1_stores.log
+                             // the 128 KB of output per tile push those lines out of the 4 MB L2 in between: with sc1 stores rocprofv3 FETCH_SIZE
+                             // over the six stride-2 launches of the headline step went 16.3 -> 14.3 GB (conv_igemm_wide: 17.9) at UNCHANGED
+                             // wall time (the re-fetches are Infinity-Cache hits; profiles/experiments/r3_s2_sc1_stores.log).  OFF: hipcc does
+                             // not model an asm store (cdna_hip_programming.md 5.7 item 1); the first build without the trailing s_nop failed
+                             // every model parity test, and with it one build still gave ONE image of one dynamic-exit test a 1e-6 deviation
+                             // that a recompile with an unrelated edit removed — a data-register hazard that depends on instruction
+                             // placement is not worth a counter that does not show up in the time.
 #endif
 #ifndef S2_PIECE_PHASE
 #define S2_PIECE_PHASE 1     // phase of a K-step whose LOAD part issues the step's patch pieces (phase 0 carries 8 fragment reads and
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         // weight stages 0, 1 and the A / B pieces of chunk 0 have landed.  The previous tile's 16 output stores per thread were
         // issued BEHIND them (vmcnt retires in order): a full tile leaves them in flight, a ragged one (some stores skipped:
         // the count is not known) and the dynamic-exit form drain everything.
-        if (IMAP || !stores16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (IMAP || !stores16 || S2_DRAIN_STORES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         RAW_BARRIER();
         if (g == 1) RAW_BARRIER();                         // stagger
@@ -447,6 +454,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                 else oc = split;
             }
             const int k = tl & 15;
+            float* const poolp = TW == 4 ? ((a.wgt_b && chl >= split) ? a.pool_b : a.pool) : nullptr;     // wave-uniform (per channel half)
+            if (poolp) {
+                // ReLU + global average pool fused (the conv feeds an exit head only): a wave's pixel tile j is image wp * 8 + j of
+                // the tile, its 16 pixels the 16 lanes of a DPP row — four v_add_f32 with DPP (quad xor 1, xor 2, half mirror, row
+                // mirror) leave the sum in every lane; lane 0 of each row stores 4 consecutive channels as fp32.  Nothing goes
+                // through LDS; the three barriers keep step with a channel half that takes the ordinary path.
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c4 = chl + wc * 64 + 16 * i + 4 * kq;
+                    const f32x4_e sc = *(const f32x4_e*)(bn_scale + c4), bi = *(const f32x4_e*)(bn_bias + c4);
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        f32x4_e v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = fmaxf(__builtin_fmaf(acc[i][j][e], sc[e], bi[e]), 0.f);     // (explicitly fused: the same bits in every instantiation)
+                            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+                            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+                            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // 7 - lane (half row)
+                            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // 15 - lane (row)
+                            v[e] = x * (1.f / 16.f);
+                        }
+                        int n = cur_n0 + wp * 8 + j;
+                        if constexpr (IMAP) n = row_tabs[cur_tsel * 16 + wp * 8 + j];
+                        else if (n >= a.N) n = -1;
+                        if (l16 == 0 && n >= 0) *(f32x4_e*)(poolp + (size_t)n * oc + chg + wc * 64 + 16 * i + 4 * kq) = v;
+                    }
+                }
+                lds_barrier(); lds_barrier(); lds_barrier();
+            } else
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 if (rr) lds_barrier();                      // round 0's reads are done
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                 }
             }
         }
-        stores16 = cur_n0 + IMGS <= a.N;
+        stores16 = cur_n0 + IMGS <= a.N;              // (a pooled half issues 32 stores: vmcnt(16) then waits for half of them, never for less)
         vb = nvb;
     }
 #undef S2_STEP
@@ -546,6 +583,7 @@ int launch_conv3x3_s2(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
     if (a.wgt_b && (!a.out_b || a.split <= 0 || a.split >= a.Cout || a.split % 128 != 0)) return BMI_ERR_INVALID;
+    if ((a.pool || a.pool_b) && a.Ho != 4) return BMI_ERR_UNSUPPORTED;      // the pooled epilogue sums the 16 lanes of a DPP row = a 4x4 map
     // 32-bit byte offsets inside a buffer descriptor: a tile's own images (always), the whole tensor for the dynamic-exit form
     if (a.imap && (size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;
     if (a.in_mod < a.N && !a.imap) return BMI_ERR_UNSUPPORTED;      // (a plain conv on a deterministic input runs once per batch: N == in_mod)

@@ -27,6 +27,7 @@ struct TensorInfo {
     bool stoch = false;
     bool bits = false;          // holds keep bits (1 bit per element) instead of fp16 activations
     bool f32 = false;           // fp32 activations (output of a DENSE op)
+    bool pooled_now = false;    // (run time) the producing conv of this chunk wrote fp32 means over its 4x4 map instead of the tensor
     int first = -1, last = -1;  // suffix op indices (stochastic tensors only)
     size_t offset = 0;          // byte offset in the workspace
 };
@@ -40,6 +41,8 @@ struct OpInfo {
     int bits_tensor = -1;   // CONV: keep bits applied to the input while staging, or -1
     float out_mul = 1.f;    // CONV: multiplies the folded-BN scale (1/(1-p) of the input-side site)
     int nsplit = 0;         // CONV (prefix): split-K workgroups per tile (bmi_plan; 0 = none)
+    bool pool_ok = false;   // CONV: its 4x4 output feeds ONE exit head and nothing else: conv3x3_s2 may write the pooled means instead
+    bool pair_pool_ok = false;   // ... the same for the second conv of a pair
     bool has_pair = false;  // CONV: a second conv on the same input rides in this launch (conv_igemm_wide pair mode)
     bmi_op_desc pair_d;
     int pair_cout = 0;
@@ -163,6 +166,7 @@ int& opt_dense_exact() { static int v = 0; return v; }
 int& opt_splitk() { static int v = 1; return v; }
 int& opt_conv_stream() { static int v = 1; return v; }
 int& opt_conv_wide() { static int v = 1; return v; }
+int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
@@ -201,6 +205,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_s2") == 0) {
         if (value < 0 || value > 2) return BMI_ERR_INVALID;
         opt_conv_s2() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "conv_pool") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_conv_pool() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_wide") == 0) {
@@ -495,6 +504,36 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
             }
         }
     }
+    // ReLU + global average pool fused into the producing conv: a plain 3x3 stride-2 conv whose 4x4 output map feeds ONE exit head and
+    // nothing else (ex1conv3 / ex2conv2 / ex3conv1 of the ResNets: relu -> avg_pool2d(4) -> Linear, resnet18.py:309-314, :320-325,
+    // :331-335) may write fp32 means [row][Cout] instead of the map when conv3x3_s2 takes the launch (decided per launch: run_op).
+    for (std::vector<OpInfo>* ops : {&e->prefix, &e->suffix}) {
+        auto readers = [&](int id, int* heads) {
+            int n = 0;
+            *heads = 0;
+            for (const std::vector<OpInfo>* o2 : {&e->prefix, &e->suffix})
+                for (const OpInfo& c : *o2) {
+                    const bmi_op_desc& d = c.d;
+                    const bool conv = d.kind == BMI_OP_CONV || d.kind == BMI_OP_STEM;
+                    if (d.in == id) { ++n; if (d.kind == BMI_OP_HEAD) ++*heads; }
+                    if (conv && d.residual == id) ++n;
+                    if (conv && d.in2 == id) ++n;
+                    if (c.bits_tensor == id) ++n;
+                }
+            return n;
+        };
+        for (OpInfo& c : *ops) {
+            if (c.d.kind != BMI_OP_CONV) continue;
+            auto eligible = [&](const bmi_op_desc& d, int cout) {
+                const TensorInfo& to = e->tensors[d.out];
+                int heads = 0;
+                return d.ksize == 3 && d.stride == 2 && d.pad == 1 && to.h == 4 && to.w == 4 && d.residual < 0 && d.in2 < 0 &&
+                       d.site.kind == BMI_SITE_NONE && cout % 128 == 0 && readers(d.out, &heads) == 1 && heads == 1;
+            };
+            c.pool_ok = c.bits_tensor < 0 && eligible(c.d, c.cout);
+            c.pair_pool_ok = c.has_pair && eligible(c.pair_d, c.pair_cout);
+        }
+    }
     // live ranges of the stochastic tensors over the suffix
     for (int k = 0; k < (int)e->suffix.size(); ++k) {
         const bmi_op_desc& d = e->suffix[k].d;
@@ -695,6 +734,19 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 p.out_b = (_Float16*)(ws + e->tensors[op.pair_d.out].offset);
                 p.split = op.cout;
                 p.Cout = op.cout + op.pair_cout;
+                e->tensors[d.out].pooled_now = e->tensors[op.pair_d.out].pooled_now = false;
+                if (opt_conv_pool() && (op.pool_ok || op.pair_pool_ok)) {
+                    ConvArgs q = p;          // the pooled means take the place of the map in the workspace (16 x 4 B <= 16 x 16 x 2 B per channel)
+                    if (op.pool_ok) q.pool = (float*)q.out;
+                    if (op.pair_pool_ok) q.pool_b = (float*)q.out_b;
+                    const int rcp = launch_conv3x3_s2(q, s);
+                    prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
+                    if (rcp != BMI_ERR_UNSUPPORTED) {
+                        e->tensors[d.out].pooled_now = op.pool_ok;
+                        e->tensors[op.pair_d.out].pooled_now = op.pair_pool_ok;
+                        return rcp;
+                    }
+                }
                 int rc = launch_conv3x3_s2(p, s);
                 prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
                 if (rc != BMI_ERR_UNSUPPORTED) return rc;
@@ -713,6 +765,17 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 a.nsplit = op.nsplit;
                 prof.tag(BMI_CONV_FAMILY_IGEMM, flops, bytes);
                 return launch_conv_igemm(a, s);
+            }
+            e->tensors[d.out].pooled_now = false;
+            if (opt_conv_pool() && op.pool_ok) {
+                ConvArgs q = a;
+                q.pool = (float*)q.out;
+                const int rcp = launch_conv3x3_s2(q, s);
+                if (rcp != BMI_ERR_UNSUPPORTED) {
+                    prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
+                    e->tensors[d.out].pooled_now = true;
+                    return rcp;
+                }
             }
             int fam = -1;
             const int rcc = launch_conv(a, s, &fam);
@@ -745,10 +808,10 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             HeadArgs a;
             std::memset(&a, 0, sizeof(a));
             a.in = ws + tin.offset;
-            a.in_kind = tin.f32 ? 1 : (e->bf16 ? 2 : 0);
+            a.in_kind = (tin.f32 || tin.pooled_now) ? 1 : (e->bf16 ? 2 : 0);      // pooled_now: fp32 means [row][K] written by the conv
             a.in_mod = tin.stoch ? n_rows : B;
             a.imap = imap; a.Bc = Bc;
-            a.HW = tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = imap ? N / Bc : N / B;
+            a.HW = tin.pooled_now ? 1 : tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = imap ? N / Bc : N / B;
             a.w = (const float*)d.weight; a.bias = d.bias; a.C = e->out_dim;
             const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
             a.site = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0, site_off(d.site, (size_t)tin.c, (size_t)tin.c));

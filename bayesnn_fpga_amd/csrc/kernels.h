@@ -27,6 +27,11 @@ struct ConvArgs {
     const float* bias_b;
     _Float16* out_b;
     int split;
+    // fused ReLU + global average pool of a 4x4 output map (conv3x3_s2 only): when set, the conv (pool: the launch's conv / the
+    // first of a pair; pool_b: the second) writes fp32 means over its 16 output pixels, [row][Cout of that conv], INSTEAD of its
+    // fp16 activation tensor — the conv feeds nothing but an exit head (relu -> avg_pool2d(4) -> Linear, resnet18.py:309-314)
+    float* pool;
+    float* pool_b;
     // inner site (converter/pytorch semantics): out = relu?((acc*scale + bias) * mask + bias_post (+ res))
     const float* bias_post;  // or null
     int site_inner;          // 1: a.site multiplies before bias_post / residual / ReLU
@@ -125,6 +130,7 @@ int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
 int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
 int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
 int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
+int& opt_conv_pool();          // 1: a conv whose 4x4 map feeds one exit head only writes the pooled means (conv3x3_s2), 0: never
 int& opt_conv_s2();            // 1: plain 3x3 stride-2 convs run in conv3x3_s2 (2 = without its minimum-grid rule: tests), 0: conv_igemm_wide
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
 int& opt_splitk();             // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch

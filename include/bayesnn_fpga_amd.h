@@ -160,6 +160,8 @@ const char* bmi_error_string(int code);
  *   "conv_s2"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-2 convs with a BN + ReLU epilogue on
  *                                           32x32 / 16x16 / 8x8 maps with Cout % 256 == 0 (a pair's channels together) run in conv3x3_s2 (input
  *                                           patch resident in LDS as four parity planes, persistent) instead of conv_igemm_wide
+ *   "conv_pool"                             0 | 1: a plain 3x3 stride-2 conv whose 4x4 output map feeds one exit head and nothing else writes
+ *                                           fp32 means over the map (ReLU + avg_pool2d(4) fused into conv3x3_s2's epilogue) instead of the map
  *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
  *   "splitk"                                0 | 1, read by bmi_plan: 3x3 convs of the once-per-batch prefix whose grid is <= 64 tiles (VGG's convs on
  *                                           2x2 maps) run split-K: one workgroup per (tile, tap), fp32 partial sums, a finishing pass

@@ -59,3 +59,30 @@ def test_real_batch_against_oracle(name):
     print(f"{name}: B={B} T={T} max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
     assert err_m <= TOL and err_v <= TOL
     np.testing.assert_allclose(mean.sum(-1), 1.0, atol=1e-6)
+
+
+def test_fused_relu_avgpool_equals_the_separate_head_pooling():
+    """A plain 3x3 stride-2 conv whose 4x4 map feeds one exit head only (ex1conv3 / ex2conv2 / ex3conv1, the last one as the second
+    conv of a pair) writes fp32 means over the map from conv3x3_s2's epilogue instead of the fp16 map ("conv_pool", default on,
+    when that kernel takes the launch: B = 250 here).  Against the same engine with the fusion off: equal to the fp16 rounding of
+    the 4x4 activations it no longer rounds (1e-4 on a sum of T probabilities), and NOT equal bit for bit (the fused path ran);
+    both within 1e-3 of each other in mean and variance."""
+    from bayesnn_fpga_amd import _lib
+    T, seed = 3, 5
+    model = build_seeded(ResNet18MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    synthetic_weights_(model, 0)
+    eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    x = synthetic_images(B, seed=1234).to(DEV)
+    fused = eng.predict(x, T, seed=seed)
+    _lib.set_option("conv_pool", 0)
+    try:
+        plain = eng.predict(x, T, seed=seed)
+    finally:
+        _lib.set_option("conv_pool", 1)
+    for k in ("mean", "var"):
+        d = (fused[k] - plain[k]).abs()
+        assert float(d.max()) < 2e-4, (k, float(d.max()))
+    assert not torch.equal(fused["mean"][:3], plain["mean"][:3])            # the three early exits took the fused epilogue
+    assert torch.equal(fused["mean"][3], plain["mean"][3])                  # the final exit's layer4 output is not a stride-2 conv's
+    again = eng.predict(x, T, seed=seed)
+    assert torch.equal(again["mean"], fused["mean"])
