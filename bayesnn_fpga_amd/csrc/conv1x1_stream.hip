@@ -31,10 +31,19 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // TJ = 2 (default): 128-pixel tile, 32 KB of LDS, three (residual launches: 164 VGPRs) or four workgroups per CU.
 // TJ = 4 ("conv_stream" = 3, the first version): 256-pixel tile, 64 KB, two workgroups per CU.  Same-process A/B at 16000
 // image-samples, tails 128 -> 512 / 256 -> 1024 / 512 -> 2048: 2467 / 1476 / 1027 us with TJ = 4, 2245 / 1370 / 963 us with TJ = 2.
+#ifndef STREAM_RES_PREFETCH
+#define STREAM_RES_PREFETCH 0   // 1: the residual tile is DMA'd into its own 16*TJ KB right behind the first K-step's operands
+#endif
+#ifndef STREAM_KD
+#define STREAM_KD 64            // channels per barrier pair: 64 | 128 (two [weights | pixels] sub-tiles per wait)
+#endif
 template <int EPI, bool BF, int TJ = 4>
-__global__ __launch_bounds__(256, TJ == 4 ? 2 : 3) void conv1x1_stream_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == BMI_EPI_LITE) || STREAM_KD == 128 ? 2 : 3)) void conv1x1_stream_kernel(ConvArgs a) {
     constexpr int SBP = 64 * TJ;
-    __shared__ __attribute__((aligned(16))) char smem[TJ == 4 ? BMI_EPILOGUE_LDS_BYTES : BMI_EPILOGUE_LDS_BYTES / 2];
+    constexpr int NSUB = TJ == 2 ? STREAM_KD / 64 : 1;
+    constexpr int SUB = (TJ == 4 ? BMI_EPILOGUE_LDS_BYTES : BMI_EPILOGUE_LDS_BYTES / 2);     // one [weights | pixels] sub-tile = the epilogue's tile
+    constexpr bool RPRE = STREAM_RES_PREFETCH && EPI == BMI_EPI_LITE && TJ == 2 && NSUB == 1;
+    __shared__ __attribute__((aligned(16))) char smem[NSUB * SUB + (RPRE ? SUB : 0)];
     constexpr int XBASE = SBC * 128;   // pixel tile behind the weight tile
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,6 +78,28 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : 3) void conv1x1_stream_kernel(Co
     }
 #pragma unroll
     for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i], smem + XBASE + (i * 256 + wave * 64) * 16);
+    const int nK = a.Cin / 64;
+#pragma unroll
+    for (int u = 1; u < NSUB; ++u)
+        if (u < nK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) GLDS16(wsrc[i] + u * 64, smem + u * SUB + (i * 256 + wave * 64) * 16);
+#pragma unroll
+            for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i] + u * 64, smem + u * SUB + XBASE + (i * 256 + wave * 64) * 16);
+        }
+    if constexpr (RPRE) {
+        // the residual tile, in epilogue_lite's layout (chunk q of pixel row p at q ^ (p & 15)), behind the first K-step's operands
+        if (a.res) {
+#pragma unroll
+            for (int i = 0; i < 4 * TJ; ++i) {
+                const int q = i * 256 + tid, p = q >> 4, pos = q & 15;
+                const int m = pix0 + p;
+                const _Float16* src = m < a.M ? a.res + ((size_t)((m / HoWo) % a.res_mod) * HoWo + (m % HoWo)) * a.Cout + ch0 + ((pos ^ (p & 15)) << 3)
+                                              : a.res;
+                GLDS16(src, smem + SUB + (i * 256 + wave * 64) * 16);
+            }
+        }
+    }
 
     typedef float accv __attribute__((ext_vector_type(4)));
     accv acc[4][2 * TJ];
@@ -82,33 +113,42 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : 3) void conv1x1_stream_kernel(Co
     const int a_off = (wc * 64 + r) * 128;
     const int b_off = XBASE + (wp * (32 * TJ) + r) * 128;
     const int sw_r = (r >> 1) & 7;
-    const int nK = a.Cin / 64;
-    for (int ks = 0; ks < nK; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int ks = 0; ks < nK; ks += NSUB) {
+        // (vmcnt retires in order: the prefetched residual sits BEHIND the first K-step's operands and in front of the later ones)
+        if (RPRE && ks == 0 && a.res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // K-step ks has landed (every wave waited for its own pieces)
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int coff = ((4 * sub + kq) ^ sw_r) << 4;
-            half8 af[4], bf[2 * TJ];
+        for (int u = 0; u < NSUB; ++u) {
+            if (ks + u >= nK) break;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(smem + a_off + i * 16 * 128 + coff);
+            for (int sub = 0; sub < 2; ++sub) {
+                const int coff = ((4 * sub + kq) ^ sw_r) << 4;
+                half8 af[4], bf[2 * TJ];
 #pragma unroll
-            for (int j = 0; j < 2 * TJ; ++j) bf[j] = *(const half8*)(smem + b_off + j * 16 * 128 + coff);
+                for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(smem + u * SUB + a_off + i * 16 * 128 + coff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 2 * TJ; ++j) bf[j] = *(const half8*)(smem + u * SUB + b_off + j * 16 * 128 + coff);
 #pragma unroll
-                for (int j = 0; j < 2 * TJ; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2 * TJ; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
+            }
         }
-        if (ks + 1 < nK) {
+        if (ks + NSUB < nK) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();             // every wave has read K-step ks: the buffer may be refilled
             asm volatile("" ::: "memory");
-            const int koff = (ks + 1) * 64;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) GLDS16(wsrc[i] + koff, smem + (i * 256 + wave * 64) * 16);
+            for (int u = 0; u < NSUB; ++u) {
+                if (ks + NSUB + u >= nK) break;
+                const int koff = (ks + NSUB + u) * 64;
 #pragma unroll
-            for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i] + koff, smem + XBASE + (i * 256 + wave * 64) * 16);
+                for (int i = 0; i < 4; ++i) GLDS16(wsrc[i] + koff, smem + u * SUB + (i * 256 + wave * 64) * 16);
+#pragma unroll
+                for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i] + koff, smem + u * SUB + XBASE + (i * 256 + wave * 64) * 16);
+            }
         }
     }
 
@@ -122,7 +162,8 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : 3) void conv1x1_stream_kernel(Co
         off = (size_t)(pix0 + p) * a.Cout;
         return pix0 + p < a.M;
     };
-    epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
+    if constexpr (RPRE) epilogue_lite<TJ, BF, true>(a, acc, smem + SUB, tid, ch0, pixmap, offmap);
+    else epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
 }
 
 bool conv_takes_stream_kernel(int ksize, int stride, int pad, int cin, int cout) {

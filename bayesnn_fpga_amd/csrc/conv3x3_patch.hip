@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         const int nch2 = a.Cin2 / 64;
         for (int c2 = 0; c2 < nch2; ++c2) {
             lds_barrier();   // every wave is done with the patch and the weight buffers
+            uint8_t kb[2 * TJ];                  // in2_bits: keep flags of this thread's pieces (8 channels each)
 #pragma unroll
             for (int i = 0; i < 2 * TJ; ++i) {   // BP cells x 8 pieces = 256 threads x 2*TJ
                 const int q = tid + 256 * i;
@@ -250,17 +251,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 const int oy = rem / TW, ox = rem - oy * TW;
                 const int c = cp ^ PSW(ox + KA * oy);
                 const int n = n0 + img;
-                const int nm = map_image<IMAP>(a, n) % a.in2_mod;
-                const _Float16* src = n < a.N ? a.in2 + (((size_t)nm * a.H2 + (size_t)(y0 + oy) * a.stride2) * a.W2 +
-                                                        (size_t)(x0 + ox) * a.stride2) * a.Cin2 + c2 * 64 + c * 8
+                const int row = map_image<IMAP>(a, n);
+                const int nm = row % a.in2_mod;
+                const size_t pix = ((size_t)(y0 + oy) * a.stride2) * a.W2 + (size_t)(x0 + ox) * a.stride2;
+                const _Float16* src = n < a.N ? a.in2 + (((size_t)nm * a.H2) * a.W2 + pix) * a.Cin2 + c2 * 64 + c * 8
                                               : (const _Float16*)g_zero_page;
                 GLDS16(src, patch + (i * 256 + wave * 64) * 16);
+                kb[i] = 0xff;
+                if (MS == 16 && a.in2_bits && n < a.N) kb[i] = a.in2_bits[(((size_t)row * a.H2) * a.W2 + pix) * (a.Cin2 >> 3) + c2 * 8 + c];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 GLDS16(a.wgt2 + (size_t)(ch0 + w_row + 32 * i) * a.Cin2 + c2 * 64 + ((tid & 7) ^ w_sw) * 8,
                        wbuf + (i * 256 + wave * 64) * 16);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (MS == 16 && a.in2_bits) {        // each thread clears the dropped elements of the pieces it fetched itself (launcher: 16x16x32 form only)
+#pragma unroll
+                for (int i = 0; i < 2 * TJ; ++i) {
+                    u32x4* const pp = (u32x4*)(patch + (i * 256 + tid) * 16);
+                    u32x4 v = *pp;
+                    const int b = kb[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(b, 2 * j, 1), hi = (unsigned)__builtin_amdgcn_sbfe(b, 2 * j + 1, 1);
+                        v[j] &= (lo & 0xffffu) | (hi & 0xffff0000u);
+                    }
+                    *pp = v;
+                }
+            }
             lds_barrier();
 #pragma unroll
             for (int kk = 0; kk < KSUB; ++kk) {
@@ -313,6 +331,7 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     const long tiles = (long)((a.N + IMGS - 1) / IMGS) * (a.Ho / TH) * (a.Wo / TW) * (a.Cout / 128);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const int ms = (a.imap || a.bf16) ? 16 : opt_mfma_shape_patch();   // bf16 / dynamic exit: the 16x16x32 shape only
+    if (a.in2_bits && (ms != 16 || TW != 16)) return BMI_ERR_UNSUPPORTED;   // keep bits on the shortcut's input: the 16x16-map, 16x16x32 form
     const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, ms) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
     const dim3 grid((unsigned)tiles), block(256);
 #define PATCH_LAUNCH(EPI_, MS_, BF_, IMAP_) \

@@ -77,6 +77,15 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef S2_ABL_NOSTORE
 #define S2_ABL_NOSTORE 0     // the epilogue runs but stores nothing
 #endif
+#ifndef S2_ABL_NOBITS
+#define S2_ABL_NOBITS 0      // masked-input form: no keep-bit DMA (the masking reads whatever the slots hold)
+#endif
+#ifndef S2_ABL_NORMW
+#define S2_ABL_NORMW 0       // masked-input form: the pieces are not masked in LDS
+#endif
+#ifndef S2_MASK_PHASE
+#define S2_MASK_PHASE 0      // masked-input form: phase of a K-step whose LOAD part masks the pieces that are due
+#endif
 #ifndef S2_ABL_NOEPI
 #define S2_ABL_NOEPI 0       // no epilogue at all (one accumulator element per lane is stored so the MFMAs stay live)
 #endif
@@ -88,9 +97,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // trip.  Timing probes (profiles/experiments/r3_s2_ablation.log) showed the 32x32 / 16x16 classes 15-20 % faster WITHOUT the
 // patch DMA, which suggested that window; a fourth stage (one more K-step, built and kept behind -DS2_NST_BIG=4) measured
 // 1-2 % SLOWER on all three classes (same-box A/B, r3_s2_stages_phase.log): the window is not what they wait for.
-template <int TW, int NST_ = (TW == 4 ? 3 : S2_NST_BIG)>
+// MSK = masked input (ConvArgs::in_bits): the patch is DMA'd from the deterministic (pre-scaled) tensor, a piece's keep bits ride
+// along as one more DMA (a dword per lane into a 2 KB slot), and the thread that issued a piece clears the dropped elements of
+// ITS 16 bytes in LDS one K-step after the piece has landed — a piece is readable one step later than without the mask.
+template <int TW, int NST_ = (TW == 4 ? 3 : S2_NST_BIG), bool MSK_ = false>
 struct S2Geom {
     static constexpr int NST = NST_;
+    static constexpr bool MSK = MSK_;
+    static constexpr int LAND = NST + (MSK ? 1 : 0);              // a piece issued in step s is readable from step s + LAND on
     static_assert(NST == 3 || NST == 4, "weight stages");
     static constexpr int BN_MAX = TW == 4 ? 1024 : 512;           // channels of the launch (both convs of a pair): the BN table
     static constexpr int CT = 256, PX = 256, IMGS = PX / (TW * TW);
@@ -120,7 +134,7 @@ struct S2Geom {
     // stages: they must have landed NST - 1 steps later, before step 0); B pieces (next chunk): steps 7, 8; own-period pieces:
     // one per step from step 0.
     __host__ __device__ static constexpr int pstep(int k) {
-        return k < NA ? (NST == 3 ? 5 + (2 * k) / NA : 5) : (k < PRO ? 7 + (2 * (k - NA)) / NB : k - PRO);
+        return k < NA ? (NST == 3 && !MSK ? 5 + (2 * k) / NA : 5) : (k < PRO ? 7 + (2 * (k - NA)) / NB : k - PRO);
     }
     __host__ __device__ static constexpr int pieces_at(int s) { int n = 0; for (int k = 0; k < NPT; ++k) n += pstep(k) == s ? 1 : 0; return n; }
     // Validity of that schedule (see the hazard notes in the kernel): a plane last read in step L may be overwritten from
@@ -130,9 +144,9 @@ struct S2Geom {
         for (int k = 0; k < NPT; ++k) {
             const int s = pstep(k);
             if (k < PRO) {            // carries the NEXT chunk: period steps 9 + first[lo] is the deadline
-                if (s < last[hi(k)] + 2 || s > 8 || s + NST > 9 + first[lo(k)]) return false;
+                if (s < last[hi(k)] + 2 || s > 8 || s + LAND > 9 + first[lo(k)]) return false;
             } else {                  // carries its own chunk; the plane was last read in the previous period
-                if (s + 9 < last[hi(k)] + 2 || s + NST > first[lo(k)] || s > 4) return false;
+                if (s + 9 < last[hi(k)] + 2 || s + LAND > first[lo(k)] || s > 4) return false;
             }
         }
         for (int s = 0; s < 9; ++s)
@@ -142,7 +156,7 @@ struct S2Geom {
     static_assert(schedule_ok(), "patch refill schedule violates a WAR / RAW window");
     // DMA instructions of step s of a chunk (`last`: the tile's last chunk — no next-chunk pieces, no weights beyond the tile)
     __host__ __device__ static constexpr bool w_issued(int s, bool last) { return s + NST - 1 <= 8 || !last; }
-    __host__ __device__ static constexpr int p_issued(int s, bool last) { return (s <= 4 || !last) ? pieces_at(s) : 0; }
+    __host__ __device__ static constexpr int p_issued(int s, bool last) { return ((s <= 4 || !last) ? pieces_at(s) : 0) * (MSK && !S2_ABL_NOBITS ? 2 : 1); }   // (+ the bits DMA)
     // What may still be in flight when step S ends: everything issued BEHIND the weights of step S + 1 (which were issued first
     // thing in step S - (NST - 2)): that step's pieces, then weights + pieces of the steps up to S.  (Steps before 0 are the
     // previous chunk's, never a last one; in a tile's first chunk they do not exist and the count is merely generous: the
@@ -166,7 +180,19 @@ struct S2Geom {
     static constexpr int END_PIECES = P_OFF + NPT * PIECE;
     static constexpr int WL_OFF = (END_PIECES + WST > E_OFF + E_BYTES ? END_PIECES : E_OFF + E_BYTES - WST);
     static constexpr int BN_OFF = WL_OFF + WST;
-    static constexpr int LDS_BYTES = BN_OFF + 2 * BN_MAX * 4 + 128;     // + the two image-row tables of the dynamic-exit instantiation
+    static constexpr int BITS_OFF = BN_OFF + 2 * BN_MAX * 4 + 128;      // (behind the two image-row tables of the dynamic-exit instantiation)
+    // keep-bit slots (2 KB: a dword per lane) of the pieces in flight.  A slot is live from the piece's issue to its masking three
+    // steps later: own-period pieces (steps 0-4 -> 3-7) take slots 0-4, the A pieces (step 5 -> 8) slots 0, 1, 5, the B pieces
+    // (steps 7, 8 -> 1, 2 of the next period) slots 2, 3.
+    __host__ __device__ static constexpr int first_due(int S) {       // first piece whose masking is due in step S (issued in step S - 3 or S + 6), or -1
+        for (int k = 0; k < NPT; ++k)
+            if (pstep(k) + 3 == S || pstep(k) + 3 == S + 9) return k;
+        return -1;
+    }
+    static constexpr int NSLOT = MSK ? 6 : 0;
+    __host__ __device__ static constexpr int slot(int k) { return k >= PRO ? k - PRO : (k < NA ? (k < 2 ? k : 5) : 2 + (k - NA)); }
+    static_assert(!MSK || (NA == 3 && NB == 2 && NOWN == 5), "keep-bit slot plan");
+    static constexpr int LDS_BYTES = BITS_OFF + NSLOT * 2048;
     static_assert(BN_OFF - E_OFF >= E_BYTES, "epilogue staging area");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __host__ __device__ static constexpr int wstage_off(int st) { return st == NST - 1 ? WL_OFF : st * WST; }
@@ -190,9 +216,10 @@ __host__ __device__ constexpr int s2_tap(int s) {
     return t[s];
 }
 
-template <int TW, bool BF, bool IMAP>
+template <int TW, bool BF, bool IMAP, bool MSK = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_tiles) {
-    using G = S2Geom<TW>;
+    using G = S2Geom<TW, (TW == 4 ? 3 : S2_NST_BIG), MSK>;
+    static_assert(!MSK || (TW == 16 && !IMAP), "masked input: one image per tile, the ordinary form");
     constexpr int CT = G::CT, IMGS = G::IMGS, NPT = G::NPT, PRO = G::PRO, NST = G::NST;
     constexpr int TI = 4, TP = 8;
     typedef float accv __attribute__((ext_vector_type(4)));
@@ -275,7 +302,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     // one descriptor per 128-row half of the channel tile (a pair's second conv has its own weight tensor)
     const unsigned woff = 2u * ((unsigned)(tid >> 2) * Ktot + (((tid & 3) ^ (((tid >> 4) & 1) << 1)) << 3));
     const unsigned wbytes = 2u * 128u * Ktot;
-    __amdgpu_buffer_rsrc_t rs_w0, rs_w1, rs_in;
+    __amdgpu_buffer_rsrc_t rs_w0, rs_w1, rs_in, rs_bits;
+
     int ch0 = 0, n0 = 0;
 
     // (the K offset of a step — tap and channel chunk, wave-uniform — rides in the instruction's SGPR offset: the per-lane
@@ -301,7 +329,48 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             o_ = (pre[K] == OOB || row_ < 0) ? OOB : 2u * ((unsigned)row_ * HWC + (pre[K] & 0xffffffu));     \
         }                                                                                                    \
         if (!S2_ABL_NOPATCH) BLDS16(rs_in, o_, __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0)), pbuf + ((K) * 512 + wave * 64) * 16); \
+        if constexpr (MSK && !S2_ABL_NOBITS) {                                                               \
+            /* the cell's 32 keep bits of this chunk (the dword that holds this piece's byte); beyond the descriptor: zeros */ \
+            /* (derived from pre[K] at every issue: as loop invariants the ten offsets are spilled, and a scratch reload in */ \
+            /*  front of a DMA is a vmcnt wait for everything in flight)                                                    */ \
+            unsigned bo_ = pre[K];                                                                           \
+            asm volatile("" : "+v"(bo_));                                                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bits, (__attribute__((address_space(3))) void*)(smem + G::BITS_OFF + G::slot(K) * 2048 + wave * 256), \
+                                                     4, (bo_ >> 4) & ~3u, __builtin_amdgcn_readfirstlane((unsigned)(C0) >> 3), 0, 0); \
+        }                                                                                                    \
     }
+    // The thread that issued piece K clears the dropped elements of its 16 bytes: byte (logical chunk) of the slot's dword -> four
+    // dword masks.  Own DMA only: the thread's counted vmcnt wait is all it needs; the barriers of the step publish the result.
+    typedef unsigned int u32x4_m __attribute__((ext_vector_type(4)));
+#define MASK_LOAD(K, W, V)                                                                                   \
+    if (!S2_ABL_NORMW) {                                                                                     \
+        int t4_ = tid * 4;                                                                                   \
+        asm volatile("" : "+v"(t4_));                                                                        \
+        W = *(const unsigned*)(smem + G::BITS_OFF + G::slot(K) * 2048 + t4_);                                /* this lane's dword of the slot */ \
+        V = *(const u32x4_m*)(pbuf + ((K) * 512 + tid) * 16);                                                \
+    }
+#define MASK_STORE(K, W, V)                                                                                  \
+    if (!S2_ABL_NORMW) {                                                                                     \
+        unsigned sh_ = pre[K];                                                                               \
+        asm volatile("" : "+v"(sh_));                                                                        \
+        const int b_ = (int)((W) >> ((sh_ >> 1) & 24u));                                                     \
+        u32x4_m v_ = V;                                                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+            const unsigned lo_ = (unsigned)__builtin_amdgcn_sbfe(b_, 2 * i_, 1), hi_ = (unsigned)__builtin_amdgcn_sbfe(b_, 2 * i_ + 1, 1); \
+            v_[i_] &= (lo_ & 0xffffu) | (hi_ & 0xffff0000u);                                                 \
+        }                                                                                                    \
+        *(u32x4_m*)(pbuf + ((K) * 512 + tid) * 16) = v_;                                                     \
+    }
+#define MASK_P(K)                                                                                            \
+    {                                                                                                        \
+        unsigned mw_;                                                                                        \
+        u32x4_m mv_;                                                                                         \
+        MASK_LOAD(K, mw_, mv_);                                                                              \
+        MASK_STORE(K, mw_, mv_);                                                                             \
+    }
+    // piece whose masking is due in step S of a period (issued three steps earlier), -1: none.  (Step 8: the A pieces, all three
+    // issued in step 5: the first one takes the early-load slot, the others follow serially.)
+#define MASK_DUE(S, K) (G::pstep(K) + 3 == (S) || G::pstep(K) + 3 == (S) + 9)
     // Tile VB: its buffer descriptors; its first two weight stages and the pieces that hold planes A / B only (chunk 0) are
     // issued: everything the first K-steps read.
 #define SETUP_TILE(VB)                                                                                       \
@@ -318,7 +387,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 2u * (unsigned)a.in_mod * HWC, 0x00020000); \
         } else {                                                                                             \
             const int nimg_ = a.N - n0 < IMGS ? a.N - n0 : IMGS;                                             \
-            rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n0 * HWC), 0, 2u * (unsigned)nimg_ * HWC, 0x00020000); \
+            /* (one image per tile: a deterministic input of in_mod images serves every sample; launcher: in_mod >= N otherwise) */ \
+            const int row0_ = IMGS == 1 ? n0 % a.in_mod : n0;                                                \
+            rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)row0_ * HWC), 0, 2u * (unsigned)nimg_ * HWC, 0x00020000); \
+            if constexpr (MSK)                                                                               \
+                rs_bits = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in_bits + (size_t)n0 * (HWC >> 3)), 0, HWC >> 3, 0x00020000); \
         }                                                                                                    \
         ISSUE_W(0, 0);                                                                                       \
         if constexpr (IMAP) {                                                                                \
@@ -364,12 +437,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         const int st_r_ = NST == 3 ? (S) % 3 : ((chunk + (S)) & 3), st_w_ = NST == 3 ? ((S) + 2) % 3 : ((chunk + (S) + 3) & 3); \
         const char* ws_ = smem + G::wstage_off(st_r_) + a_off;                                                 \
         const char* pb_ = smem + (dy_ * G::cols(pl_) + dx_) * 64 + (boff[pl_] ^ (dy_ << 5));                   \
+        /* MSK: pieces issued three steps ago have landed (this thread's wait at the end of the previous step).  The first due */ \
+        /* piece is read BEFORE the fragment reads and finished behind them: its LDS round trip overlaps their issue — as one  */ \
+        /* serial read-modify-write in front of them it stretched the LOAD part past the other group's MFMA part (2.03 -> 2.26 ms */ \
+        /* on the 64 -> 128+128 launch of the headline) */                                                     \
+        constexpr int due0_ = G::first_due(S);                                                                 \
+        const bool due_on_ = MSK && due0_ >= 0 && (due0_ >= PRO ? true : (G::pstep(due0_ < 0 ? 0 : due0_) + 3 == (S) ? !last : chunk > 0)); \
+        unsigned mw0_ = 0;                                                                                     \
+        u32x4_m mv0_ = {0u, 0u, 0u, 0u};                                                                       \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+            if constexpr (MSK && due0_ >= 0) { if (kk == S2_MASK_PHASE && due_on_) { MASK_LOAD(due0_ < 0 ? 0 : due0_, mw0_, mv0_); } } \
             if (kk == 0) {                                                                                     \
                 _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
                 bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, 4 * kk + j) * 64);                            \
+            if constexpr (MSK && due0_ >= 0) {                                                                 \
+                if (kk == S2_MASK_PHASE) {                                                                     \
+                    if (due_on_) { MASK_STORE(due0_ < 0 ? 0 : due0_, mw0_, mv0_); }                            \
+                    _Pragma("unroll") for (int k = 0; k < NPT; ++k)                                            \
+                        if (k != due0_ && MASK_DUE(S, k)) { if (due_on_) { MASK_P(k); } }                      \
+                    /* (phase 1: the masked piece may be read in the next interval — the write has to be complete at the barrier) */ \
+                    if (S2_MASK_PHASE == 1 && due_on_) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+                }                                                                                              \
+            }                                                                                                  \
             if (kk == 0 || S2_WSPLIT) {                                                                        \
                 /* weights of step S + NST - 1: of this chunk, or of the first steps of the next one (S2_WSPLIT: the two */ \
                 /* DMA instructions of a wave in the two phases of the step) */                                \
@@ -419,6 +510,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         // the count is not known) and the dynamic-exit form drain everything.
         if (IMAP || !stores16 || S2_DRAIN_STORES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (MSK) {                               // the A / B pieces of chunk 0 (issued by SETUP_TILE)
+#pragma unroll
+            for (int k = 0; k < PRO; ++k) MASK_P(k);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         RAW_BARRIER();
         if (g == 1) RAW_BARRIER();                         // stagger
         half8 af[TI], bf[4];
@@ -445,7 +541,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             if (sum_ == 12345.678f) a.out[tid] = (_Float16)sum_;
         } else {
             char* const E = smem + G::E_OFF + g * 32768;
-            const int tl = tid & 255;
+            int tl = tid & 255;
+            asm volatile("" : "+v"(tl));                    // (per tile: hoisted out of the tile loop, what derives from it is spilled)
             const int chl = cur_ch0 + 128 * g;              // launch-wide channel of this half's channel 0 (BN table index)
             _Float16* outp = a.out;
             int oc = a.Cout, chg = chl;
@@ -546,6 +643,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #undef WAIT_VM
 #undef RAW_BARRIER
 #undef SETUP_TILE
+#undef MASK_DUE
+#undef MASK_P
+#undef MASK_STORE
+#undef MASK_LOAD
 #undef ISSUE_P
 #undef ISSUE_W
 #undef ISSUE_W_HALF
@@ -567,7 +668,15 @@ static int launch_s2(const ConvArgs& a, int n_cu, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(512);
 #define S2_LAUNCH(BF_, IMAP_) hipLaunchKernelGGL((conv3x3_s2_kernel<TW, BF_, IMAP_>), grid, block, 0, s, a, (int)tiles)
-    if (a.imap) { if (a.bf16) S2_LAUNCH(true, true); else S2_LAUNCH(false, true); }
+    if (a.in_bits) {
+        if constexpr (TW == 16) {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_s2_kernel<16, true, false, true>), grid, block, 0, s, a, (int)tiles);
+            else hipLaunchKernelGGL((conv3x3_s2_kernel<16, false, false, true>), grid, block, 0, s, a, (int)tiles);
+        } else {
+            return BMI_ERR_UNSUPPORTED;
+        }
+    }
+    else if (a.imap) { if (a.bf16) S2_LAUNCH(true, true); else S2_LAUNCH(false, true); }
     else { if (a.bf16) S2_LAUNCH(true, false); else S2_LAUNCH(false, false); }
 #undef S2_LAUNCH
     BMI_CHECK_LAUNCH();
@@ -578,7 +687,9 @@ static int launch_s2(const ConvArgs& a, int n_cu, hipStream_t s) {
 // FULL-CHUNK image count (ConvArgs::n_ref), never at the samples of this launch, like conv3x3_pw's: a t-shard runs the same
 // kernel as the single-rank run and gets the same bits ("conv_s2" = 2 drops the rule: tests).
 int launch_conv3x3_s2(const ConvArgs& a_in, hipStream_t s) {
-    if (!opt_conv_s2() || a_in.in_bits || a_in.in2 || a_in.partial || !conv_epilogue_is_plain(a_in)) return BMI_ERR_UNSUPPORTED;
+    if (!opt_conv_s2() || a_in.in2 || a_in.partial || !conv_epilogue_is_plain(a_in)) return BMI_ERR_UNSUPPORTED;
+    // keep bits on the input (ConvArgs::in_bits): the 32x32 -> 16x16 class (one image per tile), a deterministic, pre-scaled input
+    if (a_in.in_bits && (a_in.Ho != 16 || a_in.imap || a_in.out_mul != 1.f || a_in.Cin % 32 != 0)) return BMI_ERR_UNSUPPORTED;
     if (!conv_takes_s2_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout, a_in.H, a_in.W, a_in.Ho, a_in.Wo)) return BMI_ERR_UNSUPPORTED;
     ConvArgs a = a_in;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
@@ -586,7 +697,7 @@ int launch_conv3x3_s2(const ConvArgs& a_in, hipStream_t s) {
     if ((a.pool || a.pool_b) && a.Ho != 4) return BMI_ERR_UNSUPPORTED;      // the pooled epilogue sums the 16 lanes of a DPP row = a 4x4 map
     // 32-bit byte offsets inside a buffer descriptor: a tile's own images (always), the whole tensor for the dynamic-exit form
     if (a.imap && (size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;
-    if (a.in_mod < a.N && !a.imap) return BMI_ERR_UNSUPPORTED;      // (a plain conv on a deterministic input runs once per batch: N == in_mod)
+    if (a.in_mod < a.N && !a.imap && a.Ho != 16) return BMI_ERR_UNSUPPORTED;      // (tiles of several images take consecutive tensor rows)
     if ((size_t)a.H * a.W * a.Cin >= (1u << 24)) return BMI_ERR_UNSUPPORTED;
     static const int n_cu = [] {
         int dev = 0, cu = 0;

@@ -342,7 +342,9 @@ __host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_sh
 //      back IN PLACE;
 //   4. barrier, then the plain epilogue's store phase.
 // Same arithmetic in the same order as epilogue_coalesced (fp32 throughout, one rounding), so the bits agree.
-template <int TJ, bool BF, class ACC, class PixMap, class OffMap>
+// RES_IN_LDS: the caller has issued the residual DMA of step 2 itself (same pieces, same layout, into `lds`) before or
+// during its main loop — conv1x1_stream, whose tile has nothing else to overlap the residual's HBM round trip with.
+template <int TJ, bool BF, bool RES_IN_LDS = false, class ACC, class PixMap, class OffMap>
 __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
                                               PixMap pixmap, OffMap offmap) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -364,7 +366,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
             for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * sc[e] + bi[e];
     }
     lds_barrier();   // the main loop is done with the LDS
-    if (a.res) {
+    if (a.res && !RES_IN_LDS) {
 #pragma unroll
         for (int i = 0; i < 4 * TJ; ++i) {
             const int q = i * 256 + tid, p = q >> 4, pos = q & 15;

@@ -28,6 +28,11 @@ struct TensorInfo {
     bool bits = false;          // holds keep bits (1 bit per element) instead of fp16 activations
     bool f32 = false;           // fp32 activations (output of a DENSE op)
     bool pooled_now = false;    // (run time) the producing conv of this chunk wrote fp32 means over its 4x4 map instead of the tensor
+    // Lazy site (the output of an elementwise MASK op on a deterministic tensor, see bmi_create): tensors that hold the keep bits of
+    // the folded batch and the deterministic input times 1/(1-p) (fp16), or -1
+    int lazy_bits = -1, lazy_scaled = -1;
+    bool lazy_pending = false;  // (run time) bits + scaled copy are written, the masked tensor itself is not (yet)
+    EltArgs lazy_call;          // (run time) the mask launch that materialises it on demand
     int first = -1, last = -1;  // suffix op indices (stochastic tensors only)
     size_t offset = 0;          // byte offset in the workspace
 };
@@ -167,6 +172,7 @@ int& opt_splitk() { static int v = 1; return v; }
 int& opt_conv_stream() { static int v = 1; return v; }
 int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_conv_pool() { static int v = 1; return v; }
+int& opt_mask_lazy() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
@@ -210,6 +216,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_pool") == 0) {
         if (value != 0 && value != 1) return BMI_ERR_INVALID;
         opt_conv_pool() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "mask_lazy") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_mask_lazy() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_wide") == 0) {
@@ -551,6 +562,35 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         if (d.kind != BMI_OP_HEAD) touch(d.out);
         if (e->suffix[k].has_pair) touch(e->suffix[k].pair_d.out);
     }
+    // Lazy sites.  The first elementwise site of a "block"-dropout ResNet expands the once-per-batch prefix (B images) to the folded
+    // batch: 3.3 GB written by the MASK op and read back by its consumers on the headline config.  Where a consumer can apply the
+    // mask itself — conv3x3_s2 on 32x32 maps (clears the dropped elements of its patch pieces in LDS), conv3x3_patch for the input of
+    // a fused shortcut on 16x16 maps — the op writes the keep bits (1/16 of the bytes) and ONE scaled copy of the B images
+    // instead; kept x 1/(1-p) rounded to fp16 and ANDed with the bits is what the MASK op itself stores, so the result is bit for
+    // bit the materialised one.  Decided per launch (run_op): a consumer whose kernel does not take the launch makes the
+    // MASK op's own launch happen first ("mask_lazy" = 0: always).
+    for (size_t mi = 0; mi < e->suffix.size(); ++mi) {
+        const bmi_op_desc md = e->suffix[mi].d;
+        if (md.kind != BMI_OP_MASK || md.site.kind != BMI_SITE_ELEMENTWISE || md.site_pos == BMI_SITE_POS_INNER || md.site.p >= 1.f) continue;
+        const TensorInfo ti = e->tensors[md.in];
+        if (ti.stoch || ti.c % 32 != 0 || ti.h != 32 || ti.w != 32) continue;
+        bool any = false;
+        for (const OpInfo& c : e->suffix) {
+            if (c.d.kind != BMI_OP_CONV) continue;
+            if (c.d.in == md.out && c.bits_tensor < 0 && c.d.residual < 0 && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE &&
+                conv_takes_s2_kernel(c.d.ksize, c.d.stride, c.d.pad, ti.c, c.cout + (c.has_pair ? c.pair_cout : 0), ti.h, ti.w, c.ho, c.wo))
+                any = true;
+            if (c.d.in2 == md.out && c.ho == 16 && c.wo == 16) any = true;
+        }
+        if (!any) continue;
+        TensorInfo tb = ti, tsc = ti;
+        tb.stoch = true; tb.bits = true; tb.first = e->tensors[md.out].first; tb.last = e->tensors[md.out].last;
+        tsc.stoch = false; tsc.first = tsc.last = -1;
+        e->tensors.push_back(tb);
+        e->tensors.push_back(tsc);
+        e->tensors[md.out].lazy_bits = (int)e->tensors.size() - 2;
+        e->tensors[md.out].lazy_scaled = (int)e->tensors.size() - 1;
+    }
     *out = e;
     return BMI_OK;
 }
@@ -681,6 +721,18 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     };
     const int n_rows = imap ? (N / Bc) * B : N;     // rows of a stochastic tensor (original folded layout)
     if (imap && d.kind != BMI_OP_CONV && d.kind != BMI_OP_HEAD) return BMI_ERR_UNSUPPORTED;
+    // a lazy site's tensor (see bmi_create) is written now if this op cannot apply the mask itself
+    auto pending = [&](int id) { return id >= 0 && e->tensors[id].lazy_pending; };
+    auto materialise = [&](int id) -> int {
+        if (!pending(id)) return BMI_OK;
+        e->tensors[id].lazy_pending = false;
+        return launch_mask_apply(e->tensors[id].lazy_call, s);
+    };
+    if (d.kind != BMI_OP_CONV || pending(d.residual) || (pending(d.in) && pending(d.in2))) {
+        int rcm = materialise(d.in);
+        if (rcm == BMI_OK && d.kind == BMI_OP_CONV) { rcm = materialise(d.residual); if (rcm == BMI_OK) rcm = materialise(d.in2); }
+        if (rcm != BMI_OK) return rcm;
+    }
     ProfScope prof(e, d.kind == OP_MASKBITS ? BMI_OP_MASK : d.kind, s);
     prof.r.out = d.out; prof.r.images = N;
     switch (d.kind) {
@@ -719,6 +771,11 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 a.H2 = t2.h; a.W2 = t2.w; a.Cin2 = t2.c; a.stride2 = t2.h / op.ho;
             }
             if (op.bits_tensor >= 0) a.in_bits = (const uint8_t*)(ws + e->tensors[op.bits_tensor].offset);
+            auto lazy_in = [&](ConvArgs& m) {   // the input as (scaled deterministic tensor, keep bits)
+                m.in = (const _Float16*)(ws + e->tensors[tin.lazy_scaled].offset);
+                m.in_mod = B;
+                m.in_bits = (const uint8_t*)(ws + e->tensors[tin.lazy_bits].offset);
+            };
             double flops = 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
             if (d.in2 >= 0) flops += 2.0 * N * op.ho * op.wo * (double)op.cout * e->tensors[d.in2].c;
             // algorithmic bytes: every operand tensor once (a deterministic operand counts its B images), weights once
@@ -735,6 +792,15 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 p.split = op.cout;
                 p.Cout = op.cout + op.pair_cout;
                 e->tensors[d.out].pooled_now = e->tensors[op.pair_d.out].pooled_now = false;
+                if (pending(d.in)) {         // lazy site on the input: conv3x3_s2 clears the dropped elements in LDS, or the tensor is written now
+                    ConvArgs m = p;
+                    lazy_in(m);
+                    const int rcl = launch_conv3x3_s2(m, s);
+                    prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
+                    if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
+                    const int rcm = materialise(d.in);
+                    if (rcm != BMI_OK) return rcm;
+                }
                 if (opt_conv_pool() && (op.pool_ok || op.pair_pool_ok)) {
                     ConvArgs q = p;          // the pooled means take the place of the map in the workspace (16 x 4 B <= 16 x 16 x 2 B per channel)
                     if (op.pool_ok) q.pool = (float*)q.out;
@@ -759,6 +825,30 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 const int rc2 = launch_conv(a, s, &fam);
                 prof.tag(fam, flops, bytes);
                 return rc2 != BMI_OK ? rc2 : launch_conv(q, s);
+            }
+            if (pending(d.in)) {
+                ConvArgs m = a;
+                lazy_in(m);
+                const int rcl = launch_conv3x3_s2(m, s);
+                prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
+                if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
+                const int rcm = materialise(d.in);
+                if (rcm != BMI_OK) return rcm;
+            }
+            if (pending(d.in2)) {            // ... on the input of a fused shortcut: conv3x3_patch on 16x16 maps
+                int rcl = BMI_ERR_UNSUPPORTED;
+                if (op.ho == 16 && op.wo == 16) {
+                    const TensorInfo& t2 = e->tensors[d.in2];
+                    ConvArgs m = a;
+                    m.in2 = (const _Float16*)(ws + e->tensors[t2.lazy_scaled].offset);
+                    m.in2_mod = B;
+                    m.in2_bits = (const uint8_t*)(ws + e->tensors[t2.lazy_bits].offset);
+                    rcl = launch_conv3x3_patch(m, s);
+                    prof.tag(BMI_CONV_FAMILY_PATCH, flops, bytes);
+                }
+                if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
+                const int rcm = materialise(d.in2);
+                if (rcm != BMI_OK) return rcm;
             }
             if (op.nsplit > 1 && !op.stoch && !rows) {
                 a.partial = (float*)(ws + e->splitk_off);
@@ -794,6 +884,20 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
             a.site = resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)tin.h * tin.w * tin.c, (size_t)tin.c));
             if (d.site_pos == BMI_SITE_POS_INNER) { a.bias_post = d.bias_post; a.relu = d.relu; }
+            TensorInfo& to = e->tensors[d.out];
+            to.lazy_pending = false;
+            if (to.lazy_bits >= 0 && opt_mask_lazy() && !tin.stoch && N % B == 0) {
+                const int rcb = launch_mask_bits((uint8_t*)(ws + e->tensors[to.lazy_bits].offset), N, tin.h * tin.w, tin.c, a.site, B, t0, s);
+                if (rcb == BMI_OK) {
+                    const int rcs = launch_scale_copy(a.in, (_Float16*)(ws + e->tensors[to.lazy_scaled].offset), (long)B * tin.h * tin.w * tin.c,
+                                                      a.site.scale, e->bf16, s);
+                    if (rcs != BMI_OK) return rcs;
+                    to.lazy_call = a;
+                    to.lazy_pending = true;
+                    return BMI_OK;
+                }
+                if (rcb != BMI_ERR_UNSUPPORTED) return rcb;
+            }
             return launch_mask_apply(a, s);
         }
         case BMI_OP_MAXPOOL:

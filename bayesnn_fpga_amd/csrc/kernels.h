@@ -13,8 +13,9 @@ struct ConvArgs {
     const float* bias;    // may be null
     const _Float16* res;  // may be null
     const uint8_t* in_bits;  // keep bits of an elementwise MC-dropout site on the INPUT (1 bit per element,
-                             // byte g = elements 8g..8g+7 of the folded tensor), or null; conv_igemm only
-    float out_mul;           // multiplies the folded-BN scale (the site's 1/(1-p) when in_bits is used), else 1
+                             // byte g = elements 8g..8g+7 of the folded tensor), or null; conv_igemm (zeroes while staging,
+                             // 1/(1-p) in out_mul) and conv3x3_s2 on 32x32 maps (clears the elements in LDS; `in` pre-scaled)
+    float out_mul;           // multiplies the folded-BN scale (the site's 1/(1-p) when conv_igemm reads in_bits), else 1
     // fused 1x1 strided shortcut (conv3x3_patch only): out += conv1x1(in2; wgt2), both BN scales folded
     // into the fp16 weights by the host, the biases summed (BasicBlock.forward :42-45 downsample path)
     const _Float16* in2;     // [N or in2_mod][H2][W2][Cin2], or null
@@ -61,6 +62,10 @@ struct ConvArgs {
     int nsplit;
     int xcd_split; // channel-tile classes of the XCD-aware tile order (xcd_tile_map's cs); set by the launcher
     SiteArgs site;
+    const uint8_t* in2_bits; // keep bits (as in_bits) for in2: conv3x3_patch on 16x16 maps clears the dropped elements of the shortcut's
+                             // pixels in LDS; in2 is then the deterministic tensor, pre-scaled by 1/(1-p) in fp16.  Or null.
+                             // (Last: the kernels that never read it keep their argument layout — a field in the middle moved
+                             // conv3x3_pw's 4x4 bf16 instantiations from 0 to 212 bytes of scratch.)
 };
 
 struct EltArgs {  // MASK op
@@ -119,6 +124,7 @@ int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, 
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
 int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s);
+int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, int bf16, hipStream_t s);   // out = round16(in * scale)
 int launch_splitk_finish(const ConvArgs& a, hipStream_t s);   // after a split-K conv_igemm launch
 int launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);
@@ -130,6 +136,7 @@ int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
 int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
 int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
 int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
+int& opt_mask_lazy();          // 1: a lazy site (engine.hip, bmi_create) writes keep bits + one scaled copy and its consumers mask in LDS, 0: always materialised
 int& opt_conv_pool();          // 1: a conv whose 4x4 map feeds one exit head only writes the pooled means (conv3x3_s2), 0: never
 int& opt_conv_s2();            // 1: plain 3x3 stride-2 convs run in conv3x3_s2 (2 = without its minimum-grid rule: tests), 0: conv_igemm_wide
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never

@@ -162,6 +162,10 @@ const char* bmi_error_string(int code);
  *                                           patch resident in LDS as four parity planes, persistent) instead of conv_igemm_wide
  *   "conv_pool"                             0 | 1: a plain 3x3 stride-2 conv whose 4x4 output map feeds one exit head and nothing else writes
  *                                           fp32 means over the map (ReLU + avg_pool2d(4) fused into conv3x3_s2's epilogue) instead of the map
+ *   "mask_lazy"                             0 | 1: the elementwise site that expands the once-per-batch prefix (32x32 maps) to the folded batch writes
+ *                                           keep bits + one scaled copy of the B images; conv3x3_s2 / conv3x3_patch (fused shortcut input) clear the
+ *                                           dropped elements in LDS, any other consumer makes the masked tensor appear first (1, default), or the
+ *                                           masked tensor is always written (0); the same bits either way
  *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
  *   "splitk"                                0 | 1, read by bmi_plan: 3x3 convs of the once-per-batch prefix whose grid is <= 64 tiles (VGG's convs on
  *                                           2x2 maps) run split-K: one workgroup per (tile, tap), fp32 partial sums, a finishing pass

@@ -24,9 +24,9 @@ def test_conv_kernels_have_no_scratch_and_no_spills(src):
     assert r.returncode == 0, r.stderr[-2000:]
     kernels = re.findall(r"Function Name: (\S+).*?VGPRs Spill: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
     assert kernels, "no kernel-resource-usage remarks in the hipcc output"
-    # conv3x3_s2's dynamic-exit instantiations (IMAP = true, the last template argument) keep a few tile-setup values in scratch
+    # conv3x3_s2's dynamic-exit instantiations (IMAP = true, the last template argument but one) keep a few tile-setup values in scratch
     # OUTSIDE the main loop (stored before it, reloaded behind it: checked in the ISA when the kernel was written — between the first
     # and the last v_mfma there is no scratch instruction): tolerated up to 256 bytes per lane, nothing else is
-    allowed = lambda n: 256 if (n.startswith("_Z17conv3x3_s2_kernel") and n.endswith("Lb1EEv8ConvArgsi")) else 0
+    allowed = lambda n: 256 if (n.startswith("_Z17conv3x3_s2_kernel") and n.endswith("Lb1ELb0EEv8ConvArgsi")) else 0
     bad = [(n, sp, sc) for n, sp, sc in kernels if int(sc) > allowed(n) or (int(sp) and not allowed(n))]
     assert not bad, f"kernels with VGPR spills / scratch: {bad}"

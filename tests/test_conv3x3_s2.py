@@ -124,3 +124,34 @@ def test_s2_leaves_what_it_does_not_take_to_the_wide_kernel(s2_always):
     out = gh.run_conv(x6, w6, scale6, bias6, res, True, 2, 1, n, n, n)
     ref = gh.conv_ref(x6, w6, scale6, bias6, res, True, 2, 1, n, n, n)
     torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("cin,cout,B,tc", [(64, 256, 3, 5), (64, 256, 7, 41), (128, 512, 2, 3), (64, 256, 25, 40)])
+def test_s2_keep_bits_on_the_input_equal_the_materialised_mask(s2_always, cin, cout, B, tc):
+    """ConvArgs::in_bits on the 32x32 -> 16x16 class: the patch pieces come from the B deterministic images (pre-scaled by 1/(1-p)
+    in fp16), their keep bits ride along as a second DMA and the issuing thread clears the dropped elements in LDS — bit for bit
+    the conv on the tensor bmi_mask_apply materialises (one image per tile up to several tiles per workgroup: 7 x 41 and
+    25 x 40 images on 256 CUs)."""
+    import ctypes as C
+    from oracle import philox
+    lib = _lib.lib()
+    H, N, t0, seed, p = 32, B * tc, 3, (7 << 32) + 5, 0.25
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, 3, B, 300 + B, False)
+    x = torch.relu(x)                                                  # (post-ReLU like the tensor the site sits on)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=1, p=p)
+    keep = []
+    s = gh.site_struct(site, keep)
+    bits = torch.zeros(N * H * H * cin // 8, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.bmi_mask_bits(gh.ptr(bits), N, H * H, cin, C.byref(s), B, t0, seed, gh.stream()), "bmi_mask_bits")
+    masked = torch.empty(N, H, H, cin, dtype=torch.float16, device=DEV)
+    _lib.check(lib.bmi_mask_apply(gh.ptr(x), gh.ptr(masked), N, B, H * H, cin, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_mask_apply")
+    torch.cuda.synchronize()
+    xs = (x.float() * float(philox.drop_scale(p))).to(torch.float16)
+    got = gh.run_conv(xs, w, scale, bias, None, True, 2, 1, N, B, 1, batch=B, in_bits=bits)
+    want = gh.run_conv(masked, w, scale, bias, None, True, 2, 1, N, N, 1, batch=B)
+    assert torch.isfinite(got.float()).all() and float(got.float().abs().max()) > 0
+    assert torch.equal(got, want)
+    for _ in range(3):                                                 # (the in-LDS masking sits in the counted-wait schedule: repeats agree)
+        assert torch.equal(gh.run_conv(xs, w, scale, bias, None, True, 2, 1, N, B, 1, batch=B, in_bits=bits), got)
+    ref = gh.conv_ref(masked, w, scale, bias, None, True, 2, 1, N, N, 1)
+    torch.testing.assert_close(got.float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=2e-3)

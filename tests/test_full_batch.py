@@ -86,3 +86,44 @@ def test_fused_relu_avgpool_equals_the_separate_head_pooling():
     assert torch.equal(fused["mean"][3], plain["mean"][3])                  # the final exit's layer4 output is not a stride-2 conv's
     again = eng.predict(x, T, seed=seed)
     assert torch.equal(again["mean"], fused["mean"])
+
+
+@pytest.mark.parametrize("dropout", ["block", "layer"])
+def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
+    """The first elementwise site of a "block" / "layer" ResNet expands the B prefix images to the folded batch.  With "mask_lazy"
+    (default) the MASK op writes keep bits + one scaled copy of the B images, conv3x3_s2 clears the dropped elements of its patch
+    pieces in LDS and conv3x3_patch those of the fused shortcut's pixels; with the option off the op stores the masked tensor.
+    Same bits either way (a kept element is x / (1 - p) rounded to fp16 in both), for the full run and for a t-shard; and the MASK
+    launch is the short one (the lazy path ran)."""
+    from bayesnn_fpga_amd import _lib
+    T, seed = 16, 11
+    model = build_seeded(ResNet18MCEarlyExit, dict(dropout_exit=True, dropout=dropout, dropout_p=0.25, out_dim=10))
+    synthetic_weights_(model, 0)
+    eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    x = synthetic_images(B, seed=1234).to(DEV)
+
+    def timed():
+        eng.predict(x, T, seed=seed)                       # warm
+        eng.profile(True)
+        r = eng.predict(x, T, seed=seed)
+        torch.cuda.synchronize()
+        eng.profile_read()
+        eng.profile(False)
+        first_mask = next(l for l in eng.profile_launches() if l["kind"] == "mask")
+        return r, first_mask["ms"]
+
+    lazy, ms_lazy = timed()
+    shard = eng.predict(x, 5, seed=seed, t_begin=3)
+    _lib.set_option("mask_lazy", 0)
+    try:
+        plain, ms_plain = timed()
+        shard_plain = eng.predict(x, 5, seed=seed, t_begin=3)
+    finally:
+        _lib.set_option("mask_lazy", 1)
+    for k in ("mean", "var", "logit_mean"):
+        assert torch.equal(lazy[k], plain[k]), k
+        assert torch.equal(shard[k], shard_plain[k]), k
+    assert float(lazy["var"].max()) > 0          # the site is live
+    print(f"first MASK launch: lazy {ms_lazy * 1e3:.0f} us, materialised {ms_plain * 1e3:.0f} us")
+    if dropout == "block":                               # ("layer": the first site sits behind layer1's first conv, on 64 -> 64 stride-1
+        assert ms_lazy < 0.7 * ms_plain                  #  consumers: nothing takes keep bits there and the op runs as before)

@@ -40,6 +40,7 @@ def main():
                                              "mfma_shape_patch=32+mfma_shape_wide=32,mfma_shape_patch=16+mfma_shape_wide=16")
     ap.add_argument("--site", action="store_true", help="fuse an elementwise MC-dropout site into the epilogue")
     ap.add_argument("--nores", action="store_true")
+    ap.add_argument("--in-mod", type=int, default=0, help="the input tensor holds this many images (a deterministic tensor under sample folding)")
     ap.add_argument("--noscale", action="store_true")
     ap.add_argument("--zero-input", action="store_true", help="all-zero activations: the same instruction stream at the lowest operand-toggling power")
     ap.add_argument("--sparse-input", action="store_true", help="post-ReLU, 25 %% dropped activations (as inside the network) instead of N(0,1)")
@@ -70,7 +71,7 @@ def main():
         def run():
             rc = lib.bmi_conv_igemm_fwd(x.data_ptr(), None, 1.0, w.data_ptr(), None if a.noscale else scale.data_ptr(),
                                         None if a.noscale else bias.data_ptr(), None if a.nores else res.data_ptr(),
-                                        out.data_ptr(), n, n, n, H, H, cin, cout, k, s, p, 1,
+                                        out.data_ptr(), n, a.in_mod or n, n, H, H, cin, cout, k, s, p, 1,
                                         C.byref(site) if site is not None else None, 250, 0, 42, 0, st)
             _lib.check(rc, "bmi_conv_igemm_fwd")
         flops = 2.0 * n * ho * ho * cout * k * k * cin
