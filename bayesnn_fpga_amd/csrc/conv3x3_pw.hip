@@ -117,6 +117,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
             GLDS16(wsrc[i] + (KOFF), wst + (ST) * G::WST + (i * 512 + wave * 64) * 16);          \
     }
 #define ISSUE_W_HALF(KOFF, ST, I) GLDS16(wsrc[I] + (KOFF), wst + (ST) * G::WST + ((I) * 512 + wave * 64) * 16)
+#ifndef PW_ABL_HALFREADS
+#define PW_ABL_HALFREADS 0   // timing probe (wrong results): every second pixel-fragment read is skipped (8 instead of 12 reads per 32 MFMAs)
+#endif
 #ifndef PW_WSPLIT
 #define PW_WSPLIT 0          // 1: a wave's two weight DMA instructions of a K-step go out in the two phases (one each)
 #endif
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
                 _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
-                bf[j] = *(const half8*)(pb_ + boff[ky_] + G::cell_delta(4 * kk + j) * 64);                     \
+                if (!PW_ABL_HALFREADS || !(j & 1)) bf[j] = *(const half8*)(pb_ + boff[ky_] + G::cell_delta(4 * kk + j) * 64); \
+                else bf[j] = bf[j - 1];                                                                        \
             if (kk == 0 && !PW_WSPLIT) {                                                                       \
                 /* weights of the step after next: (tap + 2) of this chunk, or taps 0 / 1 of the next one */   \
                 if ((TAP) < 7) { ISSUE_W(((TAP) + 2) * a.Cin + c32, ((TAP) + 2) % 3); }                        \

@@ -77,6 +77,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef S2_ABL_NOSTORE
 #define S2_ABL_NOSTORE 0     // the epilogue runs but stores nothing
 #endif
+#ifndef S2_ABL_HALFREADS
+#define S2_ABL_HALFREADS 0   // every second pixel-fragment read is skipped (8 instead of 12 reads per 32 MFMAs)
+#endif
 #ifndef S2_ABL_NOBITS
 #define S2_ABL_NOBITS 0      // masked-input form: no keep-bit DMA (the masking reads whatever the slots hold)
 #endif
@@ -451,7 +454,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                 _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
-                bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, 4 * kk + j) * 64);                            \
+                if (!S2_ABL_HALFREADS || !(j & 1)) bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, 4 * kk + j) * 64); \
+                else bf[j] = bf[j - 1];                                                                        \
             if constexpr (MSK && due0_ >= 0) {                                                                 \
                 if (kk == S2_MASK_PHASE) {                                                                     \
                     if (due_on_) { MASK_STORE(due0_ < 0 ? 0 : due0_, mw0_, mv0_); }                            \
@@ -479,13 +483,39 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                         else if (!last) { ISSUE_P(k, c32 + 32); }                                              \
                     }                                                                                          \
             }                                                                                                  \
+            /* (S2_MASK_PHASE 2: the masking of phase 0's MFMA part wrote LDS behind nothing but this phase's four fragment */ \
+            /*  reads — LDS operations of a wave complete in order: with at most four outstanding the write is done) */ \
+            if (MSK && S2_MASK_PHASE == 2 && kk == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");       \
             if (kk == 1 && g == 1) END_OF_STEP_WAIT(S);        /* interval 4T+3, group 1: LOAD part */         \
             RAW_BARRIER();                                                                                     \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
             __builtin_amdgcn_s_setprio(1);                                                                     \
-            _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                     \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-                    acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);                  \
+            if constexpr (MSK && S2_MASK_PHASE == 2 && due0_ >= 0) {                                           \
+                if (kk == 0) {                                                                                 \
+                    /* the piece's read-modify-write BETWEEN the MFMAs: its LDS round trip and its 20 vector instructions */ \
+                    /* ride in the matrix pipe's shadow instead of stretching a LOAD part */                    \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[0][j] = mfma_16x16x32<BF>(af[0], bf[j], acc[0][j]); \
+                    __builtin_amdgcn_sched_barrier(0);                                                         \
+                    if (due_on_) { MASK_LOAD(due0_ < 0 ? 0 : due0_, mw0_, mv0_); }                             \
+                    __builtin_amdgcn_sched_barrier(0);                                                         \
+                    _Pragma("unroll") for (int i = 1; i < 3; ++i)                                              \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]); \
+                    __builtin_amdgcn_sched_barrier(0);                                                         \
+                    if (due_on_) { MASK_STORE(due0_ < 0 ? 0 : due0_, mw0_, mv0_); }                            \
+                    _Pragma("unroll") for (int k = 0; k < NPT; ++k)                                            \
+                        if (k != due0_ && MASK_DUE(S, k)) { if (due_on_) { MASK_P(k); } }                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                         \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[3][j] = mfma_16x16x32<BF>(af[3], bf[j], acc[3][j]); \
+                } else {                                                                                       \
+                    _Pragma("unroll") for (int i = 0; i < TI; ++i)                                             \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+                            acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);          \
+                }                                                                                              \
+            } else {                                                                                           \
+                _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+                        acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);              \
+            }                                                                                                  \
             __builtin_amdgcn_s_setprio(0);                                                                     \
             if (kk == 1 && g == 0) END_OF_STEP_WAIT(S);        /* interval 4T+3, group 0: MFMA part */         \
             RAW_BARRIER();                                                                                     \
