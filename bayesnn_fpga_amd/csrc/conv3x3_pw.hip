@@ -314,6 +314,239 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
     epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv3x3_pw4: the same tile, LDS layout, DMA sources, K order and epilogue code with FOUR waves — one per SIMD, wave tile 128 ch x
+// 128 px (8 x 8 tiles of v_mfma_f32_16x16x32: 256 accumulator registers, the unified 512-entry file of a one-wave-per-SIMD
+// workgroup) — and NO hand-over of the matrix pipe between wave groups: a wave reads the fragments of K-step s + 1 into a second
+// register set while its 64 MFMAs of step s run (software pipelining inside one instruction stream), 16 ds_read_b128 per 64 MFMAs
+// instead of 12 per 32, ONE barrier per K-step instead of four.  Wave (wc, wp) owns the channels of conv3x3_pw's waves (0, wc, wp)
+// and (1, wc, wp): rows wc*64 + 16 i of both 128-channel halves, so each half is finished by conv_epilogue.h exactly as there.
+//   step s:  wait (own DMA of step s + 1 landed) -> barrier (everyone's landed; everyone's fragment reads of step s are done, so
+//            stage s % 3 is free) -> DMA of step s + 3 into stage s % 3 (+ two pieces of the next sub-patch) -> 16 fragment reads
+//            of step s + 1 from stage (s + 1) % 3 into the other set, interleaved with the 64 MFMAs of step s.
+// Two chunks (18 K-steps) per loop iteration: the register set alternates per step and 9 is odd (Cin % 64 == 0).
+template <int TW, int EPI, bool BF, bool IMAP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_pw4_kernel(ConvArgs a) {
+    using G = PwGeom<TW>;
+    constexpr int CT = G::CT, TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
+    constexpr int TP = 8, NPC = 2 * G::ITER_P;                       // pixel tiles per wave; patch pieces per thread and sub-patch
+    typedef float accv __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
+    char* const wst = smem;
+    char* const pbuf = smem + G::NST * G::WST;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int wc = wave >> 1, wp = wave & 1;
+
+    const int n_ctiles = a.Cout / CT;
+    const int n_ptiles = (a.N + IMGS - 1) / IMGS;
+    int ptile, ctile;
+    xcd_tile_map(blockIdx.x, n_ptiles, n_ctiles, ptile, ctile, a.xcd_split);
+    const int ch0 = ctile * CT;
+    const int n0 = ptile * IMGS;
+    const int Ktot = 9 * a.Cin;
+    const int nC = a.Cin / 32;
+
+    // weights: piece q = tid + 256 i -> row (tid >> 2) + 64 i, position tid & 3 holds chunk pos ^ 2 ((row >> 2) & 1) ((row >> 2) & 1 == (tid >> 4) & 1)
+    const _Float16* const wsrc0 = a.wgt + (size_t)(ch0 + (tid >> 2)) * Ktot + ((tid & 3) ^ (((tid >> 4) & 1) << 1)) * 8;
+    const size_t wrow64 = (size_t)64 * Ktot;
+#define ISSUE_W4(KOFF, ST)                                                                       \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            GLDS16(wsrc0 + i * wrow64 + (KOFF), wst + (ST) * G::WST + (i * 256 + wave * 64) * 16); \
+    }
+    ISSUE_W4(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    int psrc[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int q = tid + 256 * i;
+        const int cell = q >> 2, pos = q & 3;
+        const int rowc = cell / PWP, x = cell - rowc * PWP;
+        const int img = rowc / PH, y = rowc - img * PH;
+        const int n = n0 + img;
+        const int iy = y - 1, ix = x - 1;
+        const bool ok = cell < G::CELLS && x < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        psrc[i] = ok ? (int)((((size_t)(map_image<IMAP>(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + (pos ^ ((y & 1) << 1)) * 8) : -1;
+    }
+#define ISSUE_P4(I, C0, PB)                                                                                  \
+    GLDS16(psrc[I] >= 0 ? a.in + (size_t)(unsigned)psrc[I] + (C0) : (const _Float16*)g_zero_page_pw,       \
+           pbuf + (PB) * G::PBUF + ((I) * 256 + wave * 64) * 16)
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) ISSUE_P4(i, 0, 0);
+    ISSUE_W4(a.Cin, 1);                                        // K-step 1 = tap 1 of chunk 0
+    ISSUE_W4(2 * a.Cin, 2);                                    // K-step 2
+    __builtin_amdgcn_sched_barrier(0);
+
+    // fragment geometry: A rows h*128 + wc*64 + 16 i + l16 (I = 4 h + i), B as conv3x3_pw
+    const int a_off = (wc * 64 + l16) * 64 + ((kq ^ (((l16 >> 2) & 1) << 1)) << 4);
+    const int pbase = wp * 128;
+    const int wave_cell = (G::p_img(pbase) * PH + G::p_oy(pbase)) * PWP + G::p_ox(pbase);
+    int boff[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+        boff[ky] = (wave_cell + (l16 >> 2) * PWP + (l16 & 3)) * 64 + ((kq ^ ((((l16 >> 2) + ky) & 1) << 1)) << 4);
+
+    accv acc[8][TP];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define BARRIER4()                                     \
+    {                                                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+    }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    // The accumulators live in AGPRs and every MFMA updates its tile IN PLACE (inline asm, "+a"): with the builtin hipcc gave the
+    // 256 accumulator registers different source and destination tuples and copied them through VGPRs around every MFMA.
+#define MFMA4(ACC, A, B)                                                                                       \
+    {                                                                                                          \
+        if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B)); \
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B));              \
+    }
+    // fragment reads of K-step (tap TAP, sub-patch at LDS offset PBO): channel rows h*128 + wc*64 + 16 i (AF = half h), pixel tiles
+    // 0..7.  Inline asm with hand-counted lgkmcnt waits: in front of an asm MFMA hipcc waits for EVERY LDS read in flight, including
+    // the four of the other channel half issued a moment ago (a full LDS round trip per K-step in the first build).
+#define DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define READ_A(TAP, H, AF)                                                                                     \
+    {                                                                                                          \
+        DSR(AF[0], a_lds, ((TAP) % 3) * G::WST + (H) * 8192 + 0 * 1024);                                       \
+        DSR(AF[1], a_lds, ((TAP) % 3) * G::WST + (H) * 8192 + 1 * 1024);                                       \
+        DSR(AF[2], a_lds, ((TAP) % 3) * G::WST + (H) * 8192 + 2 * 1024);                                       \
+        DSR(AF[3], a_lds, ((TAP) % 3) * G::WST + (H) * 8192 + 3 * 1024);                                       \
+    }
+#define READ_B(TAP, PBO, BFR)                                                                                  \
+    {                                                                                                          \
+        constexpr int ky_ = (TAP) / 3, kx_ = (TAP) - 3 * ky_;                                                  \
+        const unsigned pb_ = b_lds[ky_] + (PBO);                                                               \
+        DSR(BFR[0], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(0) * 64);                                      \
+        DSR(BFR[1], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(1) * 64);                                      \
+        DSR(BFR[2], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(2) * 64);                                      \
+        DSR(BFR[3], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(3) * 64);                                      \
+        DSR(BFR[4], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(4) * 64);                                      \
+        DSR(BFR[5], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(5) * 64);                                      \
+        DSR(BFR[6], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(6) * 64);                                      \
+        DSR(BFR[7], pb_, (ky_ * PWP + kx_) * 64 + G::cell_delta(7) * 64);                                      \
+    }
+    // What may be in flight when step TAP takes its barrier (before its own DMA is issued): the DMA instructions of the step before — 4
+    // weight pieces (unless that step had no step + 3 inside the tile) and 2 sub-patch pieces (taps 1 .. ITER_P of a chunk with a successor)
+#define TOP_WAIT(TAP)                                                                                          \
+    {                                                                                                          \
+        constexpr int tp_ = ((TAP) + 8) % 9;                       /* tap of the previous step */              \
+        constexpr int pp_ = (tp_ >= 1 && tp_ <= G::ITER_P) ? 2 : 0;                                            \
+        const bool plast_ = (TAP) == 0 ? false : last;             /* (tap 8 of the previous chunk: never a last one) */ \
+        if (!plast_) { WAIT_VM(4 + pp_); }                                                                     \
+        else if (tp_ <= 5) { WAIT_VM(4); }                                                                     \
+        else { WAIT_VM(0); }                                                                                   \
+    }
+    // One K-step.  Entering: af_lo / af_hi = this step's channel fragments (the af_hi reads may still be in flight), BX = its pixel
+    // fragments.  Leaving: af_lo / af_hi / BY hold the next step's.
+#define STEP4(TAP, BX, BY)                                                                                     \
+    {                                                                                                          \
+        constexpr int tn_ = (TAP) == 8 ? 0 : (TAP) + 1;                                                        \
+        const unsigned pn_ = (TAP) == 8 ? pbn : pb;                /* sub-patch of the next step (LDS offset) */ \
+        const bool more_ = (TAP) < 8 || !last;                     /* a next step exists */                    \
+        /* LDS reads return in order: pixel fragments (8), af_lo (4), af_hi (4) — all but af_hi have landed */ \
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) MFMA4(acc[i][j], af_lo[i], BX[j]);                   \
+        SB();                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         /* this wave has read stage TAP % 3 completely */ \
+        TOP_WAIT(TAP);                                             /* its DMA of the next step's stage has landed */ \
+        BARRIER4();                                                                                            \
+        if ((TAP) < 6) { ISSUE_W4(((TAP) + 3) * a.Cin + c32, (TAP) % 3); }                                     \
+        else if (!last) { ISSUE_W4(((TAP) - 6) * a.Cin + c32 + 32, (TAP) % 3); }                               \
+        if ((TAP) >= 1 && (TAP) <= G::ITER_P && !last) {                                                       \
+            ISSUE_P4(2 * ((TAP) - 1), c32 + 32, nb);                                                           \
+            ISSUE_P4(2 * ((TAP) - 1) + 1, c32 + 32, nb);                                                       \
+        }                                                                                                      \
+        if (more_) { READ_B(tn_, pn_, BY); }                                                                   \
+        SB();                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            _Pragma("unroll") for (int j = 2; j < TP; ++j) MFMA4(acc[i][j], af_lo[i], BX[j]);                  \
+        SB();                                                                                                  \
+        if (more_) { READ_A(tn_, 0, af_lo); }                                                                  \
+        SB();                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            _Pragma("unroll") for (int j = 0; j < TP; ++j) MFMA4(acc[4 + i][j], af_hi[i], BX[j]);              \
+        SB();                                                                                                  \
+        if (more_) { READ_A(tn_, 1, af_hi); }                                                                  \
+        SB();                                                                                                  \
+    }
+
+    WAIT_VM(0);
+    BARRIER4();                          // stages 0, 1, 2 and sub-patch 0 have landed
+    half8 af_lo[4], af_hi[4], bf0[TP], bf1[TP];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned a_lds = lds0 + a_off;
+    unsigned b_lds[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) b_lds[ky] = lds0 + G::NST * G::WST + boff[ky];
+    READ_B(0, 0u, bf0);
+    READ_A(0, 0, af_lo);
+    READ_A(0, 1, af_hi);
+    for (int chunk = 0; chunk < nC; chunk += 2) {
+        {
+            const bool last = false;     // (nC is even: an even chunk always has a successor)
+            const int c32 = chunk * 32;
+            const int nb = 1;
+            const unsigned pb = 0u, pbn = G::PBUF;
+            STEP4(0, bf0, bf1) STEP4(1, bf1, bf0) STEP4(2, bf0, bf1) STEP4(3, bf1, bf0) STEP4(4, bf0, bf1)
+            STEP4(5, bf1, bf0) STEP4(6, bf0, bf1) STEP4(7, bf1, bf0) STEP4(8, bf0, bf1)
+        }
+        {
+            const bool last = chunk + 2 == nC;
+            const int c32 = (chunk + 1) * 32;
+            const int nb = 0;
+            const unsigned pb = G::PBUF, pbn = 0u;
+            STEP4(0, bf1, bf0) STEP4(1, bf0, bf1) STEP4(2, bf1, bf0) STEP4(3, bf0, bf1) STEP4(4, bf1, bf0)
+            STEP4(5, bf0, bf1) STEP4(6, bf1, bf0) STEP4(7, bf0, bf1) STEP4(8, bf1, bf0)
+        }
+    }
+#undef STEP4
+#undef TOP_WAIT
+#undef READ_A
+#undef READ_B
+#undef DSR
+#undef MFMA4
+#undef SB
+#undef ISSUE_P4
+#undef ISSUE_W4
+#undef WAIT_VM
+    // (the asm MFMAs are opaque to hipcc's hazard recogniser: their results are read — v_accvgpr_read — only behind these wait states)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BARRIER4();                          // every wave is done with the stages: the epilogue reuses the LDS
+#undef BARRIER4
+
+    // ---- epilogue: the two 128-channel halves one after the other, each exactly as a wave group of conv3x3_pw finishes it ----
+    auto pixmap = [&](int p, int& n, int& rem) -> bool {
+        n = n0 + G::p_img(p);
+        rem = G::p_oy(p) * TW + G::p_ox(p);
+        const bool ok = n < a.N;
+        n = map_image<IMAP>(a, n);
+        return ok;
+    };
+    auto offmap = [&](int p, size_t& off) -> bool {
+        int n, rem;
+        const bool ok = pixmap(p, n, rem);
+        off = ((size_t)n * (TH * TW) + rem) * a.Cout;
+        return ok;
+    };
+    typedef accv acc_half[4][TP];
+    epilogue_coalesced<4, EPI, 16, BF>(a, *(acc_half*)&acc[0], smem, tid, ch0, pixmap, offmap);
+    epilogue_coalesced<4, EPI, 16, BF>(a, *(acc_half*)&acc[4], smem, tid, ch0 + 128, pixmap, offmap);
+}
+
 // Shapes this kernel takes: 3x3 / stride 1 / pad 1 on 8x8 or 4x4 maps with Cout % 256 == 0.
 bool conv_takes_pw_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo) {
     return ksize == 3 && stride == 1 && pad == 1 && cin % 64 == 0 && cout % 256 == 0 && ho == wo && (ho == 8 || ho == 4);
@@ -327,6 +560,13 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)tiles), block(512);
     const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+    if (opt_conv_pw() >= 3 && !a.in2 && !a.imap && !a.bf16 && epi != BMI_EPI_GENERAL && a.Cin % 64 == 0) {   // the four-wave form ("conv_pw" = 3 | 4)
+        const dim3 block4(256);
+        if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv3x3_pw4_kernel<TW, BMI_EPI_PLAIN, false, false>), grid, block4, 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_pw4_kernel<TW, BMI_EPI_LITE, false, false>), grid, block4, 0, s, a);
+        BMI_CHECK_LAUNCH();
+        return BMI_OK;
+    }
 #define PW_LAUNCH_BF(BF_, IMAP_)                                                                                                    \
     {                                                                                                                               \
         if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_PLAIN, BF_, IMAP_>), grid, block, 0, s, a);     \
@@ -351,7 +591,7 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
 // ones: equal to fp32 rounding, not bit for bit).  "conv_pw" = 2 drops the rule (tests).
 int launch_conv3x3_pw(const ConvArgs& a, hipStream_t s) {
     if (!opt_conv_pw() || a.in_bits || a.wgt_b) return BMI_ERR_UNSUPPORTED;
-    if (opt_conv_pw() != 2) {
+    if (opt_conv_pw() != 2 && opt_conv_pw() != 4) {
         static const int n_cu = [] {
             int dev = 0, cu = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;

@@ -204,7 +204,7 @@ int bmi_set_option(const char* name, int32_t value) {
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_pw") == 0) {
-        if (value < 0 || value > 2) return BMI_ERR_INVALID;
+        if (value < 0 || value > 4) return BMI_ERR_INVALID;
         opt_conv_pw() = value;
         return BMI_OK;
     }

@@ -153,7 +153,8 @@ const char* bmi_error_string(int code);
  *   "xcd_split"                             0 | 1 | 2 | 4: channel-tile classes of the XCD-aware tile order (0 = chosen from
  *                                           the conv's weight bytes so that one XCD's weights stay L2-resident)
  *   "conv_pw"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-1 convs on 8x8 / 4x4 maps with Cout % 256 == 0 run in conv3x3_pw (256 x 256
- *                                           tile, 8 waves) instead of conv3x3_patch (128 x 128, 2 workgroups per CU)
+ *                                           tile, 8 waves) instead of conv3x3_patch (128 x 128, 2 workgroups per CU); 3 | 4 (= 1 | 2 with the four-wave,
+ *                                           software-pipelined conv3x3_pw4 where it applies: measurement reference, the same bits)
  *   "conv_stream"                           0 | 1 | 2 (= 1 without the minimum-grid rule and for plain launches too: tests) | 3 (= 1 with the
  *                                           256-pixel tile: A/B): HBM-bound 1x1 convs (Cin <= 512; with a residual, or Cout % 256 != 0) run
  *                                           in conv1x1_stream (128 x 128 tile, three or four workgroups per CU) instead of conv_igemm_wide

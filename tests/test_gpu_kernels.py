@@ -751,3 +751,25 @@ def test_dense_split_fp16_is_fp32_equivalent(in_f32):
     assert float((outs[0] - ref).abs().max()) < 2e-6 * scale                      # exact-f32 chain vs float64
     assert float((outs[1] - ref).abs().max()) < 2e-6 * scale                      # split-fp16 vs float64: the same class
     assert float((outs[1] - outs[0]).abs().max()) < 1e-6 * scale
+
+
+@pytest.mark.parametrize("cin,cout,H,n", [(256, 256, 8, 21), (512, 512, 4, 37), (64, 256, 8, 1030)])
+@pytest.mark.parametrize("use_res,use_site", [(False, False), (True, True)])
+def test_conv3x3_pw4_equals_conv3x3_pw(cin, cout, H, n, use_res, use_site):
+    """conv3x3_pw4 ("conv_pw" = 4: four waves, accumulators in AGPRs, fragments of the next K-step read under the MFMAs of this one,
+    one barrier per K-step) sums K in conv3x3_pw's order and finishes through the same epilogue code: the same bits."""
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, 3, n, 500 + n, False)
+    res = torch.randn(n, H, H, cout, generator=g).to(torch.float16).to(DEV) if use_res else None
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=2, p=0.25) if use_site else None
+    outs = {}
+    try:
+        for mode in (2, 4):
+            _lib.set_option("conv_pw", mode)
+            outs[mode] = gh.run_conv(x, w, scale, bias, res, True, 1, 1, n, n, n, site=site, batch=n, t0=1, seed=3)
+    finally:
+        _lib.set_option("conv_pw", 1)
+    assert torch.equal(outs[2].view(torch.int16), outs[4].view(torch.int16))
+    ref = gh.conv_ref(x, w, scale, bias, res, True, 1, 1, n, n, n)
+    if site is not None:
+        ref = ref * gh.folded_site_mask(site, n, cout, H, H, 1, 1, 3)
+    torch.testing.assert_close(outs[4].float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=4e-3)

@@ -1,5 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3_lds
+mkdir -p gpurun_out/r3_pw4
 cd $GRAFT_REPO_ROOT
-bash tools/ab_any.sh "python tools/conv_bench.py --images 8000 --iters 10 --only S3,S4,D3p,D4p --nores --sparse-input 2>&1 | grep -v amdgpu | grep -v all" base half > gpurun_out/r3_lds/half.log 2>&1
-cat gpurun_out/r3_lds/half.log
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "pw4" > gpurun_out/r3_pw4/t.log 2>&1; tail -3 gpurun_out/r3_pw4/t.log
