@@ -134,6 +134,11 @@ class GraphBuilder:
         h, w, cin = self.tensors[x]
         if (h, w) != (1, 1) or cin != linear.in_features:
             raise ValueError("dense layers run on flattened [N,1,1,C] tensors")
+        if cin % 32 or linear.out_features % 64:
+            # (zero-padding would move the Philox element index of a site on the padded tensor — index = row * C + c — away from
+            #  the reference's; the converter puts a site behind EVERY Linear)
+            raise TypeError(f"hidden Linear({cin}, {linear.out_features}): the accelerated path takes in_features % 32 == 0 and "
+                            "out_features % 64 == 0")
         out = self.tensor(1, 1, linear.out_features)
         self.ops.append(dict(kind=_lib.OP_DENSE, in_=x, out=out, residual=-1, relu=int(relu),
                              weight=self.dev(linear.weight, torch.float32), bias=self.dev(linear.bias, torch.float32), site=site))
@@ -144,6 +149,8 @@ class GraphBuilder:
         c_in = self.tensors[x][2]
         if linear.in_features != c_in:
             raise ValueError(f"classifier expects {linear.in_features} features, pooled tensor has {c_in}")
+        if c_in % 32:
+            raise TypeError(f"classifier Linear({c_in}, {linear.out_features}): the accelerated path takes in_features % 32 == 0")
         cpad = (linear.out_features + 31) // 32 * 32
         w = torch.zeros(cpad, c_in)
         w[:linear.out_features] = linear.weight.detach().float()

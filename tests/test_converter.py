@@ -68,6 +68,11 @@ def test_wrapper_compiles_and_rejects_what_the_engine_cannot_run():
     bad = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.MaxPool2d(3, 3), nn.Flatten(), nn.Linear(64, 10))
     with pytest.raises(TypeError):
         CompiledGraph(MCDropout(bad, 2, 0.5), "cpu", 4, 1)
+    # hidden widths the dense kernel's tiles do not divide: a clear error at graph-building time, not BMI_ERR_UNSUPPORTED from bmi_create
+    odd = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), *[nn.MaxPool2d(2, 2) for _ in range(5)], nn.Flatten(),
+                        nn.Linear(64, 100), nn.ReLU(), nn.Linear(100, 10))
+    with pytest.raises(TypeError, match="out_features % 64"):
+        CompiledGraph(MCDropout(odd, 2, 0.5), "cpu", 4, 1)
 
 
 @pytest.mark.gpu

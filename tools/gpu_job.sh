@@ -1,4 +1,6 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3_shape
+mkdir -p gpurun_out/r3_final
 cd $GRAFT_REPO_ROOT
-timeout 900 python tools/conv_bench.py --images 25000 --iters 10 --only S2 --nores --sparse-input --rounds 3 --ab mfma_shape_patch=16,mfma_shape_patch=32 2>&1 | grep -v amdgpu | tail -4 | tee gpurun_out/r3_shape/s2.log
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r3_final/test_gpu.log 2>&1; echo "gpu tests rc=$?"; tail -4 gpurun_out/r3_final/test_gpu.log
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python bench.py > gpurun_out/r3_final/bench.log 2>&1; grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"whole_step": {[^}]*}' gpurun_out/r3_final/bench.log | head -3
