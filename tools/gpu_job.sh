@@ -1,6 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3_final
+mkdir -p gpurun_out/r3_graph
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r3_final/test_gpu.log 2>&1; echo "gpu tests rc=$?"; tail -4 gpurun_out/r3_final/test_gpu.log
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 600 python bench.py > gpurun_out/r3_final/bench.log 2>&1; grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"whole_step": {[^}]*}' gpurun_out/r3_final/bench.log | head -3
+for ARGS in "--in-flight 2" "--in-flight 3" "--graph --in-flight 2" "--graph --in-flight 3"; do
+echo "masksembles $ARGS"; python3 bench.py --workload resnet18_masksembles --steps 100 --warmup 10 --no-cpu-baseline $ARGS 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo
+done 2>&1 | tee gpurun_out/r3_graph/masksembles.log
+python3 bench.py --workload resnet18_masksembles --steps 100 --warmup 10 --no-cpu-baseline --graph --in-flight 3 2>/dev/null | grep '^{' > gpurun_out/r3_graph/r03_resnet18_masksembles_graph_bench_line.json
