@@ -1,7 +1,6 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3_graph
+mkdir -p gpurun_out/r3_kw
 cd $GRAFT_REPO_ROOT
-for ARGS in "--in-flight 2" "--in-flight 3" "--graph --in-flight 2" "--graph --in-flight 3"; do
-echo "masksembles $ARGS"; python3 bench.py --workload resnet18_masksembles --steps 100 --warmup 10 --no-cpu-baseline $ARGS 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo
-done 2>&1 | tee gpurun_out/r3_graph/masksembles.log
-python3 bench.py --workload resnet18_masksembles --steps 100 --warmup 10 --no-cpu-baseline --graph --in-flight 3 2>/dev/null | grep '^{' > gpurun_out/r3_graph/r03_resnet18_masksembles_graph_bench_line.json
+for KW in "10 3" "10 10" "30 3" "60 5" "5 1"; do set -- $KW
+echo -n "steps $1 warmup $2: "; python3 bench.py --steps $1 --warmup $2 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo
+done 2>&1 | tee gpurun_out/r3_kw/kw.log
