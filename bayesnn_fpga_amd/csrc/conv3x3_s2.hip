@@ -89,6 +89,20 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef S2_MASK_PHASE
 #define S2_MASK_PHASE 0      // masked-input form: phase of a K-step whose LOAD part masks the pieces that are due
 #endif
+#ifndef S2_BITS_GROUP
+#define S2_BITS_GROUP 0      // 1: ONE keep-bit DMA serves four pieces (the four lanes of a cell fetch the dwords of four different pieces): three
+                             // bit DMAs per chunk instead of ten.  Measured SLOWER (2.21 -> 2.37 ms on the headline's pair launch): the per-lane
+                             // choice among four piece offsets costs 7 VGPRs the kernel does not have, and two of the spilled values are
+                             // reloaded inside the main loop (a scratch load in front of a DMA is a vmcnt wait for everything in flight)
+#endif
+#ifndef S2_MASK_LUT
+#define S2_MASK_LUT 1        // 1: the four dword masks of a keep byte come from a 256-entry table in LDS (one ds_read_b128) instead of 16 vector
+                             // instructions; with S2_MASK_ATOMIC the pair launch of the headline 2.245 -> 2.18 ms (r3_lazy_site.log)
+#endif
+#ifndef S2_MASK_ATOMIC
+#define S2_MASK_ATOMIC 1     // 1: the dropped elements are cleared by two ds_and_b64 (the LDS unit reads, ANDs and writes) instead of
+                             // ds_read_b128 / v_and / ds_write_b128 through the registers
+#endif
 #ifndef S2_ABL_NOEPI
 #define S2_ABL_NOEPI 0       // no epilogue at all (one accumulator element per lane is stored so the MFMAs stay live)
 #endif
@@ -159,7 +173,16 @@ struct S2Geom {
     static_assert(schedule_ok(), "patch refill schedule violates a WAR / RAW window");
     // DMA instructions of step s of a chunk (`last`: the tile's last chunk — no next-chunk pieces, no weights beyond the tile)
     __host__ __device__ static constexpr bool w_issued(int s, bool last) { return s + NST - 1 <= 8 || !last; }
-    __host__ __device__ static constexpr int p_issued(int s, bool last) { return ((s <= 4 || !last) ? pieces_at(s) : 0) * (MSK && !S2_ABL_NOBITS ? 2 : 1); }   // (+ the bits DMA)
+    // keep-bit DMAs (MSK).  Grouped: pieces 0-3 (A, A, A, B: next chunk) at step 5, pieces 4 (B, next chunk) + 9 (own) at step 4, pieces 5-8
+    // (own) at step 0 — each with its group's earliest piece, so a piece's bits land no later than the piece.
+    __host__ __device__ static constexpr int grp(int k) { return k < 4 ? 0 : (k == 4 || k == 9 ? 1 : 2); }
+    __host__ __device__ static constexpr int gidx(int k) { return k < 4 ? k : (k == 4 ? 0 : (k == 9 ? 1 : k - 5)); }
+    __host__ __device__ static constexpr int bits_at(int s, bool last) {
+        if (!MSK || S2_ABL_NOBITS) return 0;
+        if (!S2_BITS_GROUP) return (s <= 4 || !last) ? pieces_at(s) : 0;
+        return (s == 0 || s == 4) ? 1 : ((s == 5 && !last) ? 1 : 0);
+    }
+    __host__ __device__ static constexpr int p_issued(int s, bool last) { return ((s <= 4 || !last) ? pieces_at(s) : 0) + bits_at(s, last); }
     // What may still be in flight when step S ends: everything issued BEHIND the weights of step S + 1 (which were issued first
     // thing in step S - (NST - 2)): that step's pieces, then weights + pieces of the steps up to S.  (Steps before 0 are the
     // previous chunk's, never a last one; in a tile's first chunk they do not exist and the count is merely generous: the
@@ -192,10 +215,11 @@ struct S2Geom {
             if (pstep(k) + 3 == S || pstep(k) + 3 == S + 9) return k;
         return -1;
     }
-    static constexpr int NSLOT = MSK ? 6 : 0;
-    __host__ __device__ static constexpr int slot(int k) { return k >= PRO ? k - PRO : (k < NA ? (k < 2 ? k : 5) : 2 + (k - NA)); }
-    static_assert(!MSK || (NA == 3 && NB == 2 && NOWN == 5), "keep-bit slot plan");
-    static constexpr int LDS_BYTES = BITS_OFF + NSLOT * 2048;
+    static constexpr int NSLOT = MSK ? (S2_BITS_GROUP ? 3 : 6) : 0;
+    __host__ __device__ static constexpr int slot(int k) { return S2_BITS_GROUP ? grp(k) : (k >= PRO ? k - PRO : (k < NA ? (k < 2 ? k : 5) : 2 + (k - NA))); }
+    static_assert(!MSK || (NA == 3 && NB == 2 && NOWN == 5 && NPT == 10), "keep-bit slot plan");
+    static constexpr int LUT_OFF = BITS_OFF + NSLOT * 2048;
+    static constexpr int LDS_BYTES = LUT_OFF + (MSK && S2_MASK_LUT ? 4096 : 0);
     static_assert(BN_OFF - E_OFF >= E_BYTES, "epilogue staging area");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __host__ __device__ static constexpr int wstage_off(int st) { return st == NST - 1 ? WL_OFF : st * WST; }
@@ -251,6 +275,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         const int cc = second ? c - split : c;
         bn_scale[c] = (sp ? sp[cc] : 1.f) * a.out_mul;
         bn_bias[c] = bp ? bp[cc] : 0.f;
+    }
+    if constexpr (MSK && S2_MASK_LUT) {
+        if (tid < 256) {
+            typedef unsigned int u32x4_l __attribute__((ext_vector_type(4)));
+            u32x4_l m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = (((tid >> (2 * i)) & 1) ? 0xffffu : 0u) | (((tid >> (2 * i + 1)) & 1) ? 0xffff0000u : 0u);
+            *(u32x4_l*)(smem + G::LUT_OFF + tid * 16) = m;
+        }
     }
     __syncthreads();   // (no LDS-DMA in flight yet: the plain barrier and its waits are fine here)
 
@@ -332,7 +365,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             o_ = (pre[K] == OOB || row_ < 0) ? OOB : 2u * ((unsigned)row_ * HWC + (pre[K] & 0xffffffu));     \
         }                                                                                                    \
         if (!S2_ABL_NOPATCH) BLDS16(rs_in, o_, __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0)), pbuf + ((K) * 512 + wave * 64) * 16); \
-        if constexpr (MSK && !S2_ABL_NOBITS) {                                                               \
+        if constexpr (MSK && !S2_ABL_NOBITS && !S2_BITS_GROUP) {                                             \
             /* the cell's 32 keep bits of this chunk (the dword that holds this piece's byte); beyond the descriptor: zeros */ \
             /* (derived from pre[K] at every issue: as loop invariants the ten offsets are spilled, and a scratch reload in */ \
             /*  front of a DMA is a vmcnt wait for everything in flight)                                                    */ \
@@ -342,27 +375,52 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                                                      4, (bo_ >> 4) & ~3u, __builtin_amdgcn_readfirstlane((unsigned)(C0) >> 3), 0, 0); \
         }                                                                                                    \
     }
+    // Grouped keep-bit DMA: lane (cell, pos) fetches the dword of piece PA / PB / PC / PD (pos 0..3; -1: none) of ITS cell row; CB = channel
+    // offset of the group's chunk (bytes of bits: / 8), ADD0 = extra bytes for pos 0 (the one piece of the mixed group that carries the
+    // next chunk).  The four lanes of a cell are lanes of one wave: the wave's vmcnt wait covers what its neighbours fetched.
+#define ISSUE_BITS(GRP, PA, PB, PC, PD, CB, ADD0)                                                            \
+    if constexpr (MSK && !S2_ABL_NOBITS && S2_BITS_GROUP) {                                                  \
+        int p4_ = tid & 3;                                                                                   \
+        asm volatile("" : "+v"(p4_));                                                                        \
+        unsigned bo_ = p4_ == 0 ? pre[PA] : (p4_ == 1 ? pre[PB] : ((PC) >= 0 ? (p4_ == 2 ? pre[(PC) < 0 ? 0 : (PC)] : pre[(PD) < 0 ? 0 : (PD)]) : OOB)); \
+        bo_ = ((bo_ >> 4) & ~3u) + (p4_ == 0 ? (unsigned)(ADD0) : 0u);                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bits, (__attribute__((address_space(3))) void*)(smem + G::BITS_OFF + (GRP) * 2048 + wave * 256), \
+                                                 4, bo_, __builtin_amdgcn_readfirstlane((unsigned)(CB) >> 3), 0, 0); \
+    }
     // The thread that issued piece K clears the dropped elements of its 16 bytes: byte (logical chunk) of the slot's dword -> four
     // dword masks.  Own DMA only: the thread's counted vmcnt wait is all it needs; the barriers of the step publish the result.
     typedef unsigned int u32x4_m __attribute__((ext_vector_type(4)));
 #define MASK_LOAD(K, W, V)                                                                                   \
     if (!S2_ABL_NORMW) {                                                                                     \
-        int t4_ = tid * 4;                                                                                   \
+        int t4_ = S2_BITS_GROUP ? ((tid & ~3) + G::gidx(K)) * 4 : tid * 4;                                   \
         asm volatile("" : "+v"(t4_));                                                                        \
-        W = *(const unsigned*)(smem + G::BITS_OFF + G::slot(K) * 2048 + t4_);                                /* this lane's dword of the slot */ \
-        V = *(const u32x4_m*)(pbuf + ((K) * 512 + tid) * 16);                                                \
+        W = *(const unsigned*)(smem + G::BITS_OFF + G::slot(K) * 2048 + t4_);                                /* the dword of this piece's cell */ \
+        if (!S2_MASK_ATOMIC) V = *(const u32x4_m*)(pbuf + ((K) * 512 + tid) * 16);                           \
     }
 #define MASK_STORE(K, W, V)                                                                                  \
     if (!S2_ABL_NORMW) {                                                                                     \
         unsigned sh_ = pre[K];                                                                               \
         asm volatile("" : "+v"(sh_));                                                                        \
         const int b_ = (int)((W) >> ((sh_ >> 1) & 24u));                                                     \
-        u32x4_m v_ = V;                                                                                      \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
-            const unsigned lo_ = (unsigned)__builtin_amdgcn_sbfe(b_, 2 * i_, 1), hi_ = (unsigned)__builtin_amdgcn_sbfe(b_, 2 * i_ + 1, 1); \
-            v_[i_] &= (lo_ & 0xffffu) | (hi_ & 0xffff0000u);                                                 \
+        u32x4_m v_ = V, m_;                                                                                  \
+        if (S2_MASK_LUT) {                                                                                   \
+            m_ = *(const u32x4_m*)(smem + G::LUT_OFF + ((b_ & 0xff) << 4));                                  \
+            v_ &= m_;                                                                                        \
+        } else {                                                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                               \
+                const unsigned lo_ = (unsigned)__builtin_amdgcn_sbfe(b_, 2 * i_, 1), hi_ = (unsigned)__builtin_amdgcn_sbfe(b_, 2 * i_ + 1, 1); \
+                m_[i_] = (lo_ & 0xffffu) | (hi_ & 0xffff0000u);                                              \
+                v_[i_] &= m_[i_];                                                                            \
+            }                                                                                                \
         }                                                                                                    \
-        *(u32x4_m*)(pbuf + ((K) * 512 + tid) * 16) = v_;                                                     \
+        if (S2_MASK_ATOMIC) {                                                                                \
+            typedef __attribute__((address_space(3))) unsigned long long lds_u64;                            \
+            lds_u64* const q_ = (lds_u64*)(pbuf + ((K) * 512 + tid) * 16);                                   \
+            __atomic_fetch_and(q_, ((unsigned long long)m_[1] << 32) | m_[0], __ATOMIC_RELAXED);             \
+            __atomic_fetch_and(q_ + 1, ((unsigned long long)m_[3] << 32) | m_[2], __ATOMIC_RELAXED);         \
+        } else {                                                                                             \
+            *(u32x4_m*)(pbuf + ((K) * 512 + tid) * 16) = v_;                                                 \
+        }                                                                                                    \
     }
 #define MASK_P(K)                                                                                            \
     {                                                                                                        \
@@ -403,6 +461,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             __syncthreads();   /* (drains W(0) too: the dynamic-exit path only) */                           \
         }                                                                                                    \
         _Pragma("unroll") for (int k = 0; k < PRO; ++k) ISSUE_P(k, 0);                                       \
+        ISSUE_BITS(0, 0, 1, 2, 3, 0, 0);                                                                     \
+        ISSUE_BITS(1, 4, 9, -1, -1, 0, 0);                                                                   \
         ISSUE_W(s2_tap(1) * a.Cin, 1);                                                                       \
         if constexpr (NST == 4) ISSUE_W(s2_tap(2) * a.Cin, 2);                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -482,6 +542,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                         if (k >= PRO) { ISSUE_P(k, c32); }                                                     \
                         else if (!last) { ISSUE_P(k, c32 + 32); }                                              \
                     }                                                                                          \
+                if ((S) == 0) { ISSUE_BITS(2, 5, 6, 7, 8, c32, 0); }                                           \
+                if ((S) == 4) { ISSUE_BITS(1, 4, 9, -1, -1, c32, 4); }                                         \
+                if ((S) == 5) { if (!last) { ISSUE_BITS(0, 0, 1, 2, 3, c32 + 32, 0); } }                       \
             }                                                                                                  \
             /* (S2_MASK_PHASE 2: the masking of phase 0's MFMA part wrote LDS behind nothing but this phase's four fragment */ \
             /*  reads — LDS operations of a wave complete in order: with at most four outstanding the write is done) */ \
@@ -673,6 +736,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #undef WAIT_VM
 #undef RAW_BARRIER
 #undef SETUP_TILE
+#undef ISSUE_BITS
 #undef MASK_DUE
 #undef MASK_P
 #undef MASK_STORE
