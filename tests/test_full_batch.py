@@ -93,7 +93,7 @@ def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
     """The first elementwise site of a "block" / "layer" ResNet expands the B prefix images to the folded batch.  With "mask_lazy"
     (default) the MASK op writes keep bits + one scaled copy of the B images, conv3x3_s2 clears the dropped elements of its patch
     pieces in LDS and conv3x3_patch those of the fused shortcut's pixels; with the option off the op stores the masked tensor.
-    Same bits either way (a kept element is x / (1 - p) rounded to fp16 in both), for the full run and for a t-shard; and the MASK
+    Same bits either way (a kept element is x / (1 - p) rounded to fp16 in both), for the full run, a t-shard and an image shard; and the MASK
     launch is the short one (the lazy path ran)."""
     from bayesnn_fpga_amd import _lib
     T, seed = 16, 11
@@ -112,17 +112,26 @@ def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
         first_mask = next(l for l in eng.profile_launches() if l["kind"] == "mask")
         return r, first_mask["ms"]
 
+    def image_shard():                                      # images 100..249 of the batch as their own launch (bmi_forward_mcd_images)
+        part = eng.new_moments(150)
+        eng.accumulate(x[100:].contiguous(), part, 0, T, seed, 0, image_offset=100)
+        torch.cuda.synchronize()
+        return part.clone()
+
     lazy, ms_lazy = timed()
     shard = eng.predict(x, 5, seed=seed, t_begin=3)
+    imgs = image_shard()
     _lib.set_option("mask_lazy", 0)
     try:
         plain, ms_plain = timed()
         shard_plain = eng.predict(x, 5, seed=seed, t_begin=3)
+        imgs_plain = image_shard()
     finally:
         _lib.set_option("mask_lazy", 1)
     for k in ("mean", "var", "logit_mean"):
         assert torch.equal(lazy[k], plain[k]), k
         assert torch.equal(shard[k], shard_plain[k]), k
+    assert torch.equal(imgs, imgs_plain) and float(imgs.abs().max()) > 0
     assert float(lazy["var"].max()) > 0          # the site is live
     print(f"first MASK launch: lazy {ms_lazy * 1e3:.0f} us, materialised {ms_plain * 1e3:.0f} us")
     if dropout == "block":                               # ("layer": the first site sits behind layer1's first conv, on 64 -> 64 stride-1
