@@ -37,8 +37,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef STREAM_KD
 #define STREAM_KD 64            // channels per barrier pair: 64 | 128 (two [weights | pixels] sub-tiles per wait)
 #endif
-template <int EPI, bool BF, int TJ = 4>
+// MSK = keep bits on the input (ConvArgs::in_bits; lazy sites, engine.hip): `in` is the deterministic tensor pre-scaled by 1/(1-p), a
+// thread fetches the keep byte of each pixel piece it DMAs and clears the dropped elements of ITS 16 bytes in LDS between the K-step's
+// wait and its barrier (the K-steps are lock-step with a full vmcnt(0) anyway).
+template <int EPI, bool BF, int TJ = 4, bool MSK = false>
 __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == BMI_EPI_LITE) || STREAM_KD == 128 ? 2 : 3)) void conv1x1_stream_kernel(ConvArgs a) {
+    static_assert(!MSK || (TJ == 2 && STREAM_KD == 64), "masked input: the default form only");
     constexpr int SBP = 64 * TJ;
     constexpr int NSUB = TJ == 2 ? STREAM_KD / 64 : 1;
     constexpr int SUB = (TJ == 4 ? BMI_EPILOGUE_LDS_BYTES : BMI_EPILOGUE_LDS_BYTES / 2);     // one [weights | pixels] sub-tile = the epilogue's tile
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
     const int srcchunk = ((tid & 7) ^ ((rowt >> 1) & 7)) * 8;   // (32*i >> 1) & 7 == 0: the same for all i
     const _Float16* wsrc[4];
     const _Float16* xsrc[2 * TJ];
+    int bsrc[MSK ? 2 * TJ : 1];                       // MSK: byte offset of the piece's keep byte at channel chunk 0, -1 beyond the tensor
 #pragma unroll
     for (int i = 0; i < 4; ++i) wsrc[i] = a.wgt + (size_t)(ch0 + 32 * i + rowt) * a.Cin + srcchunk;
 #pragma unroll
@@ -75,7 +80,29 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
         const int oy = rem / a.Wo;
         const int ox = rem - oy * a.Wo;
         xsrc[i] = a.in + ((size_t)(n % a.in_mod) * a.H * a.W + (size_t)(oy * a.stride) * a.W + ox * a.stride) * a.Cin + srcchunk;
+        if constexpr (MSK) bsrc[i] = m < a.M ? (int)((((size_t)n * a.H + (size_t)(oy * a.stride)) * a.W + ox * a.stride) * (a.Cin >> 3) + (srcchunk >> 3)) : -1;
     }
+    uint32_t kb[MSK ? 2 * TJ : 1];
+#define LOAD_KB(KS)                                                                               \
+    if constexpr (MSK) {                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2 * TJ; ++i) kb[i] = bsrc[i] >= 0 ? a.in_bits[(size_t)(unsigned)bsrc[i] + (KS) * 8] : 0xffu; \
+    }
+#define APPLY_KB()                                                                                \
+    if constexpr (MSK) {                                                                          \
+        typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));                         \
+        _Pragma("unroll") for (int i = 0; i < 2 * TJ; ++i) {                                      \
+            u32x4_s* const pp = (u32x4_s*)(smem + XBASE + (i * 256 + tid) * 16);                  \
+            u32x4_s v = *pp;                                                                      \
+            const int b = (int)kb[i];                                                             \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                       \
+                const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(b, 2 * d, 1), hi = (unsigned)__builtin_amdgcn_sbfe(b, 2 * d + 1, 1); \
+                v[d] &= (lo & 0xffffu) | (hi & 0xffff0000u);                                      \
+            }                                                                                     \
+            *pp = v;                                                                              \
+        }                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    }
+    LOAD_KB(0);
 #pragma unroll
     for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i], smem + XBASE + (i * 256 + wave * 64) * 16);
     const int nK = a.Cin / 64;
@@ -117,6 +144,7 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
         // (vmcnt retires in order: the prefetched residual sits BEHIND the first K-step's operands and in front of the later ones)
         if (RPRE && ks == 0 && a.res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TJ) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        APPLY_KB();
         __builtin_amdgcn_s_barrier();                 // K-step ks has landed (every wave waited for its own pieces)
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -149,8 +177,11 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
 #pragma unroll
                 for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i] + koff, smem + u * SUB + XBASE + (i * 256 + wave * 64) * 16);
             }
+            LOAD_KB(ks + NSUB);
         }
     }
+#undef LOAD_KB
+#undef APPLY_KB
 
     auto pixmap = [&](int p, int& n, int& rem) -> bool {
         const int m = pix0 + p;
@@ -172,12 +203,13 @@ bool conv_takes_stream_kernel(int ksize, int stride, int pad, int cin, int cout)
 
 // BMI_ERR_UNSUPPORTED -> the caller goes on to conv_igemm_wide / conv_igemm.
 int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
-    if (!opt_conv_stream() || a_in.in_bits || a_in.wgt_b || a_in.in2 || a_in.imap) return BMI_ERR_UNSUPPORTED;
+    if (!opt_conv_stream() || a_in.wgt_b || a_in.in2 || a_in.imap) return BMI_ERR_UNSUPPORTED;
+    if (a_in.in_bits && (a_in.out_mul != 1.f || (size_t)a_in.N * a_in.H * a_in.W * (a_in.Cin >> 3) >= 0x7fffffffull)) return BMI_ERR_UNSUPPORTED;
     if (!conv_takes_stream_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout)) return BMI_ERR_UNSUPPORTED;
     if (a_in.N <= 0 || a_in.M <= 0 || a_in.in_mod <= 0 || a_in.B <= 0 || (a_in.res && a_in.res_mod <= 0)) return BMI_ERR_INVALID;
     ConvArgs a = a_in;
     a.xcd_split = xcd_split_for(a.Cout / SBC, (size_t)a.Cout * a.Cin * 2);
-    const int SBP = opt_conv_stream() == 3 ? 256 : 128;   // 3: the 256-pixel tile (A/B)
+    const int SBP = (opt_conv_stream() == 3 && !a_in.in_bits) ? 256 : 128;   // 3: the 256-pixel tile (A/B)
     const long tiles = (((long)a.M + SBP - 1) / SBP) * (a.Cout / SBC);
     if (tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     // the minimum-grid rule of the other wide-tile kernels (on the engine's full-chunk image count, never this launch's)
@@ -197,11 +229,14 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
     // 1470 / 970 us here; with the residual 2502 / 1529 us there, 2227 / 1373 us here.  "conv_stream" = 2 takes them too (tests).
     // Where the wide kernel cannot go (Cout % 256 != 0: the 256 -> 128 / 64 -> 128 reduce and downsample convs) the alternative is the
     // per-tap conv_igemm, and this kernel wins plain launches too: 256 -> 128 on 32x32 2723 -> 2310 us, 64 -> 128 stride 2 455 -> 312 us.
-    if (epi == BMI_EPI_PLAIN && a.Cout % 256 == 0 && opt_conv_stream() != 2) return BMI_ERR_UNSUPPORTED;
+    if (epi == BMI_EPI_PLAIN && a.Cout % 256 == 0 && opt_conv_stream() != 2 && !a.in_bits) return BMI_ERR_UNSUPPORTED;   // (keep bits: the wide kernel has no place to apply them)
     const dim3 grid((unsigned)tiles), block(256);
 #define STREAM_LAUNCH(BF_)                                                                                                      \
     {                                                                                                                           \
-        if (SBP == 128) {                                                                                                       \
+        if (a.in_bits) {                                                                                                        \
+            if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_, 2, true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_, 2, true>), grid, block, 0, s, a);                 \
+        } else if (SBP == 128) {                                                                                                       \
             if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_, 2>), grid, block, 0, s, a); \
             else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_, 2>), grid, block, 0, s, a);                       \
         } else if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_>), grid, block, 0, s, a); \

@@ -328,6 +328,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         BMI_CHECK_LAUNCH();
         return launch_splitk_finish(a, s);
     }
+    if (a.in_bits && a.imap) return BMI_ERR_UNSUPPORTED;   // (no dynamic-exit instantiation of the masked-input variant: the engine writes the masked tensor then)
     if (a.in_bits) {   // masked-input variant (register budget: 128-pixel tiles only)
         if (a.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2, true, true>(a, s);
         return launch_cfg<64, 128, 1, 4, true, true>(a, s);

@@ -573,16 +573,32 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         const bmi_op_desc md = e->suffix[mi].d;
         if (md.kind != BMI_OP_MASK || md.site.kind != BMI_SITE_ELEMENTWISE || md.site_pos == BMI_SITE_POS_INNER || md.site.p >= 1.f) continue;
         const TensorInfo ti = e->tensors[md.in];
-        if (ti.stoch || ti.c % 32 != 0 || ti.h != 32 || ti.w != 32) continue;
-        bool any = false;
+        if (ti.stoch || ti.c % 32 != 0) continue;
+        // every reader must be able to apply the bits itself (else the tensor is written anyway and the bits are extra work):
+        //   conv3x3_s2 on 32x32 maps (also as a pair launch); conv3x3_patch for the input of a fused shortcut on 16x16 maps;
+        //   1x1 convs (conv1x1_stream clears the elements in LDS, conv_igemm while staging) and the 3x3 stride-2 convs that run in
+        //   conv_igemm anyway (ResNet-50's first site: 256 -> 128 k3s2, 256 -> 128 k1, 256 -> 512 k1s2).  A 3x3 stride-1 reader would
+        //   lose its patch kernel to the per-tap one: not lazy.
+        int readers = 0;
+        bool all = true;
         for (const OpInfo& c : e->suffix) {
-            if (c.d.kind != BMI_OP_CONV) continue;
-            if (c.d.in == md.out && c.bits_tensor < 0 && c.d.residual < 0 && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE &&
-                conv_takes_s2_kernel(c.d.ksize, c.d.stride, c.d.pad, ti.c, c.cout + (c.has_pair ? c.pair_cout : 0), ti.h, ti.w, c.ho, c.wo))
-                any = true;
-            if (c.d.in2 == md.out && c.ho == 16 && c.wo == 16) any = true;
+            const bool reads = c.d.in == md.out || (c.d.kind == BMI_OP_CONV && (c.d.residual == md.out || c.d.in2 == md.out)) || c.bits_tensor == md.out;
+            if (!reads || &c == &e->suffix[mi]) continue;
+            ++readers;
+            bool ok = false;
+            if (c.d.kind == BMI_OP_CONV && c.d.residual != md.out && c.bits_tensor < 0) {
+                if (c.d.in2 == md.out) ok = c.d.in != md.out && c.ho == 16 && c.wo == 16;
+                else if (c.d.in2 < 0) {
+                    const bool s2 = ti.h == 32 && ti.w == 32 && c.d.residual < 0 && c.d.site.kind == BMI_SITE_NONE &&
+                                    conv_takes_s2_kernel(c.d.ksize, c.d.stride, c.d.pad, ti.c, c.cout + (c.has_pair ? c.pair_cout : 0), ti.h, ti.w, c.ho, c.wo);
+                    const bool igemm = !c.has_pair && ti.c % 64 == 0 && c.cout % 64 == 0 &&
+                                       (c.d.ksize == 1 || (c.d.ksize == 3 && c.d.stride == 2));
+                    ok = s2 || igemm;
+                }
+            }
+            all = all && ok;
         }
-        if (!any) continue;
+        if (!all || readers == 0) continue;
         TensorInfo tb = ti, tsc = ti;
         tb.stoch = true; tb.bits = true; tb.first = e->tensors[md.out].first; tb.last = e->tensors[md.out].last;
         tsc.stoch = false; tsc.first = tsc.last = -1;
@@ -826,11 +842,12 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 prof.tag(fam, flops, bytes);
                 return rc2 != BMI_OK ? rc2 : launch_conv(q, s);
             }
-            if (pending(d.in)) {
+            if (pending(d.in)) {             // whichever kernel of the chain applies keep bits: conv1x1_stream, conv3x3_s2, conv_igemm
                 ConvArgs m = a;
                 lazy_in(m);
-                const int rcl = launch_conv3x3_s2(m, s);
-                prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
+                int faml = -1;
+                const int rcl = launch_conv(m, s, &faml);
+                prof.tag(faml, flops, bytes);
                 if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
                 const int rcm = materialise(d.in);
                 if (rcm != BMI_OK) return rcm;

@@ -301,8 +301,24 @@ __global__ __launch_bounds__(256) void mask_bits_call_kernel(uint8_t* __restrict
         uint64_t out = 0;
         if (!s.drop_all) {
             const philox4 r = philox_site_call(s, elem0, (uint32_t)(t0 + tl));
+            if constexpr (LB == 1) {
+                // 2 bits per element: word w holds elements 16 w .. 16 w + 15, field e at bits 2e.  field >= thresh on all 16 fields at once
+                // (b0 / b1 = the even / odd bits: b1 | b0 for thresh 1, b1 for 2, b1 & b0 for 3), then the even bits are packed into 16
+                const uint32_t use_or = s.thresh == 1 ? 0xffffffffu : 0u, use_and = s.thresh == 3 ? 0xffffffffu : 0u;
 #pragma unroll
-            for (int q = 0; q < GPC; ++q) out |= (uint64_t)philox_keep8(r, (uint32_t)elem0 + 8u * q, LB, s.thresh) << (8 * q);
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t f = r.w[w], b0 = f & 0x55555555u, b1 = (f >> 1) & 0x55555555u;
+                    uint32_t x = (b1 | (b0 & use_or)) & (b0 | ~use_and) & 0x55555555u;
+                    x = (x | (x >> 1)) & 0x33333333u;
+                    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+                    x = (x | (x >> 4)) & 0x00ff00ffu;
+                    x = (x | (x >> 8)) & 0x0000ffffu;
+                    out |= (uint64_t)x << (16 * w);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < GPC; ++q) out |= (uint64_t)philox_keep8(r, (uint32_t)elem0 + 8u * q, LB, s.thresh) << (8 * q);
+            }
         }
         if constexpr (GPC == 8) *(uint64_t*)(bits + i * 8) = out;
         else if constexpr (GPC == 4) *(uint32_t*)(bits + i * 4) = (uint32_t)out;

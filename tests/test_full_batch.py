@@ -136,3 +136,36 @@ def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
     print(f"first MASK launch: lazy {ms_lazy * 1e3:.0f} us, materialised {ms_plain * 1e3:.0f} us")
     if dropout == "block":                               # ("layer": the first site sits behind layer1's first conv, on 64 -> 64 stride-1
         assert ms_lazy < 0.7 * ms_plain                  #  consumers: nothing takes keep bits there and the op runs as before)
+
+
+def test_lazy_first_site_resnet50():
+    """ResNet-50 multi-exit: the first site (256 channels, 32x32) is read by a 3x3 stride-2 conv that runs in conv_igemm (keep bits applied
+    while staging), a 1x1 conv and a 1x1 stride-2 conv (conv1x1_stream: elements cleared in LDS).  Lazy vs materialised: the same
+    inputs and masks through different kernels of the same K order -> equal to fp32 summation order (1e-5 on probabilities), and the MASK
+    launch is the short one."""
+    from bayesnn_fpga_amd import _lib
+    T, seed = 8, 3
+    model = build_seeded(bx.ResNet50MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    synthetic_weights_(model, 0)
+    eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    x = synthetic_images(B, seed=1234).to(DEV)
+
+    def timed():
+        eng.predict(x, T, seed=seed)
+        eng.profile(True)
+        r = eng.predict(x, T, seed=seed)
+        torch.cuda.synchronize()
+        eng.profile_read()
+        eng.profile(False)
+        return r, next(l for l in eng.profile_launches() if l["kind"] == "mask")["ms"]
+
+    lazy, ms_lazy = timed()
+    _lib.set_option("mask_lazy", 0)
+    try:
+        plain, ms_plain = timed()
+    finally:
+        _lib.set_option("mask_lazy", 1)
+    for k in ("mean", "var"):
+        assert float((lazy[k] - plain[k]).abs().max()) < 1e-5, k
+    print(f"ResNet-50 first MASK launch: lazy {ms_lazy * 1e3:.0f} us, materialised {ms_plain * 1e3:.0f} us")
+    assert ms_lazy < 0.7 * ms_plain
