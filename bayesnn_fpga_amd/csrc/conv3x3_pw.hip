@@ -78,8 +78,9 @@ struct PwGeom {
     __host__ __device__ static constexpr int cell_delta(int j) { return (j / BI) * PH * PWP + 4 * ((j % BI) / BR) * PWP + 4 * ((j % BI) % BR); }
 };
 
-template <int TW, int EPI, bool BF, bool IMAP>
+template <int TW, int EPI, bool BF, bool IMAP, bool POOL = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
+    static_assert(!POOL || (TW == 4 && EPI == BMI_EPI_LITE), "pooled output: 4x4 maps, the lite epilogue");
     using G = PwGeom<TW>;
     constexpr int CT = G::CT, TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
     constexpr int TJ = 4, TI = 4, TP = 8;
@@ -311,7 +312,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pw_kernel(ConvArgs a) {
         off = ((size_t)n * (TH * TW) + rem) * a.Cout;
         return ok;
     };
-    epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+    if constexpr (POOL) epilogue_lite<TJ, BF, false, true>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
+    else epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem + g * BMI_EPILOGUE_LDS_BYTES, tid & 255, chg, pixmap, offmap);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -560,6 +562,20 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)tiles), block(512);
     const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+    if (a.pool) {   // fp32 means over the 4x4 map instead of the map (the conv feeds one exit head only): the lite epilogue on the registers
+        if constexpr (TW == 4) {
+            if (epi == BMI_EPI_GENERAL) return BMI_ERR_UNSUPPORTED;
+            if (a.imap) {
+                if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<4, BMI_EPI_LITE, true, true, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((conv3x3_pw_kernel<4, BMI_EPI_LITE, false, true, true>), grid, block, 0, s, a);
+            } else if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<4, BMI_EPI_LITE, true, false, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_pw_kernel<4, BMI_EPI_LITE, false, false, true>), grid, block, 0, s, a);
+            BMI_CHECK_LAUNCH();
+            return BMI_OK;
+        } else {
+            return BMI_ERR_UNSUPPORTED;
+        }
+    }
     if (opt_conv_pw() >= 3 && !a.in2 && !a.imap && !a.bf16 && epi != BMI_EPI_GENERAL && a.Cin % 64 == 0) {   // the four-wave form ("conv_pw" = 3 | 4)
         const dim3 block4(256);
         if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv3x3_pw4_kernel<TW, BMI_EPI_PLAIN, false, false>), grid, block4, 0, s, a);

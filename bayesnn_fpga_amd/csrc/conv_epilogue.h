@@ -344,7 +344,10 @@ __host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_sh
 // Same arithmetic in the same order as epilogue_coalesced (fp32 throughout, one rounding), so the bits agree.
 // RES_IN_LDS: the caller has issued the residual DMA of step 2 itself (same pieces, same layout, into `lds`) before or
 // during its main loop — conv1x1_stream, whose tile has nothing else to overlap the residual's HBM round trip with.
-template <int TJ, bool BF, bool RES_IN_LDS = false, class ACC, class PixMap, class OffMap>
+// POOL (conv3x3_pw on 4x4 maps, ConvArgs::pool): the 16 pixels of an accumulator tile are one image; instead of the fp16 map the
+// launch stores fp32 means over the map, [row][Cout] — the tile's 16 lanes are a DPP row: four v_add_f32 with DPP modifiers leave the
+// sum in every lane, lane 0 stores 4 consecutive channels.  The conv feeds nothing but an exit head (relu -> avg_pool2d(4) -> Linear).
+template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, class ACC, class PixMap, class OffMap>
 __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
                                               PixMap pixmap, OffMap offmap) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -425,6 +428,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
                 f32x4_e mk = {1.f, 1.f, 1.f, 1.f};
                 if (msk) mk = *(const f32x4_e*)(mrow + 16 * i);
                 half4 o;
+                f32x4_e pv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[i][j][e];
@@ -434,12 +438,28 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
                     if (msk) v = mk[e] == 0.f ? 0.f : v * mk[e];
                     asm("" : "+v"(v));   // keep the fp32 product: fused into v_fma_mixlo_f16 it is rounded once instead of twice,
                                          // and 1 element in 10^6 ends one fp16 ulp away from what epilogue_coalesced stores
-                    o[e] = a16_from_f32<BF>(v);
+                    if constexpr (POOL) {
+                        float x = fmaxf(v, 0.f);                       // (the head's ReLU)
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // 7 - lane (half row)
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // 15 - lane (row)
+                        pv[e] = x * (1.f / 16.f);
+                    } else {
+                        o[e] = a16_from_f32<BF>(v);
+                    }
                 }
-                *(half4*)(lds + p * 256 + ((cq ^ l16) << 4) + ((q4 & 1) << 3)) = o;
+                if constexpr (POOL) {
+                    int n, rem;
+                    const bool okp = pixmap(p, n, rem);
+                    if (l16 == 0 && okp) *(f32x4_e*)(a.pool + (size_t)n * a.Cout + ch0 + wc * 64 + 16 * i + 4 * q4) = pv;
+                } else {
+                    *(half4*)(lds + p * 256 + ((cq ^ l16) << 4) + ((q4 & 1) << 3)) = o;
+                }
             }
         }
     }
+    if constexpr (POOL) return;
     lds_barrier();
     const int k = tid & 15;
     half8_e o[4 * TJ];

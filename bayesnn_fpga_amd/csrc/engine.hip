@@ -48,6 +48,7 @@ struct OpInfo {
     int nsplit = 0;         // CONV (prefix): split-K workgroups per tile (bmi_plan; 0 = none)
     bool pool_ok = false;   // CONV: its 4x4 output feeds ONE exit head and nothing else: conv3x3_s2 may write the pooled means instead
     bool pair_pool_ok = false;   // ... the same for the second conv of a pair
+    bool pool_pw_ok = false;     // CONV (3x3 stride 1, 4x4 map, feeds ONE exit head only): conv3x3_pw may write the pooled means instead
     bool has_pair = false;  // CONV: a second conv on the same input rides in this launch (conv_igemm_wide pair mode)
     bmi_op_desc pair_d;
     int pair_cout = 0;
@@ -214,7 +215,7 @@ int bmi_set_option(const char* name, int32_t value) {
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_pool") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        if (value < 0 || value > 2) return BMI_ERR_INVALID;
         opt_conv_pool() = value;
         return BMI_OK;
     }
@@ -541,6 +542,16 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 return d.ksize == 3 && d.stride == 2 && d.pad == 1 && to.h == 4 && to.w == 4 && d.residual < 0 && d.in2 < 0 &&
                        d.site.kind == BMI_SITE_NONE && cout % 128 == 0 && readers(d.out, &heads) == 1 && heads == 1;
             };
+            // ... and the last conv of the net (layer4[1].conv2: stride 1, with its residual) in front of the final head: conv3x3_pw's
+            // lite epilogue does the same on its registers
+            auto eligible_pw = [&](const bmi_op_desc& d, int cout) {
+                const TensorInfo& to = e->tensors[d.out];
+                int heads = 0;
+                return d.ksize == 3 && d.stride == 1 && d.pad == 1 && to.h == 4 && to.w == 4 && d.in2 < 0 && d.relu &&
+                       (d.site.kind == BMI_SITE_NONE || d.site_pos != BMI_SITE_POS_INNER) && cout % 256 == 0 && !c.has_pair &&
+                       readers(d.out, &heads) == 1 && heads == 1;
+            };
+            c.pool_pw_ok = c.bits_tensor < 0 && eligible_pw(c.d, c.cout);
             c.pool_ok = c.bits_tensor < 0 && eligible(c.d, c.cout);
             c.pair_pool_ok = c.has_pair && eligible(c.pair_d, c.pair_cout);
         }
@@ -874,6 +885,16 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 return launch_conv_igemm(a, s);
             }
             e->tensors[d.out].pooled_now = false;
+            if (opt_conv_pool() == 1 && op.pool_pw_ok) {      // ("conv_pool" = 2: conv3x3_s2's only)
+                ConvArgs q = a;
+                q.pool = (float*)q.out;
+                const int rcp = launch_conv3x3_pw(q, s);
+                if (rcp != BMI_ERR_UNSUPPORTED) {
+                    prof.tag(BMI_CONV_FAMILY_PW, flops, bytes);
+                    e->tensors[d.out].pooled_now = true;
+                    return rcp;
+                }
+            }
             if (opt_conv_pool() && op.pool_ok) {
                 ConvArgs q = a;
                 q.pool = (float*)q.out;

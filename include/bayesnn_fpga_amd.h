@@ -161,8 +161,9 @@ const char* bmi_error_string(int code);
  *   "conv_s2"                               0 | 1 | 2 (= 1 without the minimum-grid rule: tests): 3x3 stride-2 convs with a BN + ReLU epilogue on
  *                                           32x32 / 16x16 / 8x8 maps with Cout % 256 == 0 (a pair's channels together) run in conv3x3_s2 (input
  *                                           patch resident in LDS as four parity planes, persistent) instead of conv_igemm_wide
- *   "conv_pool"                             0 | 1: a plain 3x3 stride-2 conv whose 4x4 output map feeds one exit head and nothing else writes
- *                                           fp32 means over the map (ReLU + avg_pool2d(4) fused into conv3x3_s2's epilogue) instead of the map
+ *   "conv_pool"                             0 | 1 | 2: a 3x3 conv whose 4x4 output map feeds one exit head and nothing else writes fp32 means over the
+ *                                           map (ReLU + avg_pool2d(4) fused into the epilogue) instead of the map: the plain stride-2 convs in
+ *                                           conv3x3_s2 (1, 2) and the stride-1 conv in front of the final head in conv3x3_pw (1)
  *   "mask_lazy"                             0 | 1: the elementwise site that expands the once-per-batch prefix (32x32 maps) to the folded batch writes
  *                                           keep bits + one scaled copy of the B images; conv3x3_s2 / conv3x3_patch (fused shortcut input) clear the
  *                                           dropped elements in LDS, any other consumer makes the masked tensor appear first (1, default), or the

@@ -64,7 +64,8 @@ def test_real_batch_against_oracle(name):
 def test_fused_relu_avgpool_equals_the_separate_head_pooling():
     """A plain 3x3 stride-2 conv whose 4x4 map feeds one exit head only (ex1conv3 / ex2conv2 / ex3conv1, the last one as the second
     conv of a pair) writes fp32 means over the map from conv3x3_s2's epilogue instead of the fp16 map ("conv_pool", default on,
-    when that kernel takes the launch: B = 250 here).  Against the same engine with the fusion off: equal to the fp16 rounding of
+    when that kernel takes the launch: B = 250 here); so does the last conv of the net in front of the final head (layer4[1].conv2:
+    3x3 stride 1 with its residual, conv3x3_pw's lite epilogue).  Against the same engine with the fusion off: equal to the fp16 rounding of
     the 4x4 activations it no longer rounds (1e-4 on a sum of T probabilities), and NOT equal bit for bit (the fused path ran);
     both within 1e-3 of each other in mean and variance."""
     from bayesnn_fpga_amd import _lib
@@ -82,8 +83,8 @@ def test_fused_relu_avgpool_equals_the_separate_head_pooling():
     for k in ("mean", "var"):
         d = (fused[k] - plain[k]).abs()
         assert float(d.max()) < 2e-4, (k, float(d.max()))
-    assert not torch.equal(fused["mean"][:3], plain["mean"][:3])            # the three early exits took the fused epilogue
-    assert torch.equal(fused["mean"][3], plain["mean"][3])                  # the final exit's layer4 output is not a stride-2 conv's
+    assert not torch.equal(fused["mean"][:3], plain["mean"][:3])            # the three early exits took conv3x3_s2's fused epilogue
+    assert not torch.equal(fused["mean"][3], plain["mean"][3])              # ... and the final exit conv3x3_pw's (layer4[1].conv2, with its residual)
     again = eng.predict(x, T, seed=seed)
     assert torch.equal(again["mean"], fused["mean"])
 
