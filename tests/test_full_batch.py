@@ -170,3 +170,29 @@ def test_lazy_first_site_resnet50():
         assert float((lazy[k] - plain[k]).abs().max()) < 1e-5, k
     print(f"ResNet-50 first MASK launch: lazy {ms_lazy * 1e3:.0f} us, materialised {ms_plain * 1e3:.0f} us")
     assert ms_lazy < 0.7 * ms_plain
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_lazy_first_site_bf16_engine(arch):
+    """The bf16 instantiations of the lazy path (scaled copy rounded to bf16, conv3x3_s2 / conv3x3_patch / conv1x1_stream masking in
+    LDS, conv_igemm while staging): lazy vs materialised on the bf16 engine — ResNet-18: the same kernels read the same bits -> equal;
+    ResNet-50: other kernels of the same K order -> equal to fp32 summation order."""
+    from bayesnn_fpga_amd import _lib
+    T, seed = 4, 9
+    cls = ResNet18MCEarlyExit if arch == "resnet18" else bx.ResNet50MCEarlyExit
+    model = build_seeded(cls, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    synthetic_weights_(model, 0)
+    eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=B, dtype="bf16")
+    x = synthetic_images(B, seed=1234).to(DEV)
+    lazy = eng.predict(x, T, seed=seed)
+    _lib.set_option("mask_lazy", 0)
+    try:
+        plain = eng.predict(x, T, seed=seed)
+    finally:
+        _lib.set_option("mask_lazy", 1)
+    for k in ("mean", "var"):
+        if arch == "resnet18":
+            assert torch.equal(lazy[k], plain[k]), k
+        else:
+            assert float((lazy[k] - plain[k]).abs().max()) < 1e-4, k
+    assert float(lazy["var"].max()) > 0
