@@ -12,12 +12,12 @@ LIB_PATH = os.path.join(HERE, "libbayesnn_fpga_amd.so")
 BMI_OK = 0
 SITE_NONE, SITE_ELEMENTWISE, SITE_CHANNEL, SITE_MASKSEMBLE = 0, 1, 2, 3
 SITE_POS_OUTER, SITE_POS_INNER = 0, 1
-DTYPE_F16, DTYPE_BF16 = 0, 1
+DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
 PROFILE_SLOTS = 8
 CONV_FAMILY_KERNELS = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel", "conv1x1_stream_kernel",
                        "conv3x3_s2_kernel")
-ABI_VERSION = 300             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
+ABI_VERSION = 400             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
 CONV_FAMILIES = len(CONV_FAMILY_KERNELS)     # BMI_CONV_FAMILIES
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
                  OP_DENSE: "dense"}
@@ -61,6 +61,8 @@ _PROTOS = {
     "bmi_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "bmi_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                             C.POINTER(C.c_int32)]),
+    "bmi_tensor_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)] + [C.POINTER(C.c_int32)] * 5),
+    "bmi_image_offset_ok": (C.c_int, [C.c_void_p, C.c_int32]),
     "bmi_forward_mcd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "bmi_forward_mcd_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,

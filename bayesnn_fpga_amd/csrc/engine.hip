@@ -74,6 +74,9 @@ struct bmi_engine_s {
     std::vector<OpInfo> prefix, suffix;
     int n_exits = 0, out_dim = 0;
     int bf16 = 0;               // BMI_DTYPE_BF16
+    int f32 = 0;                // BMI_DTYPE_F32: the exact engine (fp32 activations and conv weights, conv_exact.hip)
+    int dtype = 0;              // BMI_DTYPE_*
+    bool no_reuse = false;      // bmi_plan: every suffix tensor keeps its own workspace range ("ws_no_reuse": per-layer traces)
     int64_t prefix_macs = 0, suffix_macs = 0;
     // plan
     int max_batch = 0, chunk = 0;
@@ -175,6 +178,7 @@ int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_mask_lazy() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
+int& opt_ws_no_reuse() { static int v = 0; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
     return v;
@@ -195,8 +199,13 @@ int bmi_version(void) { return BMI_VERSION; }
 int bmi_set_option(const char* name, int32_t value) {
     if (!name) return BMI_ERR_INVALID;
     if (std::strcmp(name, "unit_entry_dtype") == 0) {
-        if (value != BMI_DTYPE_F16 && value != BMI_DTYPE_BF16) return BMI_ERR_INVALID;
+        if (value != BMI_DTYPE_F16 && value != BMI_DTYPE_BF16 && value != BMI_DTYPE_F32) return BMI_ERR_INVALID;
         opt_unit_dtype() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "ws_no_reuse") == 0) {   // read by bmi_plan
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_ws_no_reuse() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "wide_persist_min_x10") == 0) {
@@ -276,17 +285,20 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     if (!desc || !out || desc->n_tensors < 2 || desc->n_ops < 1 || !desc->tensors || !desc->ops) return BMI_ERR_INVALID;
     if (desc->n_exits < 1 || desc->out_dim < 1) return BMI_ERR_INVALID;
     if (desc->out_dim > 128) return BMI_ERR_UNSUPPORTED;
-    if (desc->dtype != BMI_DTYPE_F16 && desc->dtype != BMI_DTYPE_BF16) return BMI_ERR_INVALID;
+    if (desc->dtype != BMI_DTYPE_F16 && desc->dtype != BMI_DTYPE_BF16 && desc->dtype != BMI_DTYPE_F32) return BMI_ERR_INVALID;
     bmi_engine_s* e = new (std::nothrow) bmi_engine_s();
     if (!e) return BMI_ERR_NOMEM;
     e->n_exits = desc->n_exits;
     e->out_dim = desc->out_dim;
     e->bf16 = desc->dtype == BMI_DTYPE_BF16;
+    e->f32 = desc->dtype == BMI_DTYPE_F32;
+    e->dtype = desc->dtype;
     e->tensors.resize(desc->n_tensors);
     for (int i = 0; i < desc->n_tensors; ++i) {
         const bmi_tensor_desc& t = desc->tensors[i];
         if (t.h < 1 || t.w < 1 || t.c < 1) { delete e; return BMI_ERR_INVALID; }
         e->tensors[i].h = t.h; e->tensors[i].w = t.w; e->tensors[i].c = t.c;
+        e->tensors[i].f32 = e->f32 && i > 0;   // the exact engine keeps every activation in fp32
     }
     std::vector<char> written(desc->n_tensors, 0);
     written[0] = 1;  // network input
@@ -300,7 +312,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         if (!tensor_ok(d.in) || !written[d.in] || !site_ok(d.site)) { rc = BMI_ERR_INVALID; break; }
         const TensorInfo tin = e->tensors[d.in];
         bool in_st = tin.stoch;
-        if (tin.f32 && d.kind != BMI_OP_DENSE && d.kind != BMI_OP_HEAD) { rc = BMI_ERR_UNSUPPORTED; break; }
+        if (tin.f32 && !e->f32 && d.kind != BMI_OP_DENSE && d.kind != BMI_OP_HEAD) { rc = BMI_ERR_UNSUPPORTED; break; }
         switch (d.kind) {
             case BMI_OP_STEM:
             case BMI_OP_CONV: {
@@ -327,6 +339,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     in_st = in_st || tr.stoch;
                 }
                 int64_t macs = (int64_t)op.ho * op.wo * op.cout * d.ksize * d.ksize * tin.c;
+                if (d.kind == BMI_OP_CONV && d.in2 >= 0 && e->f32) { rc = BMI_ERR_UNSUPPORTED; break; }   // a speed feature (BN scales folded into 16-bit weights)
                 if (d.kind == BMI_OP_CONV && d.in2 >= 0) {
                     if (!tensor_ok(d.in2) || !written[d.in2] || d.in2 == 0 || !d.weight2 || d.scale) { rc = BMI_ERR_INVALID; break; }
                     const TensorInfo& t2 = e->tensors[d.in2];
@@ -456,7 +469,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     // so it is OFF by default; BMI_MASK_BITS=1 enables it (covered by the parity tests).
     {
         const char* env = std::getenv("BMI_MASK_BITS");
-        const bool enable = env && std::atoi(env) == 1;
+        const bool enable = env && std::atoi(env) == 1 && !e->f32;
         for (size_t mi = 0; enable && mi < e->suffix.size(); ++mi) {
             OpInfo& m = e->suffix[mi];
             if (m.d.kind != BMI_OP_MASK || m.d.site.kind != BMI_SITE_ELEMENTWISE || e->tensors[m.d.in].stoch) continue;
@@ -492,7 +505,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     // in between).  BMI_CONV_PAIR=0 keeps them separate (A/B, tests).
     {
         const char* env = std::getenv("BMI_CONV_PAIR");
-        const bool enable = !env || std::atoi(env) != 0;
+        const bool enable = (!env || std::atoi(env) != 0) && !e->f32;
         auto plain = [&](const OpInfo& c) {
             return c.d.kind == BMI_OP_CONV && !c.has_pair && c.d.residual < 0 && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE &&
                    c.bits_tensor < 0 && c.out_mul == 1.f && c.d.scale && c.d.bias;
@@ -535,7 +548,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
             return n;
         };
         for (OpInfo& c : *ops) {
-            if (c.d.kind != BMI_OP_CONV) continue;
+            if (c.d.kind != BMI_OP_CONV || e->f32) continue;
             auto eligible = [&](const bmi_op_desc& d, int cout) {
                 const TensorInfo& to = e->tensors[d.out];
                 int heads = 0;
@@ -580,7 +593,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     // instead; kept x 1/(1-p) rounded to fp16 and ANDed with the bits is what the MASK op itself stores, so the result is bit for
     // bit the materialised one.  Decided per launch (run_op): a consumer whose kernel does not take the launch makes the
     // MASK op's own launch happen first ("mask_lazy" = 0: always).
-    for (size_t mi = 0; mi < e->suffix.size(); ++mi) {
+    for (size_t mi = 0; mi < e->suffix.size() && !e->f32; ++mi) {
         const bmi_op_desc md = e->suffix[mi].d;
         if (md.kind != BMI_OP_MASK || md.site.kind != BMI_SITE_ELEMENTWISE || md.site_pos == BMI_SITE_POS_INNER || md.site.p >= 1.f) continue;
         const TensorInfo ti = e->tensors[md.in];
@@ -651,9 +664,10 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     std::sort(order.begin(), order.end(), [&](int a, int b) { return h->tensors[a].first < h->tensors[b].first; });
     const size_t st_base = off;
     size_t st_peak = 0;
+    h->no_reuse = opt_ws_no_reuse() != 0;
     for (int id : order) {
         TensorInfo& t = h->tensors[id];
-        live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.last < t.first; }), live.end());
+        if (!h->no_reuse) live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.last < t.first; }), live.end());
         std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
         const size_t size = align_up(t.bits ? NS * t.h * t.w * t.c / 8 : NS * t.h * t.w * t.c * (t.f32 ? 4 : 2), 256);
         size_t pos = 0;
@@ -676,7 +690,7 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     for (OpInfo& op : h->prefix) {
         op.nsplit = 0;
         const bmi_op_desc& d = op.d;
-        if (d.kind != BMI_OP_CONV || !opt_splitk() || d.ksize != 3 || d.residual >= 0 || d.in2 >= 0 || d.site.kind != BMI_SITE_NONE ||
+        if (d.kind != BMI_OP_CONV || h->f32 || !opt_splitk() || d.ksize != 3 || d.residual >= 0 || d.in2 >= 0 || d.site.kind != BMI_SITE_NONE ||
             op.has_pair || op.bits_tensor >= 0 || op.cout % 128 != 0)
             continue;
         const TensorInfo& ti = h->tensors[d.in];
@@ -694,6 +708,19 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     h->max_batch = max_batch;
     h->chunk = chunk_samples;
     *workspace_bytes = off;
+    return BMI_OK;
+}
+
+int bmi_tensor_info(bmi_handle h, int32_t id, int64_t* offset, int32_t* elem_bytes, int32_t* per_sample, int32_t* th, int32_t* tw, int32_t* tc) {
+    if (!h || id < 1 || id >= (int32_t)h->tensors.size() || h->max_batch == 0) return BMI_ERR_INVALID;
+    const TensorInfo& t = h->tensors[id];
+    if (t.bits || (t.stoch && t.first < 0)) return BMI_ERR_UNSUPPORTED;   // keep bits / a tensor nothing reads have no activation layout
+    if (offset) *offset = (int64_t)t.offset;
+    if (elem_bytes) *elem_bytes = t.f32 ? 4 : 2;
+    if (per_sample) *per_sample = t.stoch ? 1 : 0;
+    if (th) *th = t.h;
+    if (tw) *tw = t.w;
+    if (tc) *tc = t.c;
     return BMI_OK;
 }
 
@@ -748,6 +775,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     };
     const int n_rows = imap ? (N / Bc) * B : N;     // rows of a stochastic tensor (original folded layout)
     if (imap && d.kind != BMI_OP_CONV && d.kind != BMI_OP_HEAD) return BMI_ERR_UNSUPPORTED;
+    if (imap && e->f32) return BMI_ERR_UNSUPPORTED;
     // a lazy site's tensor (see bmi_create) is written now if this op cannot apply the mask itself
     auto pending = [&](int id) { return id >= 0 && e->tensors[id].lazy_pending; };
     auto materialise = [&](int id) -> int {
@@ -765,7 +793,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     switch (d.kind) {
         case BMI_OP_STEM:
             return launch_stem_conv(x, (const float*)d.weight, d.scale, d.bias, (_Float16*)(ws + e->tensors[d.out].offset), N,
-                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, e->bf16, s);
+                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, e->dtype, s);
         case BMI_OP_CONV: {
             ConvArgs a;
             std::memset(&a, 0, sizeof(a));
@@ -775,7 +803,10 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.scale = d.scale; a.bias = d.bias;
             a.out = (_Float16*)(ws + e->tensors[d.out].offset);
             a.N = N;
-            a.n_ref = (tin.stoch || (d.residual >= 0 && e->tensors[d.residual].stoch) || op.stoch) ? B * e->chunk : B;
+            // kernel selection looks at the PLANNED batch (x the planned chunk for suffix launches), never at this call's batch or sample
+            // count: a t-shard, a partial chunk, an image share (bmi_forward_mcd_images) and a loader's smaller last batch all run the
+            // kernels — and get the bits — of the full batch
+            a.n_ref = (tin.stoch || (d.residual >= 0 && e->tensors[d.residual].stoch) || op.stoch) ? e->max_batch * e->chunk : e->max_batch;
             a.imap = rows; a.Bc = Bc;
             a.in_mod = tin.stoch ? n_rows : B;
             if (d.residual >= 0) {
@@ -803,10 +834,16 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 m.in_mod = B;
                 m.in_bits = (const uint8_t*)(ws + e->tensors[tin.lazy_bits].offset);
             };
+            if (e->f32) {   // the exact engine: one generic kernel (a.in / a.wgt / a.res / a.out hold fp32)
+                prof.tag(-1, 0, 0);
+                return launch_conv_exact(a, s);
+            }
             double flops = 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
             if (d.in2 >= 0) flops += 2.0 * N * op.ho * op.wo * (double)op.cout * e->tensors[d.in2].c;
-            // algorithmic bytes: every operand tensor once (a deterministic operand counts its B images), weights once
+            // algorithmic bytes: every operand tensor once (a deterministic operand counts its B images), weights once; an operand read
+            // through a lazy site (the B scaled images + the folded batch's keep bits) counts what such a launch actually has to move
             auto tbytes = [&](int id) { const TensorInfo& t = e->tensors[id]; return 2.0 * (t.stoch ? N : B) * t.h * t.w * t.c; };
+            auto lazy_saving = [&](int id) { const TensorInfo& t = e->tensors[id]; return tbytes(id) - (2.0 * B + N / 8.0) * t.h * t.w * t.c; };
             double bytes = tbytes(d.in) + 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) +
                            2.0 * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
             if (d.residual >= 0) bytes += tbytes(d.residual);
@@ -823,7 +860,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                     ConvArgs m = p;
                     lazy_in(m);
                     const int rcl = launch_conv3x3_s2(m, s);
-                    prof.tag(BMI_CONV_FAMILY_S2, flops, bytes);
+                    prof.tag(BMI_CONV_FAMILY_S2, flops, bytes - lazy_saving(d.in));
                     if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
                     const int rcm = materialise(d.in);
                     if (rcm != BMI_OK) return rcm;
@@ -858,7 +895,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 lazy_in(m);
                 int faml = -1;
                 const int rcl = launch_conv(m, s, &faml);
-                prof.tag(faml, flops, bytes);
+                prof.tag(faml, flops, bytes - lazy_saving(d.in));
                 if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
                 const int rcm = materialise(d.in);
                 if (rcm != BMI_OK) return rcm;
@@ -872,12 +909,13 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                     m.in2_mod = B;
                     m.in2_bits = (const uint8_t*)(ws + e->tensors[t2.lazy_bits].offset);
                     rcl = launch_conv3x3_patch(m, s);
-                    prof.tag(BMI_CONV_FAMILY_PATCH, flops, bytes);
+                    prof.tag(BMI_CONV_FAMILY_PATCH, flops, bytes - lazy_saving(d.in2));
                 }
                 if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
                 const int rcm = materialise(d.in2);
                 if (rcm != BMI_OK) return rcm;
             }
+            e->tensors[d.out].pooled_now = false;
             if (op.nsplit > 1 && !op.stoch && !rows) {
                 a.partial = (float*)(ws + e->splitk_off);
                 a.nsplit = op.nsplit;
@@ -922,6 +960,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
             a.site = resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)tin.h * tin.w * tin.c, (size_t)tin.c));
             if (d.site_pos == BMI_SITE_POS_INNER) { a.bias_post = d.bias_post; a.relu = d.relu; }
+            if (e->f32) return launch_mask_apply_f32(a, s);
             TensorInfo& to = e->tensors[d.out];
             to.lazy_pending = false;
             if (to.lazy_bits >= 0 && opt_mask_lazy() && !tin.stoch && N % B == 0) {
@@ -939,6 +978,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             return launch_mask_apply(a, s);
         }
         case BMI_OP_MAXPOOL:
+            if (e->f32) return launch_maxpool2_f32((const float*)(ws + tin.offset), (float*)(ws + e->tensors[d.out].offset), N, tin.h, tin.w, tin.c, s);
             return launch_maxpool2((const _Float16*)(ws + tin.offset), (_Float16*)(ws + e->tensors[d.out].offset), N, tin.h,
                                    tin.w, tin.c, e->bf16, s);
         case BMI_OP_DENSE:
@@ -972,25 +1012,30 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
 
 extern "C" {
 
+int bmi_image_offset_ok(bmi_handle h, int32_t image_offset) {
+    if (!h || image_offset < 0) return BMI_ERR_INVALID;
+    if (image_offset == 0) return BMI_OK;
+    // a site's index offset must be a whole number of Philox calls at every bit width (64 elements): per-image element counts
+    // of every site tensor — conv / mask outputs, pooled features, dense outputs
+    for (const std::vector<OpInfo>* ops : {&h->prefix, &h->suffix})
+        for (const OpInfo& op : *ops) {
+            const bmi_op_desc& d = op.d;
+            if (d.site.kind != BMI_SITE_ELEMENTWISE && d.site.kind != BMI_SITE_CHANNEL) continue;
+            if (d.kind == BMI_OP_HEAD && d.site_pos == BMI_SITE_POS_INNER) continue;      // logits site: the kernel adds b0 itself
+            const TensorInfo& tin = h->tensors[d.in];
+            const size_t unit = d.kind == BMI_OP_HEAD ? (size_t)tin.c
+                                : d.kind == BMI_OP_DENSE || d.site.kind == BMI_SITE_CHANNEL ? (size_t)op.cout
+                                : (size_t)op.ho * op.wo * op.cout;
+            if (((size_t)image_offset * unit) % 64 != 0) return BMI_ERR_UNSUPPORTED;
+        }
+    return BMI_OK;
+}
+
 int bmi_forward_mcd_images(bmi_handle h, const float* x_nchw, int32_t batch, int32_t image_offset, int32_t t_begin,
                            int32_t t_count, uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL,
                            void* workspace, size_t workspace_bytes, bmi_stream stream) {
-    if (!h || image_offset < 0) return BMI_ERR_INVALID;
-    if (image_offset > 0) {
-        // a site's index offset must be a whole number of Philox calls at every bit width (64 elements): per-image element counts
-        // of every site tensor — conv / mask outputs, pooled features, dense outputs — are checked here, once per call
-        for (const std::vector<OpInfo>* ops : {&h->prefix, &h->suffix})
-            for (const OpInfo& op : *ops) {
-                const bmi_op_desc& d = op.d;
-                if (d.site.kind != BMI_SITE_ELEMENTWISE && d.site.kind != BMI_SITE_CHANNEL) continue;
-                if (d.kind == BMI_OP_HEAD && d.site_pos == BMI_SITE_POS_INNER) continue;      // logits site: the kernel adds b0 itself
-                const TensorInfo& tin = h->tensors[d.in];
-                const size_t unit = d.kind == BMI_OP_HEAD ? (size_t)tin.c
-                                    : d.kind == BMI_OP_DENSE || d.site.kind == BMI_SITE_CHANNEL ? (size_t)op.cout
-                                    : (size_t)op.ho * op.wo * op.cout;
-                if (((size_t)image_offset * unit) % 64 != 0) return BMI_ERR_UNSUPPORTED;
-            }
-    }
+    const int rco = bmi_image_offset_ok(h, image_offset);
+    if (rco != BMI_OK) return rco;
     h->image_offset = image_offset;
     const int rc = bmi_forward_mcd(h, x_nchw, batch, t_begin, t_count, seed, mask_cnt0, S1, S2, SL, workspace, workspace_bytes, stream);
     h->image_offset = 0;
@@ -1027,7 +1072,7 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
     if (!h || !x_nchw || !S1 || !S2 || !SL || !workspace || !exit_of_image || !active_after) return BMI_ERR_INVALID;
     if (batch < 1 || t_count < 1 || mask_cnt0 < 0 || first_exit < 0) return BMI_ERR_INVALID;
     if (h->max_batch == 0 || batch > h->max_batch) return BMI_ERR_INVALID;
-    if (t_count > h->chunk) return BMI_ERR_UNSUPPORTED;     // an exit's decision needs ALL samples of the stage in the workspace
+    if (t_count > h->chunk || h->f32) return BMI_ERR_UNSUPPORTED;     // an exit's decision needs ALL samples of the stage in the workspace
     if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
@@ -1141,7 +1186,7 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
                       int32_t pad, int32_t relu, bmi_stream stream) {
     if (!x_nchw || !weight || !out_nhwc) return BMI_ERR_INVALID;
     return launch_stem_conv(x_nchw, weight, scale, bias, (_Float16*)out_nhwc, n, cin, h, w, cout, ksize, stride, pad, relu,
-                            opt_unit_dtype() == BMI_DTYPE_BF16, (hipStream_t)stream);
+                            opt_unit_dtype(), (hipStream_t)stream);
 }
 
 int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* site, int32_t batch, int32_t t0,
@@ -1172,6 +1217,7 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
     a.site = resolve_site(site, seed, mask_cnt0);
     a.in_bits = (const uint8_t*)in_keep_bits;
     a.out_mul = out_mul;
+    if (opt_unit_dtype() == BMI_DTYPE_F32) return launch_conv_exact(a, (hipStream_t)stream);
     return launch_conv(a, (hipStream_t)stream);
 }
 
@@ -1228,11 +1274,13 @@ int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t
                    int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
     EltArgs a;
     const int rc = elt_args(a, in, out, n, in_mod, hw, c, site, batch, t0, seed, mask_cnt0);
+    if (rc == BMI_OK && opt_unit_dtype() == BMI_DTYPE_F32) return launch_mask_apply_f32(a, (hipStream_t)stream);
     return rc != BMI_OK ? rc : launch_mask_apply(a, (hipStream_t)stream);
 }
 
 int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c, bmi_stream stream) {
     if (!in || !out) return BMI_ERR_INVALID;
+    if (opt_unit_dtype() == BMI_DTYPE_F32) return launch_maxpool2_f32((const float*)in, (float*)out, n, h, w, c, (hipStream_t)stream);
     return launch_maxpool2((const _Float16*)in, (_Float16*)out, n, h, w, c, opt_unit_dtype() == BMI_DTYPE_BF16, (hipStream_t)stream);
 }
 

@@ -110,7 +110,11 @@ int launch_conv3x3_s2(const ConvArgs& a, hipStream_t s);      // 3x3 stride-2 co
 bool conv_takes_s2_kernel(int ksize, int stride, int pad, int cin, int cout, int h, int w, int ho, int wo);
 int launch_conv(const ConvArgs& a, hipStream_t s, int* family = nullptr);   // picks the kernel; *family = BMI_CONV_FAMILY_*
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
-                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int bf16, hipStream_t s);
+                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int dt /* BMI_DTYPE_* of out */, hipStream_t s);
+// the exact engine (BMI_DTYPE_F32, conv_exact.hip): the 16-bit pointer fields of ConvArgs / EltArgs hold fp32 tensors and fp32 weights
+int launch_conv_exact(const ConvArgs& a, hipStream_t s);
+int launch_mask_apply_f32(const EltArgs& a, hipStream_t s);
+int launch_maxpool2_f32(const float* in, float* out, int n, int h, int w, int c, hipStream_t s);
 int launch_mask_apply(const EltArgs& a, hipStream_t s);
 int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, int bf16, hipStream_t s);
 // hidden dense layer, fp32 weights [cout][k] / accumulate / output; `in` 16-bit (in_kind 0: fp16, 2: bf16) or fp32 (1) [n or in_mod][k]

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void mask_apply_lb1_kernel(EltArgs a) {
     const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long)gridDim.x * blockDim.x) >> 6;
     const uint32_t thresh = a.site.thresh;
     const uint32_t use_or = thresh == 1 ? 0xFFFFu : 0u, use_and = thresh == 3 ? 0xFFFFu : 0u;
+    const uint32_t keep_all = thresh == 0 ? 0x5555u : 0u;     // p = 0: every field >= 0 (the bit tricks below only cover thresh 1..3)
     const char* const myfield = (const char*)W + (lane >> 3) * 16 + 2 * (lane & 7);   // + 128 * j: owner lane j*8 + lane/8
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // Work item = (super-block of the sample, chunk of `tchunk` samples).  With a deterministic input (the usual case: the site
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void mask_apply_lb1_kernel(EltArgs a) {
             for (int j = 0; j < 8; ++j) {
                 const uint32_t f = *(const uint16_t*)(myfield + 128 * j);
                 const uint32_t b0 = f & 0x5555u, b1 = (f >> 1) & 0x5555u;
-                const uint32_t kb = a.site.drop_all ? 0u : ((b1 | (b0 & use_or)) & (b0 | ~use_and));   // bit 2e = keep element e
+                const uint32_t kb = a.site.drop_all ? 0u : (((b1 | (b0 & use_or)) & (b0 | ~use_and)) | keep_all);   // bit 2e = keep element e
                 half8 r;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = a16_from_f32<BF>(a16_to_f32<BF>(x[j][e]) * a.site.scale);
@@ -305,10 +306,11 @@ __global__ __launch_bounds__(256) void mask_bits_call_kernel(uint8_t* __restrict
                 // 2 bits per element: word w holds elements 16 w .. 16 w + 15, field e at bits 2e.  field >= thresh on all 16 fields at once
                 // (b0 / b1 = the even / odd bits: b1 | b0 for thresh 1, b1 for 2, b1 & b0 for 3), then the even bits are packed into 16
                 const uint32_t use_or = s.thresh == 1 ? 0xffffffffu : 0u, use_and = s.thresh == 3 ? 0xffffffffu : 0u;
+                const uint32_t keep_all = s.thresh == 0 ? 0x55555555u : 0u;     // p = 0: every field >= 0 (thresh 1..3 below)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const uint32_t f = r.w[w], b0 = f & 0x55555555u, b1 = (f >> 1) & 0x55555555u;
-                    uint32_t x = (b1 | (b0 & use_or)) & (b0 | ~use_and) & 0x55555555u;
+                    uint32_t x = (((b1 | (b0 & use_or)) & (b0 | ~use_and)) | keep_all) & 0x55555555u;
                     x = (x | (x >> 1)) & 0x33333333u;
                     x = (x | (x >> 2)) & 0x0f0f0f0fu;
                     x = (x | (x >> 4)) & 0x00ff00ffu;
@@ -395,7 +397,8 @@ int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int 
 // one pixel (8 channels each): every wave-load fetched 8 distinct words and the kernel sat at 80 us for 0.9 GFLOP.
 // FAST: three input channels and whole 32-channel blocks (every model of the path): no per-quad channel guards, the three
 // loads of a tap issued together.
-template <bool BF, bool FAST>
+// F32OUT (the exact engine, BMI_DTYPE_F32): `out` holds fp32.
+template <bool BF, bool FAST, bool F32OUT = false>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         _Float16* __restrict__ out, int N, int Cin_, int H, int W, int Cout,
@@ -444,33 +447,47 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             }
         }
     }
-    _Float16* op = out + (((size_t)n * Ho + oy) * Wo + ox) * Cout + c0;
+    const size_t o_off = (((size_t)n * Ho + oy) * Wo + ox) * Cout + c0;
+    _Float16* op = out + o_off;
 #pragma unroll
     for (int g8 = 0; g8 < 4; ++g8) {
         if (8 * g8 < nc) {
             half8 o;
+            float of[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = acc[8 * g8 + e];
                 if (scale) v *= scale[c0 + 8 * g8 + e];
                 if (bias) v += bias[c0 + 8 * g8 + e];
                 if (relu) v = fmaxf(v, 0.f);
-                o[e] = a16_from_f32<BF>(v);
+                if constexpr (F32OUT) of[e] = v;
+                else o[e] = a16_from_f32<BF>(v);
             }
-            *(half8*)(op + 8 * g8) = o;
+            if constexpr (F32OUT) {
+                float* fp = (float*)out + o_off + 8 * g8;
+                *(float4*)fp = make_float4(of[0], of[1], of[2], of[3]);
+                *(float4*)(fp + 4) = make_float4(of[4], of[5], of[6], of[7]);
+            } else {
+                *(half8*)(op + 8 * g8) = o;
+            }
         }
     }
 }
 
+// dt: BMI_DTYPE_* of `out` (F16 / BF16: 16-bit NHWC; F32: fp32 NHWC)
 int launch_stem_conv(const float* x, const float* w, const float* scale, const float* bias, _Float16* out, int n,
-                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int bf16, hipStream_t s) {
+                     int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int dt, hipStream_t s) {
+    const int bf16 = dt == BMI_DTYPE_BF16;
     if (cout % 8 != 0 || cout * ksize * ksize * cin > STEM_MAX_W) return BMI_ERR_UNSUPPORTED;
     if (n <= 0) return BMI_ERR_INVALID;
     const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wdt + 2 * pad - ksize) / stride + 1;
     const long total = (long)n * ho * wo;
     const dim3 grid((unsigned)((total + 255) / 256), (unsigned)((cout + 31) / 32)), block(256);
 #define STEM_LAUNCH(BF_, F_) hipLaunchKernelGGL((stem_conv_kernel<BF_, F_>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu)
-    if (cin == 3 && cout % 32 == 0) { if (bf16) STEM_LAUNCH(true, true); else STEM_LAUNCH(false, true); }
+    if (dt == BMI_DTYPE_F32) {
+        if (cin == 3 && cout % 32 == 0) hipLaunchKernelGGL((stem_conv_kernel<false, true, true>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+        else hipLaunchKernelGGL((stem_conv_kernel<false, false, true>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+    } else if (cin == 3 && cout % 32 == 0) { if (bf16) STEM_LAUNCH(true, true); else STEM_LAUNCH(false, true); }
     else { if (bf16) STEM_LAUNCH(true, false); else STEM_LAUNCH(false, false); }
 #undef STEM_LAUNCH
     BMI_CHECK_LAUNCH();

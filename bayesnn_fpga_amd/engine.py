@@ -44,11 +44,11 @@ class GraphBuilder:
     """Collects tensors / ops / device-resident weights for one model on one device."""
 
     def __init__(self, device, dtype="f16"):
-        if dtype not in ("f16", "bf16"):
-            raise ValueError(f"dtype must be 'f16' or 'bf16', got {dtype!r}")
+        if dtype not in ("f16", "bf16", "f32"):
+            raise ValueError(f"dtype must be 'f16', 'bf16' or 'f32' (the exact engine), got {dtype!r}")
         self.device = device
         self.dtype = dtype
-        self.act_dtype = torch.float16 if dtype == "f16" else torch.bfloat16     # conv weights / activations
+        self.act_dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype]     # conv weights / activations
         self.tensors = []          # (h, w, c)
         self.ops = []              # dicts
         self.keep = []             # device tensors that must outlive the engine
@@ -166,11 +166,12 @@ def _unwrap(module):
     return module, None
 
 
-def _can_fuse_shortcut(t_in, blk):
+def _can_fuse_shortcut(t_in, blk, dtype="f16"):
     """The 1x1 strided downsample conv rides along in the 3x3 patch kernel when that kernel takes conv2
     (16x16 / 8x8 / 4x4 maps, Cout % 128 == 0) and the block input has a multiple of 64 channels.
-    BMI_FUSE_SHORTCUT=0 keeps the separate launch + residual (A/B, tests)."""
-    if os.environ.get("BMI_FUSE_SHORTCUT", "1") == "0":
+    BMI_FUSE_SHORTCUT=0 keeps the separate launch + residual (A/B, tests); the exact engine never fuses (the fusion folds
+    the BN scales into the 16-bit weights: a speed feature)."""
+    if os.environ.get("BMI_FUSE_SHORTCUT", "1") == "0" or dtype == "f32":
         return False
     h, w, c = t_in
     ds = blk.downsample[0]
@@ -225,7 +226,7 @@ def build_resnet_graph(model, g):
             a = g.conv(x, c1, blk.bn1, relu=True, site=g.site(w1, channelwise=True), site_inner=w1 is not None)
             # site ids follow call order: a block's site is allocated when the block finishes; conv2's before the shortcut's
             site2 = g.site(w2, channelwise=True) if w2 is not None else g.site(site_mod)
-            if ds is not None and wd is None and w2 is None and _can_fuse_shortcut(g.tensors[a], blk):
+            if ds is not None and wd is None and w2 is None and _can_fuse_shortcut(g.tensors[a], blk, g.dtype):
                 x = g.conv(a, c2, blk.bn2, relu=True, site=site2, shortcut=(x, ds, blk.downsample[1]))
             else:
                 res = x
@@ -322,7 +323,7 @@ class CompiledGraph:
             else:
                 d.site = _lib.make_site()
         desc = _lib.ModelDesc(len(g.tensors), tarr, len(g.ops), oarr, self.n_exits, self.out_dim,
-                              _lib.DTYPE_BF16 if self.dtype == "bf16" else _lib.DTYPE_F16)
+                              {"f16": _lib.DTYPE_F16, "bf16": _lib.DTYPE_BF16, "f32": _lib.DTYPE_F32}[self.dtype])
         return (desc, tarr, oarr)
 
     def flops_per_batch(self, batch, T):
@@ -407,6 +408,14 @@ class MCDEngine(CompiledGraph):
         _lib.check(rc, "bmi_forward_mcd_images")
         return S
 
+    def image_offset_ok(self, image_offset):
+        """Whether a share of a batch that starts at image ``image_offset`` can be run by ``accumulate(..., image_offset=)``
+        (bmi_image_offset_ok: host-only, every site's index offset must be a whole number of Philox calls)."""
+        rc = self.lib.bmi_image_offset_ok(self.handle, int(image_offset))
+        if rc not in (_lib.BMI_OK, -95):
+            _lib.check(rc, "bmi_image_offset_ok")
+        return rc == _lib.BMI_OK
+
     def finalize(self, S, t_total):
         """mean / var (ddof=0) / mean logit, float64 [E, B, C] each."""
         out = torch.empty_like(S)
@@ -453,9 +462,26 @@ class MCDEngine(CompiledGraph):
         self.accumulate(x, S, t, 1, seed, cnt0)
         return [S[2, e].float() for e in range(self.n_exits)]
 
+    def read_tensor(self, tensor_id, batch, samples=1):
+        """A copy of graph tensor ``tensor_id`` as it sits in the workspace after a forward (bmi_tensor_info): fp32
+        [samples * batch or batch, h, w, c].  For per-layer traces (tools/layer_trace.py): plan the engine under
+        ``set_option("ws_no_reuse", 1)`` (and ``mask_lazy`` = 0, ``conv_pool`` = 0), else a later tensor may have taken the range."""
+        off, eb, ps = C.c_int64(), C.c_int32(), C.c_int32()
+        th, tw, tc = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.bmi_tensor_info(self.handle, int(tensor_id), C.byref(off), C.byref(eb), C.byref(ps), C.byref(th),
+                                            C.byref(tw), C.byref(tc)), "bmi_tensor_info")
+        n = batch * (samples if ps.value else 1)
+        count = n * th.value * tw.value * tc.value
+        raw = self.workspace[off.value:off.value + count * eb.value]
+        dt = torch.float32 if eb.value == 4 else (torch.bfloat16 if self.dtype == "bf16" else torch.float16)
+        return raw.view(dt).view(n, th.value, tw.value, tc.value).float().clone()
+
     # ---- measurement helpers ---------------------------------------------------------------------
+    profiling = False
+
     def profile(self, enable):
         _lib.check(self.lib.bmi_profile_enable(self.handle, int(bool(enable))), "bmi_profile_enable")
+        self.profiling = bool(enable)
 
     def profile_read(self):
         ms = (C.c_double * _lib.PROFILE_SLOTS)()
@@ -528,49 +554,95 @@ class BatchesInFlight:
         with torch.cuda.stream(st):
             return fn(self.engines[i])
 
-    def predict_graphed(self, x, T, seed=0, cnt0=0):
+    def predict_graphed(self, x, T, seed=0, cnt0=0, group=None):
         """``engine.predict(x, T, seed, cnt0=cnt0)`` of the next slot as ONE hipGraph launch (torch.cuda.CUDAGraph on ROCm).
         The library neither allocates nor synchronises inside bmi_forward_mcd / bmi_finalize, so the whole batch step — zero
         the moments, the once-per-batch prefix, every sample chunk of the suffix, finalize — is captured once per
         (slot, batch size, T, seed, cnt0) and replayed on the slot's static input buffer; a batch of another size (a loader's
-        smaller last batch) is captured on first sight, anything that cannot be captured runs eagerly.  What it buys: the
-        small-model configs are launch-bound — VGG-11 at batch 250 x T = 30 is 20 launches of 20-50 us on a ~20 us floor each
-        — and a replay issues them back to back.  Results are bit for bit the eager ones (tests/test_gpu_model.py).
+        smaller last batch) is captured on first sight.  What it buys: the small-model configs are launch-bound — VGG-11 at
+        batch 250 x T = 30 is 20 launches of 20-50 us on a ~20 us floor each — and a replay issues them back to back.
+        Results are bit for bit the eager ones (tests/test_gpu_model.py).
+
+        With a process group of more than one rank (``group``, or the default group when ``torch.distributed`` is initialised) the
+        graph holds THIS RANK'S SHARE of the step (``sharding.accumulate_share``: its samples, or its images when T < ranks — one
+        Masksembles mask of config 4 per GPU is exactly such a launch-bound step) and the all-reduce + finalize follow the replay
+        eagerly on the slot's stream: a collective is never captured.
+
         The scalars of a launch (seed, first sample index, Masksembles counter) are baked into the captured kernel arguments:
-        batches that must differ in them get a graph each.  Returns the slot's STATIC output tensors: read them (after
-        `last_stream`) before the slot comes round again, i.e. within the next len(engines) - 1 submissions."""
+        batches that must differ in them get a graph each — keep seed / cnt0 constant over a loader walk, or the cache (at most
+        ``graph_cache_max`` graphs per slot, least recently used evicted with its static buffers) turns over.  Engine profiling
+        (bmi_profile_enable records events) cannot be captured: refused.  A capture that fails runs the step eagerly instead.
+        Returns the slot's STATIC output tensors: read them (after `last_stream`) before the slot comes round again, i.e. within
+        the next len(engines) - 1 submissions."""
+        from .sharding import _rank_world, accumulate_share
+        rank, world = _rank_world(group)
         i = self.slot()
         self.k += 1
         eng = self.engines[i]
         if not hasattr(self, "_graphs"):
-            self._graphs = [dict() for _ in self.engines]
+            from collections import OrderedDict
+            self._graphs = [OrderedDict() for _ in self.engines]
             self._gstreams = [st if st is not None else torch.cuda.Stream(self.device) for st in self.streams]
         st = self._gstreams[i]
         self.last_stream = st
         cur = torch.cuda.current_stream(self.device)
-        key = (tuple(x.shape), int(T), int(seed), int(cnt0))
-        rec = self._graphs[i].get(key)
+        key = (tuple(x.shape), int(T), int(seed), int(cnt0), rank, world)
+        cache = self._graphs[i]
+        rec = cache.get(key)
+
+        def eager():
+            st.wait_stream(cur)
+            x.record_stream(st)
+            with torch.cuda.stream(st):
+                S = eng.new_moments(x.shape[0])
+                accumulate_share(eng, x, S, T, seed, cnt0, rank, world)
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
+                return eng.finalize(S, T)
+
         if rec is None:
+            if eng.profiling:
+                raise RuntimeError("predict_graphed while engine profiling is on: the event records of bmi_profile_enable cannot be captured")
             xs = torch.empty_like(x)
             S = eng.new_moments(x.shape[0])
             st.wait_stream(cur)
             with torch.cuda.stream(st):                          # warm-up on the capture stream (module load, first launches)
                 xs.copy_(x)
-                eng.accumulate(xs, S, 0, T, seed, cnt0)
+                accumulate_share(eng, xs, S, T, seed, cnt0, rank, world)
             st.synchronize()
             graph, out = torch.cuda.CUDAGraph(), {}
-            with torch.cuda.graph(graph, stream=st):
-                S.zero_()
-                eng.accumulate(xs, S, 0, T, seed, cnt0)
-                out.update(eng.finalize(S, T))
-            rec = self._graphs[i][key] = (graph, xs, S, out)
+            try:
+                with torch.cuda.graph(graph, stream=st):
+                    S.zero_()
+                    accumulate_share(eng, xs, S, T, seed, cnt0, rank, world)
+                    if world == 1:
+                        out.update(eng.finalize(S, T))
+            except Exception as exc:                              # (a launcher returned non-OK under capture, ...)
+                import warnings
+                warnings.warn(f"hipGraph capture of a batch step failed ({exc}); running eagerly")
+                torch.cuda.synchronize(self.device)
+                cache[key] = "eager"
+                return eager()
+            rec = cache[key] = (graph, xs, S, out)
+            while len(cache) > self.graph_cache_max:
+                cache.popitem(last=False)                          # least recently used: its graph and static buffers are freed
+        if rec == "eager":
+            return eager()
+        cache.move_to_end(key)
         graph, xs, S, out = rec
         st.wait_stream(cur)
         x.record_stream(st)
         with torch.cuda.stream(st):
             xs.copy_(x, non_blocking=True)
             graph.replay()
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
+                return eng.finalize(S, T)
         return out
+
+    graph_cache_max = 8
 
     def synchronize(self):
         for st in list(self.streams) + list(getattr(self, "_gstreams", [])):

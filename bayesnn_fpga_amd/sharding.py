@@ -37,34 +37,58 @@ def accumulate_sharded(accumulate_fn, S, T, group=None, t_begin=0):
     return S
 
 
-def partition(T, B, rank, world):
+def partition(T, B, rank, world, kind=None):
     """What rank ``rank`` of ``world`` runs of a batch of B images x T Monte-Carlo samples: ``("samples", lo, hi)`` — the
     sample range [lo, hi) on all images — while there are at least as many samples as ranks, else ``("images", lo, hi)`` —
     ALL T samples on images [lo, hi): the fallback of SURVEY.md §8.5 ("partition by images, pure DP") for T < G, where a
     sample split would leave ranks idle (T = 4 on 8 GPUs: half of them) and every rank would still recompute the whole
-    once-per-batch prefix.  Either way the shares are disjoint and their moment buffers add up to the one-rank result."""
-    if T >= world:
-        return ("samples",) + shard_range(T, rank, world)
-    return ("images",) + shard_range(B, rank, world)
+    once-per-batch prefix.  Either way the shares are disjoint and their moment buffers add up to the one-rank result.
+    T == world (config 4: one Masksembles mask per GPU) goes by samples: measured on one MI355X, a rank's share of
+    250 images x 1 sample against 31 images x 8 samples (tools/share_bench.py, profiles/r04_share_config4.txt).
+    ``kind`` forces one of the two (measurements, tests)."""
+    if kind not in (None, "samples", "images"):
+        raise ValueError(f"kind must be 'samples' or 'images', got {kind!r}")
+    if kind is None:
+        kind = "samples" if T >= world else "images"
+    return (kind,) + (shard_range(T, rank, world) if kind == "samples" else shard_range(B, rank, world))
 
 
-def accumulate_partitioned(engine, x, S, T, seed=0, cnt0=0, group=None):
-    """This rank's share of batch ``x`` x T samples ADDED into the moment buffer ``S`` [3, E, B, C], then ONE all-reduce (sum)
-    over the group.  Shares by samples when T >= world size (``accumulate_sharded``), by images otherwise: the rank runs
-    ``engine.accumulate(x[lo:hi], ..., image_offset=lo)`` — masks drawn at the images' indices in the whole batch
-    (bmi_forward_mcd_images) — into its rows of S; the other ranks' rows stay zero until the all-reduce."""
+def _rank_world(group=None):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-    else:
-        rank, world = 0, 1
-    kind, lo, hi = partition(T, x.shape[0], rank, world)
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def accumulate_share(engine, x, S, T, seed=0, cnt0=0, rank=0, world=1, kind=None):
+    """Rank ``rank``'s share of batch ``x`` x T samples ADDED into the moment buffer ``S`` [3, E, B, C]; NO collective (what a
+    hipGraph of a rank's step captures: ``BatchesInFlight.predict_graphed``).  Shares by samples when T >= world size, by images
+    otherwise: the rank runs ``engine.accumulate(x[lo:hi], ..., image_offset=lo)`` — masks drawn at the images' indices in the
+    whole batch (bmi_forward_mcd_images) — into its rows of S; the other ranks' rows stay zero until the all-reduce."""
+    kind, lo, hi = partition(T, x.shape[0], rank, world, kind)
     if kind == "samples":
-        return accumulate_sharded(lambda buf, t0, n: engine.accumulate(x, buf, t0, n, seed, cnt0), S, T, group)
+        if hi > lo:
+            engine.accumulate(x, S, lo, hi - lo, seed, cnt0)
+        return S
+    # every rank checks EVERY rank's image offset (host-only, the same answer everywhere): a partition some rank's kernels cannot
+    # take is refused by the whole group before anyone launches, instead of one rank raising while the others wait in the all-reduce
+    bad = [r for r in range(world) if not engine.image_offset_ok(shard_range(x.shape[0], r, world)[0])]
+    if bad:
+        raise ValueError(f"image partition of a batch of {x.shape[0]} over {world} ranks: the shares of ranks {bad} do not start on a "
+                         "whole Philox call of every site (bmi_image_offset_ok)")
     if hi > lo:
         part = S.new_zeros(3, S.shape[1], hi - lo, S.shape[3])
         engine.accumulate(x[lo:hi].contiguous(), part, 0, T, seed, cnt0, image_offset=lo)
         S[:, :, lo:hi] += part
+    return S
+
+
+def accumulate_partitioned(engine, x, S, T, seed=0, cnt0=0, group=None):
+    """This rank's share of batch ``x`` x T samples ADDED into the moment buffer ``S`` [3, E, B, C] (``accumulate_share``), then ONE
+    all-reduce (sum) over the group."""
+    import torch.distributed as dist
+    rank, world = _rank_world(group)
+    accumulate_share(engine, x, S, T, seed, cnt0, rank, world)
     if world > 1:
         dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
     return S

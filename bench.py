@@ -33,6 +33,9 @@ import os
 import sys
 import time
 
+if os.environ.get("BENCH_RANK_MARK_DIR") and "RANK" in os.environ:      # tests: "rank r of the job was started" (before the slow imports)
+    open(os.path.join(os.environ["BENCH_RANK_MARK_DIR"], "rank" + os.environ["RANK"]), "w").close()
+
 import numpy as np
 import torch
 
@@ -97,7 +100,8 @@ def parse():
                          "the once-per-batch prefix of step k+1 runs beside the suffix of step k; 1 = one stream")
     ap.add_argument("--graph", action="store_true",
                     help="each batch step (zero, prefix, suffix chunks, finalize) is ONE hipGraph replay (engine.BatchesInFlight.predict_graphed): "
-                         "takes the launch floor out of the launch-bound small-model configs (VGG-11); single rank only")
+                         "takes the launch floor out of the launch-bound small-model configs (VGG-11, one Masksembles mask per GPU); with more "
+                         "than one rank the graph holds the rank's share and the all-reduce + finalize follow the replay eagerly")
     ap.add_argument("--dump-mean", default="", help="rank 0 writes the final predictive mean [E,B,C] float64 to this .npy (tests)")
     return ap.parse_args()
 
@@ -313,9 +317,6 @@ def main():
         accumulate_partitioned(e, x, S, T, a.seed)
         return e.finalize(S, T)
 
-    if a.graph and world > 1:
-        raise SystemExit("--graph captures a whole single-rank batch step; the sharded path issues its all-reduce eagerly")
-
     def step():
         # one step = one batch through the whole path; consecutive steps alternate between the engines / streams of `pipe`
         if a.graph:
@@ -331,11 +332,20 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    # per-step completion events (the median of >= 10 timed iterations next to the mean): one record per step on the
+    # stream the step ran on — no synchronisation inside the timed region, `value` stays K steps / wall
+    ev0 = torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev0.record(torch.cuda.current_stream(dev))
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for k in range(a.steps):
         out = step()
+        evs[k].record(pipe.last_stream if pipe.last_stream is not None else torch.cuda.current_stream(dev))
     fence()
     dt = time.perf_counter() - t0
+    done_ms = [ev0.elapsed_time(e) for e in evs]              # completion time of step k since the start of the timed region
+    step_ms = sorted(b - a_ for a_, b in zip([0.0] + done_ms[:-1], done_ms))      # intervals between consecutive completions
+    median_ms = (step_ms[len(step_ms) // 2] + step_ms[(len(step_ms) - 1) // 2]) / 2 if step_ms else 0.0
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -358,8 +368,8 @@ def main():
         conv_ms, conv_launches = prof.get("conv_igemm", (0.0, 0))
         conv_flops -= 2.0 * my_B * eng.stem_macs     # the 3-channel stem runs in its own direct kernel
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        alg_bytes, _ = eng.conv_traffic_model(my_B, my_T)
         alg_launches = int(conv_launches)            # launches actually made (paired convs are one launch)
+        alg_bytes = sum(v["bytes"] for v in eng.conv_families.values())       # what the launches were priced at (lazy-site operands: B images + bits)
         traffic, traffic_src = (hbm_traffic(a.workload, max(alg_launches, 1))
                                 if (world == 1 and not a.batch and not a.T and not a.chunk) else (None, None))
         mean = out["mean"].cpu().numpy()
@@ -371,7 +381,13 @@ def main():
             "metric": "MCD-samples/sec (T x images/s) + ECE, ResNet-18 multi-exit T=100" if a.workload == "resnet18_me"
                       else f"MCD-samples/sec (T x images/s) + ECE, {a.workload} T={T}",
             "value": round(value, 1), "unit": "MCD-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            # interval between consecutive step completions (HIP events on the steps' own streams), rank 0: median / min / max, and the rate
+            # the median implies (the first intervals of a short run sit on the clock ramp: SURVEY §8.4 asks for the median)
+            "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(step_ms[0], 3) if step_ms else None,
+            "ms_per_step_max": round(step_ms[-1], 3) if step_ms else None,
+            "value_at_median": round(B * T / (median_ms * 1e-3), 1) if median_ms > 0 else None,
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
@@ -379,6 +395,7 @@ def main():
                        "sharding": (f"T over {world} rank(s)" if share[0] == "samples" else f"images over {world} ranks (T < ranks)") +
                                    ", one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
+            "ece_note": "synthetic weights on uniform synthetic labels: plumbing (equal to the CPU oracle's at equal T), not calibration",
             "tflops_executed": round(eng.flops_per_batch(B, T) * a.steps / dt / 1e12, 2),
             "tflops_naive_equiv": round(2.0 * (eng.prefix_macs + eng.suffix_macs) * samples / dt / 1e12, 2),
             "roofline": None,
@@ -410,7 +427,7 @@ def main():
                 "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": d["hbm_frac"] if hbm_bound else d["frac"],
                 "traffic": None if dom_traffic is None else round(dom_traffic),
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                "traffic_unit": "fabric bytes per launch = L2 misses, Infinity-Cache hits included (PMC FETCH_SIZE x2 + WRITE_SIZE): an upper bound of the HBM bytes", "traffic_source": traffic_src,
                 "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
                 "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                 "launches": d["launches"], "avg_launch_ms": d["avg_launch_ms"],

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BMI_VERSION 300
+#define BMI_VERSION 400
 
 #define BMI_OK 0
 #define BMI_ERR_INVALID (-22)      /* EINVAL: bad descriptor / argument            */
@@ -123,6 +123,11 @@ typedef struct bmi_op_desc {
 /* element type of the 16-bit activations and conv weights of an engine */
 #define BMI_DTYPE_F16 0  /* IEEE half: v_mfma_f32_*_f16 (default; meets the 1e-3 parity bar)            */
 #define BMI_DTYPE_BF16 1 /* bfloat16:  v_mfma_f32_16x16x32_bf16 (8 mantissa bits: measured error in DESIGN.md) */
+#define BMI_DTYPE_F32 2  /* the EXACT engine, for parity: fp32 activations in the workspace, fp32 conv weights (`weight`
+                            fp32 [Cout][k][k][Cin]), every conv on v_mfma_f32_32x32x2_f32 in one generic per-tap kernel
+                            (csrc/conv_exact.hip) — the arithmetic of the reference's fp32 CPU path, 1/16 of the fp16 MFMA
+                            rate.  Graph features that exist for speed only are not built (in2 is BMI_ERR_UNSUPPORTED; no
+                            pair / pooling / lazy-site fusion); bmi_forward_mcd_exit is BMI_ERR_UNSUPPORTED.              */
 
 typedef struct bmi_model_desc {
     int32_t n_tensors;
@@ -131,7 +136,7 @@ typedef struct bmi_model_desc {
     const bmi_op_desc* ops;
     int32_t n_exits;
     int32_t out_dim;
-    int32_t dtype; /* BMI_DTYPE_*: conv weights (`weight`, `weight2`) must be in this type */
+    int32_t dtype; /* BMI_DTYPE_*: conv weights (`weight`, `weight2`) must be in this type (F32: fp32) */
 } bmi_model_desc;
 
 /* per-op-kind device time, filled by bmi_profile_read */
@@ -145,8 +150,8 @@ const char* bmi_error_string(int code);
  * bit: "mfma_shape_*" and "epilogue_lite" leave every bit alone; "conv_pw", "conv_s2", "conv_stream" and "conv_wide" move a
  * conv to a kernel family that sums its K dimension in another order, "splitk" adds nine fp32 partial sums separately,
  * "dense_exact" swaps the split-fp16 product for the exact-f32 MFMA.  (Kernel selection itself looks at the conv's shape
- * and the engine's planned batch x chunk only, so two runs of one engine — whole, sharded, partial chunks — agree bit for
- * bit up to the order in which float64 moment sums of more than 64 samples meet.)  Returns BMI_ERR_INVALID for an unknown
+ * and the engine's planned batch x chunk only, so two runs of one engine — whole, t-sharded, image-sharded, partial chunks —
+ * agree bit for bit: the float64 moment sums of an image's 32-sample groups are joined in group order.)  Returns BMI_ERR_INVALID for an unknown
  * name / value.  Names:
  *   "mfma_shape_patch", "mfma_shape_wide"   16 | 32: MFMA instruction shape of conv3x3_patch / conv_igemm_wide
  *                                           (v_mfma_f32_16x16x32_f16 | v_mfma_f32_32x32x16_f16); 0 = built-in default
@@ -180,7 +185,11 @@ const char* bmi_error_string(int code);
  *   "wide_persist_min_x10"                  10..1000: conv_igemm_wide runs persistent (one workgroup per CU walking the tiles)
  *                                           when tiles * 10 > value * CUs
  *   "unit_entry_dtype"                      BMI_DTYPE_*: how the single-kernel entry points below (unit tests) interpret
- *                                           their 16-bit buffers; engines carry their own dtype in bmi_model_desc
+ *                                           their 16-bit buffers; engines carry their own dtype in bmi_model_desc.  BMI_DTYPE_F32:
+ *                                           bmi_conv_igemm_fwd / bmi_stem_conv_fwd (output) / bmi_mask_apply / bmi_maxpool2 take fp32
+ *                                           buffers (and fp32 conv weights) and run the exact engine's kernels
+ *   "ws_no_reuse"                           0 | 1, read by bmi_plan: every suffix tensor keeps its own workspace range (per-layer
+ *                                           traces through bmi_tensor_info; the workspace grows to the sum of the activations)
  * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT). */
 int bmi_set_option(const char* name, int32_t value);
 
@@ -198,6 +207,15 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
  * stochastic suffix; and the op counts after the split. */
 int bmi_query(bmi_handle h, int64_t* prefix_macs, int64_t* suffix_macs, int32_t* n_prefix_ops, int32_t* n_suffix_ops);
 
+/* Traces (tools/layer_trace.py): where tensor `id` (1 .. n_tensors-1 of the descriptor) of a PLANNED engine lives in the caller's
+ * workspace: byte offset, bytes per element (2: the engine's 16-bit type, 4: fp32), whether it holds one image set per
+ * Monte-Carlo sample of the chunk ([chunk*B][h][w][c], image = t_local*B + b) or the once-per-batch B images, and its extent.
+ * Suffix tensors share workspace ranges by live range unless the engine was planned under bmi_set_option("ws_no_reuse", 1);
+ * a fused launch may leave a tensor unwritten (set "mask_lazy" = 0, "conv_pool" = 0 for a full trace).  Keep-bit tensors and
+ * tensors nothing reads are BMI_ERR_UNSUPPORTED.  No reference counterpart (a forward hook on an nn.Module). */
+int bmi_tensor_info(bmi_handle h, int32_t id, int64_t* offset, int32_t* elem_bytes, int32_t* per_sample, int32_t* th, int32_t* tw,
+                    int32_t* tc);
+
 /* Runs samples t_begin .. t_begin+t_count-1 for one batch and ADDS, per exit e, image b and
  * class c:  S1 += softmax_p, S2 += softmax_p^2, SL += logit   (float64 [E][B][C]). */
 int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_begin, int32_t t_count,
@@ -207,10 +225,13 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
 /* The same for images image_offset .. image_offset+batch-1 of a LARGER batch: `x_nchw` and S1/S2/SL hold this share only
  * ([batch] rows), while every dropout mask is drawn at the image's index in the whole batch — so the shares of a batch
  * partitioned by IMAGES over several GPUs (the fallback of SURVEY.md §8.5 when there are fewer Monte-Carlo samples than
- * ranks: every rank runs all T samples on its images, nobody idles) reproduce the rows of the one-GPU run.  A site's
- * index offset must be a whole number of Philox calls (image_offset x elements per image % 64 == 0: true for every tensor
- * of the CNN families here), else BMI_ERR_UNSUPPORTED.  Masksembles masks do not depend on the image.  No reference
- * counterpart (single device: SA/train/train_utils.py:10-11). */
+ * ranks: every rank runs all T samples on its images, nobody idles) reproduce the rows of the one-GPU run bit for bit when
+ * the engine is planned for the whole batch (kernel selection looks at the planned batch, not at the call's).
+ * A site's index offset must be a whole number of Philox calls (image_offset x elements per image % 64 == 0: true for every
+ * tensor of the CNN families here), else BMI_ERR_UNSUPPORTED — bmi_image_offset_ok (host-only) tells beforehand, so that the
+ * ranks of a group can refuse a partition TOGETHER instead of one rank failing while the others wait in the all-reduce.
+ * Masksembles masks do not depend on the image.  No reference counterpart (single device: SA/train/train_utils.py:10-11). */
+int bmi_image_offset_ok(bmi_handle h, int32_t image_offset);
 int bmi_forward_mcd_images(bmi_handle h, const float* x_nchw, int32_t batch, int32_t image_offset, int32_t t_begin,
                            int32_t t_count, uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL,
                            void* workspace, size_t workspace_bytes, bmi_stream stream);

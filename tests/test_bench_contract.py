@@ -124,21 +124,71 @@ def test_fewer_samples_than_ranks_partitions_the_images(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][0])
         assert ("images over 2 ranks" in d["config"]["sharding"]) == (n == 2)
-    np.testing.assert_allclose(np.load(f2), np.load(f1), rtol=0, atol=2e-3)
+    # an image share runs the kernels of the whole batch (selection looks at the engine's planned batch): the rows are the one-rank
+    # run's, only the all-reduce (adding zeros) touches them
+    np.testing.assert_allclose(np.load(f2), np.load(f1), rtol=0, atol=1e-12)
 
 
-def test_bench_self_launch_starts_n_ranks_without_a_launcher():
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--graph"]], ids=["eager", "graph"])
+def test_two_rank_bench_over_rccl(tmp_path, extra):
+    """Two ranks on two GPUs over RCCL (backend "nccl"), as the driver's scaling run launches them — only where the box has two
+    GPUs (the 1-GPU boxes of the test pool skip; the gloo / share-GPU tests above cover the same code path there).  T = 8 over
+    two ranks, eager and with each rank's share as a hipGraph replay + eager all-reduce; equals the one-rank run to 1e-12."""
+    import numpy as np
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    common = ["--steps", "2", "--warmup", "1", "--T", "8", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    f1, f2 = str(tmp_path / "m1.npy"), str(tmp_path / "m2.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--dump-mean", f1],
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl", *common, *extra, "--dump-mean", f2],
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    np.testing.assert_allclose(np.load(f2), np.load(f1), rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_graphed_share_on_the_sharded_path(tmp_path):
+    """--graph with more than one rank: each rank's share (accumulate only) is ONE hipGraph replay, the all-reduce and finalize follow
+    eagerly.  Config 4's shape — T = world: one sample of the whole batch per rank — in dry run on one GPU (gloo); equal to the eager
+    two-rank run and to the one-rank run to 1e-12."""
+    import numpy as np
+    common = ["--workload", "resnet18_masksembles", "--T", "2", "--batch", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    fs = []
+    for n, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu"]), (2, ["--backend", "gloo", "--share-gpu", "--graph"])):
+        f = str(tmp_path / f"m{len(fs)}.npy")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *extra, *common, "--dump-mean", f],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][0])
+        assert d["config"]["hipgraph"] == ("--graph" in extra)
+        fs.append(np.load(f))
+    np.testing.assert_allclose(fs[1], fs[0], rtol=0, atol=1e-12)
+    assert np.array_equal(fs[2], fs[1])
+
+
+def test_bench_self_launch_starts_n_ranks_without_a_launcher(tmp_path):
     """CPU box: the launch mechanics alone.  `bench.py --gpus 2` with no WORLD_SIZE in the environment must start two rank
-    processes (each then refuses to run without a GPU: the HIP path has no CPU fallback) and pass their failure on."""
+    processes (each then refuses to run without a GPU: the HIP path has no CPU fallback) and pass their failure on.
+    Each rank leaves a marker file as the first thing it does (BENCH_RANK_MARK_DIR): torchrun's agent kills the surviving rank as
+    soon as the first one has failed, so how many of them get to PRINT the refusal is a race (round-3 review: 1 of 4 runs)."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("covered by test_bench_launches_its_own_ranks on a GPU box")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_RANK_MARK_DIR"] = str(tmp_path)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "1",
                         "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     out = r.stdout + r.stderr
     assert r.returncode != 0
-    assert out.count("bench.py needs an MI355X") == 2, out[-3000:]
+    assert out.count("bench.py needs an MI355X") >= 1, out[-3000:]
+    assert sorted(os.listdir(tmp_path)) == ["rank0", "rank1"]
 
 
 def test_bench_rejects_a_launcher_whose_world_size_differs():

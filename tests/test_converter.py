@@ -172,7 +172,11 @@ def test_gpu_converted_resnet18base_against_reference_golden():
     assert zero.any() and np.array_equal(passes == 0, zero)
     ref_probs = torch.softmax(torch.from_numpy(ref), -1).numpy().astype(np.float64)
     r = m.engine(x.device, max_batch=B).predict(x, T, seed=seed)
-    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref_probs.mean(0), rtol=0, atol=2e-3)
+    # north_star's bar on mean AND variance (measured round 4: 5.4e-5 / 1.4e-4; the exact-engine twin of this test,
+    # tests/test_exact_engine.py::test_exact_engine_converter_goldens_mean_and_var_within_1e3, sits at 3e-7 / 4e-7 and its per-pass
+    # logits at 2e-4: the 6e-2 above is fp16 rounding through 20 layers, not a layer misbehaving — profiles/experiments/r4_layer_trace_*.txt)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref_probs.mean(0), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(r["var"].cpu().numpy(), ref_probs.var(0), rtol=0, atol=1e-3)
     m.eval()
     m.mc_pass = 0
     mean_logits = m(x)                                          # eval mode: sum(pred) / len(pred) over nSamples, per exit
@@ -227,4 +231,6 @@ def test_gpu_converted_vgg19_against_reference_golden():
     assert zero.any() and np.array_equal(passes == 0, zero)
     ref_probs = torch.softmax(torch.from_numpy(ref), -1).numpy().astype(np.float64)
     r = m.engine(x.device, max_batch=B).predict(x, T, seed=seed)
-    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref_probs.mean(0), rtol=0, atol=2e-2)    # (peaky softmax of logits ~80)
+    # north_star's bar on mean AND variance (measured round 4: 1.2e-4 / 1.5e-4 with logits up to 83; exact-engine twin: 3.5e-6 / 2.8e-6)
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), ref_probs.mean(0), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(r["var"].cpu().numpy(), ref_probs.var(0), rtol=0, atol=1e-3)

@@ -139,6 +139,32 @@ def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
         assert ms_lazy < 0.7 * ms_plain                  #  consumers: nothing takes keep bits there and the op runs as before)
 
 
+def test_lazy_first_site_with_p_zero_keeps_everything():
+    """dropout_p = 0.0: every site resolves to 2 bits per element with threshold 0 — keep all.  The 2-bit fast paths (mask_apply_lb1,
+    mask_bits_call<1>) test their fields with bit tricks that only covered thresholds 1..3 and kept HALF the elements (round-3 advisor
+    finding); the lazy and the materialised path agreed with each other, not with the conv-epilogue sites or the oracle.  Now both equal
+    the oracle, and the T-sample variance of a p = 0 model is exactly 0."""
+    from bayesnn_fpga_amd import _lib
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.0, out_dim=10)
+    Bs, T, seed = 32, 3, 7
+    model, o = build_seeded(ResNet18MCEarlyExit, kw), build_seeded(oresnet.ResNet18MCEarlyExit, kw)
+    synthetic_weights_(model, 0)
+    synthetic_weights_(o, 0)
+    x = synthetic_images(Bs, seed=1234)
+    ref = mcd.mcd_predict(o, x, T, seed)
+    eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=Bs)
+    lazy = eng.predict(x.to(DEV), T, seed=seed)
+    _lib.set_option("mask_lazy", 0)
+    try:
+        plain = eng.predict(x.to(DEV), T, seed=seed)
+    finally:
+        _lib.set_option("mask_lazy", 1)
+    for r in (lazy, plain):
+        assert float(np.abs(r["mean"].cpu().numpy() - ref["mean"]).max()) <= TOL
+        assert float(r["var"].max()) <= 1e-12 and float(ref["var"].max()) <= 1e-12
+    assert torch.equal(lazy["mean"], plain["mean"])
+
+
 def test_lazy_first_site_resnet50():
     """ResNet-50 multi-exit: the first site (256 channels, 32x32) is read by a 3x3 stride-2 conv that runs in conv_igemm (keep bits applied
     while staging), a 1x1 conv and a 1x1 stride-2 conv (conv1x1_stream: elements cleared in LDS).  Lazy vs materialised: the same

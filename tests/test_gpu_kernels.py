@@ -175,6 +175,32 @@ def test_mask_apply_expands_and_masks(kind):
     assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)        # one rounding, bit-exact
 
 
+@pytest.mark.parametrize("p", [0.0, 0.25, 0.5, 0.75, 1.0])
+def test_two_bit_fast_paths_cover_every_threshold(p):
+    """2 bits per element (p * 4 an integer): thresholds 0..3 and drop-all.  The fast kernels — mask_apply_lb1 (whole 4096-element
+    super-blocks) and mask_bits_call<1> — must equal the oracle's mask for each, p = 0 (threshold 0: keep all) included."""
+    lib = _lib.lib()
+    B, tc, H, Cc, t0, seed = 4, 3, 8, 64, 1, 5
+    x = torch.randn(B, H, H, Cc, generator=_gen(6)).to(torch.float16).to(DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=2, p=p)
+    keep = []
+    s = gh.site_struct(site, keep)
+    out = torch.empty(B * tc, H, H, Cc, dtype=torch.float16, device=DEV)
+    _lib.check(lib.bmi_mask_apply(gh.ptr(x), gh.ptr(out), B * tc, B, H * H, Cc, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_mask_apply")
+    bits = torch.zeros(B * tc * H * H * Cc // 8, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.bmi_mask_bits(gh.ptr(bits), B * tc, H * H, Cc, C.byref(s), B, t0, seed, gh.stream()), "bmi_mask_bits")
+    torch.cuda.synchronize()
+    mult = gh.folded_site_mask(site, B, Cc, H, H, tc, t0, seed)
+    ref = (x.float().cpu().permute(0, 3, 1, 2).repeat(tc, 1, 1, 1) * mult).to(torch.float16).float()
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), ref)
+    want = np.concatenate([philox.keep_bits(B * H * H * Cc, seed, 2, t0 + tl, p) for tl in range(tc)])
+    assert np.array_equal(np.unpackbits(bits.cpu().numpy(), bitorder="little").astype(bool), want)
+    if p == 0.0:
+        assert want.all()
+    if p == 1.0:
+        assert not want.any()
+
+
 def _head_ref(x_nhwk, in_mod, B, tc, t0, seed, w, b, out_dim, site, site_logits, cnt0=0):
     """float64 reference of one exit head over tc samples: returns (S1, S2, SL) [B, out_dim] and per-sample logits."""
     N = B * tc

@@ -128,6 +128,11 @@ class _OracleEngine:
     def __init__(self, model, x_full, seed):
         self.fn, self.x_full = _oracle_accumulate(model, x_full, seed), x_full
 
+    def image_offset_ok(self, image_offset):
+        return self.bad_offset is None or image_offset != self.bad_offset
+
+    bad_offset = None
+
     def accumulate(self, x, S, t_begin, t_count, seed=0, cnt0=0, image_offset=0):
         assert torch.equal(x, self.x_full[image_offset:image_offset + x.shape[0]])
         full = torch.zeros(3, S.shape[1], self.x_full.shape[0], S.shape[3], dtype=torch.float64)
@@ -168,3 +173,16 @@ def test_two_rank_gloo_image_partition_equals_single_rank(tmp_path):
     accumulate_partitioned(_OracleEngine(model, x, 42), x, S1, T, seed=42)      # no process group: one rank, all samples
     np.testing.assert_allclose(S2, S1.numpy(), rtol=1e-12, atol=1e-12)
     assert np.allclose(S2[0].sum(-1), 1.0, atol=1e-6)
+
+
+def test_image_partition_is_refused_by_every_rank_together():
+    """A partition one rank's kernels cannot take (a share that does not start on a whole Philox call: bmi_image_offset_ok) is a
+    ValueError on EVERY rank before anyone launches — not one rank raising while the others wait in the all-reduce (round-3 advisor).
+    Single process: the check is host-only and looks at all ranks' offsets, so rank 0 alone already sees rank 1's problem."""
+    from bayesnn_fpga_amd.sharding import accumulate_partitioned as ap
+    model = _build(KW_MC)
+    x = torch.zeros(3, 3, 32, 32)
+    eng = _OracleEngine(model, x, 42)
+    eng.bad_offset = 0                     # world = 1: the only share starts at image 0
+    with pytest.raises(ValueError, match="whole Philox call"):
+        ap(eng, x, torch.zeros(3, 4, 3, 10, dtype=torch.float64), 0, seed=42)     # T = 0 < world = 1 -> image partition
