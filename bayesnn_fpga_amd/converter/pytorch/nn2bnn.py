@@ -23,8 +23,11 @@ What the engine accepts after conversion:
   AdaptiveAvgPool2d(1) / AvgPool2d over the whole map, Flatten, Linear (+ReLU), Dropout (identity in eval).
 
 The mask of a wrapped Conv2d lands BEFORE its BatchNorm (an "inner" site of the C ABI, include/bayesnn_fpga_amd.h), the last
-Linear's mask multiplies the logits.  Any other hand-written ``forward`` raises TypeError (compiling arbitrary Python needs a
-tracer, which is outside the path).
+Linear's mask multiplies the logits.
+* any other module whose hand-written ``forward`` ``torch.fx`` can trace and that is made of what the engine has — conv [+ BatchNorm]
+  [+ residual add] [+ ReLU], MaxPool2d(2), a global average pool + flatten + Linear per output, hidden Linears — through
+  ``fx_frontend.build_graph_fx`` (round 4; pinned case: the reference's ``_convert_model`` on a small hand-written residual net,
+  tests/golden/converter_custom.npz).  Anything else raises TypeError naming the node.
 """
 import torch
 from torch import nn
@@ -70,6 +73,12 @@ class MCDropout(EngineModelMixin, nn.Module):
         self.resnet = fam in ("resnet", "vgg")       # one of the package's own mirrors: its forward returns a LIST of logits
         self.multi_exit = bool(self.resnet and getattr(self.model, "multi_exit", True))
         self.n_exits = (4 if fam == "resnet" else 5) if self.multi_exit else 1
+        self.traced = not self.resnet and not isinstance(self.model, nn.Sequential)
+        if self.traced:
+            # a hand-written forward: compiled through torch.fx (fx_frontend.py); it may return one logits tensor or a list of them
+            from .fx_frontend import traced_outputs
+            self.n_exits, self.resnet = traced_outputs(self.model)
+            self.multi_exit = self.n_exits > 1
         linears = [m for m in self.model.modules() if isinstance(m, nn.Linear)]
         if not linears:
             raise TypeError("the engine needs a model that ends in nn.Linear")
@@ -104,7 +113,10 @@ class MCDropout(EngineModelMixin, nn.Module):
             from ...models.vgg19.vgg19 import build_vgg_graph
             return build_vgg_graph(self.model, g)
         if not isinstance(self.model, nn.Sequential):
-            raise TypeError("the engine compiles converted nn.Sequential CNNs; got " + type(self.model).__name__)
+            from .fx_frontend import build_graph_fx
+            n, _ = build_graph_fx(self.model, g)
+            assert n == self.n_exits
+            return
         mods = _leaves(self.model)
         x = g.tensor(32, 32, 3)
         first, flat, relu_last, i = True, False, False, 0

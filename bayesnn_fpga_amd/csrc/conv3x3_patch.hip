@@ -254,11 +254,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 const int row = map_image<IMAP>(a, n);
                 const int nm = row % a.in2_mod;
                 const size_t pix = ((size_t)(y0 + oy) * a.stride2) * a.W2 + (size_t)(x0 + ox) * a.stride2;
-                const _Float16* src = n < a.N ? a.in2 + (((size_t)nm * a.H2) * a.W2 + pix) * a.Cin2 + c2 * 64 + c * 8
-                                              : (const _Float16*)g_zero_page;
+                // element offset inside the image: NHWC, or the lazy site's planar layout (kernels.h lazy_planar_off; only with keep bits)
+                const size_t eoff = (MS == 16 && a.in2_bits && a.lazy_planar)
+                                        ? (size_t)lazy_planar_off(c2 * 64 + c * 8, (y0 + oy) * a.stride2, (x0 + ox) * a.stride2, a.H2 * a.W2, a.W2)
+                                        : pix * a.Cin2 + c2 * 64 + c * 8;
+                const size_t img_e = (size_t)a.H2 * a.W2 * a.Cin2;
+                const _Float16* src = n < a.N ? a.in2 + (size_t)nm * img_e + eoff : (const _Float16*)g_zero_page;
                 GLDS16(src, patch + (i * 256 + wave * 64) * 16);
                 kb[i] = 0xff;
-                if (MS == 16 && a.in2_bits && n < a.N) kb[i] = a.in2_bits[(((size_t)row * a.H2) * a.W2 + pix) * (a.Cin2 >> 3) + c2 * 8 + c];
+                if (MS == 16 && a.in2_bits && n < a.N) kb[i] = a.in2_bits[((size_t)row * img_e + eoff) >> 3];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -332,6 +336,7 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const int ms = (a.imap || a.bf16) ? 16 : opt_mfma_shape_patch();   // bf16 / dynamic exit: the 16x16x32 shape only
     if (a.in2_bits && (ms != 16 || TW != 16)) return BMI_ERR_UNSUPPORTED;   // keep bits on the shortcut's input: the 16x16-map, 16x16x32 form
+    if (a.lazy_planar && (!a.in2_bits || (a.W2 & 1) || a.Cin2 % 32 != 0)) return BMI_ERR_UNSUPPORTED;
     const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, ms) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
     const dim3 grid((unsigned)tiles), block(256);
 #define PATCH_LAUNCH(EPI_, MS_, BF_, IMAP_) \

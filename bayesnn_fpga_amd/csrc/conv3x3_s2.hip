@@ -327,7 +327,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         const int y = rm / Q, x = rm - y * Q;
         const int iy = 2 * y - pyl, ix = 2 * x - pxl;
         const bool ok = lc < IMGS * RQ && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const unsigned inoff = (unsigned)((iy * a.W + ix) * a.Cin + ((pos ^ ((y & 1) << 1)) << 3));
+        // (masked input in the lazy site's planar layout, kernels.h lazy_planar_off: a plane row's cells are contiguous 64-byte runs)
+        const unsigned inoff = (MSK && a.lazy_planar) ? (unsigned)((iy * a.W + (ix & 1) * (a.W >> 1) + (ix >> 1)) * 32 + ((pos ^ ((y & 1) << 1)) << 3))
+                                                      : (unsigned)((iy * a.W + ix) * a.Cin + ((pos ^ ((y & 1) << 1)) << 3));
         pre[k] = !ok ? OOB : (IMAP ? ((unsigned)img << 24) | inoff : 2u * ((unsigned)img * HWC + inoff));
     }
     // IMAP: tensor row of each image of a tile (-1 beyond N), two tables: the epilogue of tile i reads table i & 1 while the
@@ -338,6 +340,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     // one descriptor per 128-row half of the channel tile (a pair's second conv has its own weight tensor)
     const unsigned woff = 2u * ((unsigned)(tid >> 2) * Ktot + (((tid & 3) ^ (((tid >> 4) & 1) << 1)) << 3));
     const unsigned wbytes = 2u * 128u * Ktot;
+    // element offset of channel chunk C0 (a multiple of 32) = C0 * cmul: 1 in NHWC, H * W in the planar layout (one 32-channel plane per chunk)
+    const unsigned cmul = (MSK && a.lazy_planar) ? (unsigned)(a.H * a.W) : 1u;
     __amdgpu_buffer_rsrc_t rs_w0, rs_w1, rs_in, rs_bits;
 
     int ch0 = 0, n0 = 0;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             const int row_ = row_tabs[tsel * 16 + ((pre[K] >> 24) & 15)];                                    \
             o_ = (pre[K] == OOB || row_ < 0) ? OOB : 2u * ((unsigned)row_ * HWC + (pre[K] & 0xffffffu));     \
         }                                                                                                    \
-        if (!S2_ABL_NOPATCH) BLDS16(rs_in, o_, __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0)), pbuf + ((K) * 512 + wave * 64) * 16); \
+        if (!S2_ABL_NOPATCH) BLDS16(rs_in, o_, __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0) * cmul), pbuf + ((K) * 512 + wave * 64) * 16); \
         if constexpr (MSK && !S2_ABL_NOBITS && !S2_BITS_GROUP) {                                             \
             /* the cell's 32 keep bits of this chunk (the dword that holds this piece's byte); beyond the descriptor: zeros */ \
             /* (derived from pre[K] at every issue: as loop invariants the ten offsets are spilled, and a scratch reload in */ \
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             unsigned bo_ = pre[K];                                                                           \
             asm volatile("" : "+v"(bo_));                                                                    \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bits, (__attribute__((address_space(3))) void*)(smem + G::BITS_OFF + G::slot(K) * 2048 + wave * 256), \
-                                                     4, (bo_ >> 4) & ~3u, __builtin_amdgcn_readfirstlane((unsigned)(C0) >> 3), 0, 0); \
+                                                     4, (bo_ >> 4) & ~3u, __builtin_amdgcn_readfirstlane(((unsigned)(C0) * cmul) >> 3), 0, 0); \
         }                                                                                                    \
     }
     // Grouped keep-bit DMA: lane (cell, pos) fetches the dword of piece PA / PB / PC / PD (pos 0..3; -1: none) of ITS cell row; CB = channel
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         unsigned bo_ = p4_ == 0 ? pre[PA] : (p4_ == 1 ? pre[PB] : ((PC) >= 0 ? (p4_ == 2 ? pre[(PC) < 0 ? 0 : (PC)] : pre[(PD) < 0 ? 0 : (PD)]) : OOB)); \
         bo_ = ((bo_ >> 4) & ~3u) + (p4_ == 0 ? (unsigned)(ADD0) : 0u);                                       \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bits, (__attribute__((address_space(3))) void*)(smem + G::BITS_OFF + (GRP) * 2048 + wave * 256), \
-                                                 4, bo_, __builtin_amdgcn_readfirstlane((unsigned)(CB) >> 3), 0, 0); \
+                                                 4, bo_, __builtin_amdgcn_readfirstlane(((unsigned)(CB) * cmul) >> 3), 0, 0); \
     }
     // The thread that issued piece K clears the dropped elements of its 16 bytes: byte (logical chunk) of the slot's dword -> four
     // dword masks.  Own DMA only: the thread's counted vmcnt wait is all it needs; the barriers of the step publish the result.
@@ -784,6 +788,7 @@ int launch_conv3x3_s2(const ConvArgs& a_in, hipStream_t s) {
     if (!opt_conv_s2() || a_in.in2 || a_in.partial || !conv_epilogue_is_plain(a_in)) return BMI_ERR_UNSUPPORTED;
     // keep bits on the input (ConvArgs::in_bits): the 32x32 -> 16x16 class (one image per tile), a deterministic, pre-scaled input
     if (a_in.in_bits && (a_in.Ho != 16 || a_in.imap || a_in.out_mul != 1.f || a_in.Cin % 32 != 0)) return BMI_ERR_UNSUPPORTED;
+    if (a_in.lazy_planar && (!a_in.in_bits || (a_in.W & 1))) return BMI_ERR_UNSUPPORTED;
     if (!conv_takes_s2_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout, a_in.H, a_in.W, a_in.Ho, a_in.Wo)) return BMI_ERR_UNSUPPORTED;
     ConvArgs a = a_in;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;

@@ -31,7 +31,10 @@ struct TensorInfo {
     // Lazy site (the output of an elementwise MASK op on a deterministic tensor, see bmi_create): tensors that hold the keep bits of
     // the folded batch and the deterministic input times 1/(1-p) (fp16), or -1
     int lazy_bits = -1, lazy_scaled = -1;
+    bool lazy_planar = false;   // every reader is a stride-2 consumer (conv3x3_s2 on 32x32 maps / conv3x3_patch's fused shortcut) and the site draws 2 bits
+                                // per element: bits + scaled copy are stored in the planar layout (kernels.h lazy_planar_off)
     bool lazy_pending = false;  // (run time) bits + scaled copy are written, the masked tensor itself is not (yet)
+    bool lazy_planar_now = false;   // (run time) ... in the planar layout
     EltArgs lazy_call;          // (run time) the mask launch that materialises it on demand
     int first = -1, last = -1;  // suffix op indices (stochastic tensors only)
     size_t offset = 0;          // byte offset in the workspace
@@ -179,6 +182,7 @@ int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_mask_lazy() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
 int& opt_ws_no_reuse() { static int v = 0; return v; }
+int& opt_lazy_planar() { static int v = 1; return v; }
 int& opt_xcd_split() {
     static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
     return v;
@@ -201,6 +205,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "unit_entry_dtype") == 0) {
         if (value != BMI_DTYPE_F16 && value != BMI_DTYPE_BF16 && value != BMI_DTYPE_F32) return BMI_ERR_INVALID;
         opt_unit_dtype() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "lazy_planar") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_lazy_planar() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "ws_no_reuse") == 0) {   // read by bmi_plan
@@ -604,20 +613,21 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         //   conv_igemm anyway (ResNet-50's first site: 256 -> 128 k3s2, 256 -> 128 k1, 256 -> 512 k1s2).  A 3x3 stride-1 reader would
         //   lose its patch kernel to the per-tap one: not lazy.
         int readers = 0;
-        bool all = true;
+        bool all = true, all_s2 = true;
         for (const OpInfo& c : e->suffix) {
             const bool reads = c.d.in == md.out || (c.d.kind == BMI_OP_CONV && (c.d.residual == md.out || c.d.in2 == md.out)) || c.bits_tensor == md.out;
             if (!reads || &c == &e->suffix[mi]) continue;
             ++readers;
             bool ok = false;
             if (c.d.kind == BMI_OP_CONV && c.d.residual != md.out && c.bits_tensor < 0) {
-                if (c.d.in2 == md.out) ok = c.d.in != md.out && c.ho == 16 && c.wo == 16;
+                if (c.d.in2 == md.out) { ok = c.d.in != md.out && c.ho == 16 && c.wo == 16; all_s2 = all_s2 && ti.h == 2 * c.ho && ti.w == 2 * c.wo; }
                 else if (c.d.in2 < 0) {
                     const bool s2 = ti.h == 32 && ti.w == 32 && c.d.residual < 0 && c.d.site.kind == BMI_SITE_NONE &&
                                     conv_takes_s2_kernel(c.d.ksize, c.d.stride, c.d.pad, ti.c, c.cout + (c.has_pair ? c.pair_cout : 0), ti.h, ti.w, c.ho, c.wo);
                     const bool igemm = !c.has_pair && ti.c % 64 == 0 && c.cout % 64 == 0 &&
                                        (c.d.ksize == 1 || (c.d.ksize == 3 && c.d.stride == 2));
                     ok = s2 || igemm;
+                    all_s2 = all_s2 && s2;
                 }
             }
             all = all && ok;
@@ -630,6 +640,8 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         e->tensors.push_back(tsc);
         e->tensors[md.out].lazy_bits = (int)e->tensors.size() - 2;
         e->tensors[md.out].lazy_scaled = (int)e->tensors.size() - 1;
+        e->tensors[md.out].lazy_planar = all_s2 && ti.c % 64 == 0 && ti.w >= 2 && (ti.w & (ti.w - 1)) == 0 && ((ti.h * ti.w) & (ti.h * ti.w - 1)) == 0 &&
+                                         bmi_site_log2_bits(md.site.p) == 1;
     }
     *out = e;
     return BMI_OK;
@@ -833,6 +845,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 m.in = (const _Float16*)(ws + e->tensors[tin.lazy_scaled].offset);
                 m.in_mod = B;
                 m.in_bits = (const uint8_t*)(ws + e->tensors[tin.lazy_bits].offset);
+                m.lazy_planar = tin.lazy_planar_now;
             };
             if (e->f32) {   // the exact engine: one generic kernel (a.in / a.wgt / a.res / a.out hold fp32)
                 prof.tag(-1, 0, 0);
@@ -908,6 +921,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                     m.in2 = (const _Float16*)(ws + e->tensors[t2.lazy_scaled].offset);
                     m.in2_mod = B;
                     m.in2_bits = (const uint8_t*)(ws + e->tensors[t2.lazy_bits].offset);
+                    m.lazy_planar = t2.lazy_planar_now;
                     rcl = launch_conv3x3_patch(m, s);
                     prof.tag(BMI_CONV_FAMILY_PATCH, flops, bytes - lazy_saving(d.in2));
                 }
@@ -964,10 +978,12 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             TensorInfo& to = e->tensors[d.out];
             to.lazy_pending = false;
             if (to.lazy_bits >= 0 && opt_mask_lazy() && !tin.stoch && N % B == 0) {
-                const int rcb = launch_mask_bits((uint8_t*)(ws + e->tensors[to.lazy_bits].offset), N, tin.h * tin.w, tin.c, a.site, B, t0, s);
+                const bool planar = to.lazy_planar && opt_lazy_planar();
+                to.lazy_planar_now = planar;
+                const int rcb = launch_mask_bits((uint8_t*)(ws + e->tensors[to.lazy_bits].offset), N, tin.h * tin.w, tin.c, a.site, B, t0, s, planar ? tin.w : 0);
                 if (rcb == BMI_OK) {
                     const int rcs = launch_scale_copy(a.in, (_Float16*)(ws + e->tensors[to.lazy_scaled].offset), (long)B * tin.h * tin.w * tin.c,
-                                                      a.site.scale, e->bf16, s);
+                                                      a.site.scale, e->bf16, s, planar ? tin.h * tin.w : 0, planar ? tin.w : 0, planar ? tin.c : 0);
                     if (rcs != BMI_OK) return rcs;
                     to.lazy_call = a;
                     to.lazy_pending = true;

@@ -66,7 +66,21 @@ struct ConvArgs {
                              // pixels in LDS; in2 is then the deterministic tensor, pre-scaled by 1/(1-p) in fp16.  Or null.
                              // (Last: the kernels that never read it keep their argument layout — a field in the middle moved
                              // conv3x3_pw's 4x4 bf16 instantiations from 0 to 212 bytes of scratch.)
+    int lazy_planar;         // the operand that comes with keep bits (in + in_bits: conv3x3_s2; in2 + in2_bits: conv3x3_patch) and its bits are
+                             // stored in the lazy site's PLANAR layout (lazy_planar_off below) instead of NHWC
 };
+
+// Layout of a lazy site's scaled copy and keep bits when every reader is a stride-2 consumer (conv3x3_s2 on 32x32 maps, the fused 1x1
+// stride-2 shortcut of conv3x3_patch): element (c, y, x) of an image of hw = H x w pixels (w even, C % 32 == 0) sits at
+//     (c >> 5) * hw * 32 + (y * w + (x & 1) * (w >> 1) + (x >> 1)) * 32 + (c & 31)
+// — 32-channel planes, and inside a row the even columns in front of the odd ones.  A stride-2 reader takes every other column of a
+// row: its 64-byte cells (32 channels) are then CONTIGUOUS, whole 128-byte lines that nobody asks for twice; in NHWC a 32-channel
+// chunk is half of a pixel's line and the other half is requested nine K-steps later (round 3: 6.7 GB of fabric fetch per launch for
+// 33 MB of unique input).  The keep bits follow the same permutation (bit index = element index), so a piece's 16 bytes and its bits
+// byte stay at "activation byte offset / 16" of each other.
+__host__ __device__ inline long lazy_planar_off(int c, int y, int x, int hw, int w) {
+    return (long)(c >> 5) * hw * 32 + ((long)y * w + (x & 1) * (w >> 1) + (x >> 1)) * 32 + (c & 31);
+}
 
 struct EltArgs {  // MASK op
     int bf16;     // 16-bit tensors hold bfloat16 bits
@@ -127,8 +141,11 @@ int launch_expand_rows(const int* active, int bc, int batch, int tc, int* rows, 
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
                     double* var, double* lm, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
-int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s);
-int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, int bf16, hipStream_t s);   // out = round16(in * scale)
+// planar_w > 0: the bits in the lazy site's planar layout (rows of planar_w pixels; 2-bit sites, c % 64 == 0)
+int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s, int planar_w = 0);
+// out = round16(in * scale); planar_w > 0: images of planar_hw pixels x planar_c channels stored in the planar layout
+int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, int bf16, hipStream_t s, int planar_hw = 0, int planar_w = 0, int planar_c = 0);
+int& opt_lazy_planar();        // 1: lazy sites whose readers are all stride-2 consumers store their scaled copy + bits in the planar layout
 int launch_splitk_finish(const ConvArgs& a, hipStream_t s);   // after a split-K conv_igemm launch
 int launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);

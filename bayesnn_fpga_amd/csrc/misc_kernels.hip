@@ -268,10 +268,25 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(uint8_t* __restrict__ bi
 
 // out = x * scale rounded once to the activation type: what mask_apply stores for a kept element (lazy sites: the consumers AND
 // this copy of the B deterministic images with the keep bits).
+// PLANAR (w, c > 0): the copy is stored in the layout its stride-2 consumers DMA whole lines from (kernels.h, lazy_planar_off):
+// [image][c / 32][y][x & 1][x >> 1][c & 31] instead of NHWC.
 template <bool BF>
-__global__ __launch_bounds__(256) void scale_copy_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, long n8, float scale) {
+__global__ __launch_bounds__(256) void scale_copy_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, long n8, float scale,
+                                                         int hw, int w, int c) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        const half8 x = *(const half8*)(in + i * 8);
+        long src = i * 8;
+        if (w > 0) {                                     // thread i = 8 elements at OUTPUT offset 8 i: (image, plane, position, 8-channel group)
+            const long per_img = (long)hw * c;
+            const long img = (i * 8) / per_img;
+            const long rem = i * 8 - img * per_img;
+            const int plane = (int)(rem / ((long)hw * 32));
+            const long r2 = rem - (long)plane * hw * 32;
+            const int pos = (int)(r2 >> 5), c8 = (int)(r2 & 31);
+            const int y = pos / w, xx = pos - y * w, hwid = w >> 1;
+            const int x = xx < hwid ? 2 * xx : 2 * (xx - hwid) + 1;
+            src = img * per_img + ((long)y * w + x) * c + plane * 32 + c8;
+        }
+        const half8 x = *(const half8*)(in + src);
         half8 r;
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = a16_from_f32<BF>(a16_to_f32<BF>(x[e]) * scale);
@@ -279,12 +294,13 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const _Float16* __restr
     }
 }
 
-int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, int bf16, hipStream_t s) {
+int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, int bf16, hipStream_t s, int planar_hw, int planar_w, int planar_c) {
     if (n <= 0 || n % 8 != 0) return BMI_ERR_INVALID;
+    if (planar_w > 0 && (planar_c % 32 != 0 || (planar_w & 1) || planar_hw % planar_w != 0 || n % ((long)planar_hw * planar_c) != 0)) return BMI_ERR_INVALID;
     long blocks = (n / 8 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    if (bf16) hipLaunchKernelGGL(scale_copy_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n / 8, scale);
-    else hipLaunchKernelGGL(scale_copy_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n / 8, scale);
+    if (bf16) hipLaunchKernelGGL(scale_copy_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n / 8, scale, planar_hw, planar_w, planar_c);
+    else hipLaunchKernelGGL(scale_copy_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n / 8, scale, planar_hw, planar_w, planar_c);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -292,13 +308,33 @@ int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, in
 // The same bits from ONE Philox call per 128 >> LB elements (the kernel above draws a call per byte: 8 / 4 / 2 times the calls
 // at 2 / 4 / 8 bits per element — 0.70 ms for the 1.6 G elements of the headline's first site, as long as writing the masked
 // tensor itself): a thread takes a call and stores its 8 / 4 / 2 bytes of keep flags.
+// PLANAR (LB = 1, w > 0): the flags of element (c, y, x) of an image sit at bit lazy_planar_off(c, y, x) of the image's bits — the
+// permutation of the scaled copy (scale_copy_kernel): a call's 64 channels are two dwords, one per 32-channel plane.
 template <int LB>
-__global__ __launch_bounds__(256) void mask_bits_call_kernel(uint8_t* __restrict__ bits, long calls_per_sample, int tc, int t0, SiteArgs s) {
+__global__ __launch_bounds__(256) void mask_bits_call_kernel(uint8_t* __restrict__ bits, long calls_per_sample, int tc, int t0, SiteArgs s,
+                                                             int hw, int w, int c) {
     constexpr int EPC = 128 >> LB, GPC = EPC / 8;
     const long total = calls_per_sample * tc;
+    const long imgs_per_sample = (GPC == 8 && w > 0) ? calls_per_sample / ((long)hw * (c >> 6)) : 0;      // (planar) B
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long tl = i / calls_per_sample;
-        const uint64_t elem0 = (uint64_t)(i - tl * calls_per_sample) * EPC;
+        long tl = i / calls_per_sample;
+        uint64_t elem0 = (uint64_t)(i - tl * calls_per_sample) * EPC;
+        long pl_word = 0;                  // planar: dword index of this call's first 32-channel plane
+        if (GPC == 8 && w > 0) {
+            // planar: thread i = (sample, image, 64-channel group, POSITION in the plane): consecutive threads store consecutive dwords;
+            // the position's pixel is (y, x) with the even columns of a row in front of the odd ones.  hw and w are powers of two
+            // (launcher): shifts only — this kernel is bound by its integer instructions (Philox), 64-bit divisions showed (0.12 -> 0.21 ms)
+            const int lhw = __builtin_ctz((unsigned)hw), lw = __builtin_ctz((unsigned)w);
+            const unsigned cpp = (unsigned)c >> 6;
+            const unsigned r = (unsigned)(i - tl * calls_per_sample);       // (b * cpp + cgrp) * hw + pos inside the sample
+            const unsigned pos = r & (unsigned)(hw - 1), bc = r >> lhw;
+            const unsigned b = cpp == 1 ? bc : bc / cpp, cgrp = bc - b * cpp;
+            const unsigned y = pos >> lw, xx = pos & (unsigned)(w - 1), hwid = (unsigned)w >> 1;
+            const unsigned x = xx < hwid ? 2 * xx : 2 * (xx - hwid) + 1;
+            elem0 = ((((uint64_t)b << lhw) + (y << lw) + x) * cpp + cgrp) << 6;
+            const long img = tl * imgs_per_sample + b;                      // folded image index
+            pl_word = (img * (long)cpp * 2 + 2 * cgrp) * hw + pos;
+        }
         uint64_t out = 0;
         if (!s.drop_all) {
             const philox4 r = philox_site_call(s, elem0, (uint32_t)(t0 + tl));
@@ -322,14 +358,23 @@ __global__ __launch_bounds__(256) void mask_bits_call_kernel(uint8_t* __restrict
                 for (int q = 0; q < GPC; ++q) out |= (uint64_t)philox_keep8(r, (uint32_t)elem0 + 8u * q, LB, s.thresh) << (8 * q);
             }
         }
-        if constexpr (GPC == 8) *(uint64_t*)(bits + i * 8) = out;
+        if constexpr (GPC == 8) {
+            if (w > 0) {
+                ((uint32_t*)bits)[pl_word] = (uint32_t)out;
+                ((uint32_t*)bits)[pl_word + hw] = (uint32_t)(out >> 32);
+            } else {
+                *(uint64_t*)(bits + i * 8) = out;
+            }
+        }
         else if constexpr (GPC == 4) *(uint32_t*)(bits + i * 4) = (uint32_t)out;
         else *(uint16_t*)(bits + i * 2) = (uint16_t)out;
     }
 }
 
-int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s) {
+int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s, int planar_w) {
     if (c % 8 != 0 || site.kind != BMI_SITE_ELEMENTWISE) return BMI_ERR_UNSUPPORTED;
+    if (planar_w > 0 && (site.log2_bits != 1 || c % 64 != 0 || planar_w < 2 || (planar_w & (planar_w - 1)) || (hw & (hw - 1)) || hw % planar_w != 0))
+        return BMI_ERR_UNSUPPORTED;
     if (n <= 0 || batch <= 0 || n % batch != 0) return BMI_ERR_INVALID;
     const long gps = (long)batch * hw * (c / 8);
     const int tc = n / batch;
@@ -339,12 +384,13 @@ int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, 
         long cblocks = (cps * tc + 255) / 256;
         if (cblocks > 256 * 32) cblocks = 256 * 32;
         const dim3 g((unsigned)cblocks), b(256);
-        if (lb == 1) hipLaunchKernelGGL(mask_bits_call_kernel<1>, g, b, 0, s, bits, cps, tc, t0, site);
-        else if (lb == 2) hipLaunchKernelGGL(mask_bits_call_kernel<2>, g, b, 0, s, bits, cps, tc, t0, site);
-        else hipLaunchKernelGGL(mask_bits_call_kernel<3>, g, b, 0, s, bits, cps, tc, t0, site);
+        if (lb == 1) hipLaunchKernelGGL(mask_bits_call_kernel<1>, g, b, 0, s, bits, cps, tc, t0, site, hw, planar_w, c);
+        else if (lb == 2) hipLaunchKernelGGL(mask_bits_call_kernel<2>, g, b, 0, s, bits, cps, tc, t0, site, hw, 0, c);
+        else hipLaunchKernelGGL(mask_bits_call_kernel<3>, g, b, 0, s, bits, cps, tc, t0, site, hw, 0, c);
         BMI_CHECK_LAUNCH();
         return BMI_OK;
     }
+    if (planar_w > 0) return BMI_ERR_UNSUPPORTED;
     long blocks = ((gps * tc + 3) / 4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(mask_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bits, gps, tc, t0, site);

@@ -554,7 +554,7 @@ class BatchesInFlight:
         with torch.cuda.stream(st):
             return fn(self.engines[i])
 
-    def predict_graphed(self, x, T, seed=0, cnt0=0, group=None):
+    def predict_graphed(self, x, T, seed=0, cnt0=0, group=None, kind=None):
         """``engine.predict(x, T, seed, cnt0=cnt0)`` of the next slot as ONE hipGraph launch (torch.cuda.CUDAGraph on ROCm).
         The library neither allocates nor synchronises inside bmi_forward_mcd / bmi_finalize, so the whole batch step — zero
         the moments, the once-per-batch prefix, every sample chunk of the suffix, finalize — is captured once per
@@ -586,7 +586,7 @@ class BatchesInFlight:
         st = self._gstreams[i]
         self.last_stream = st
         cur = torch.cuda.current_stream(self.device)
-        key = (tuple(x.shape), int(T), int(seed), int(cnt0), rank, world)
+        key = (tuple(x.shape), int(T), int(seed), int(cnt0), rank, world, kind)
         cache = self._graphs[i]
         rec = cache.get(key)
 
@@ -595,7 +595,7 @@ class BatchesInFlight:
             x.record_stream(st)
             with torch.cuda.stream(st):
                 S = eng.new_moments(x.shape[0])
-                accumulate_share(eng, x, S, T, seed, cnt0, rank, world)
+                accumulate_share(eng, x, S, T, seed, cnt0, rank, world, kind)
                 if world > 1:
                     import torch.distributed as dist
                     dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
@@ -609,13 +609,13 @@ class BatchesInFlight:
             st.wait_stream(cur)
             with torch.cuda.stream(st):                          # warm-up on the capture stream (module load, first launches)
                 xs.copy_(x)
-                accumulate_share(eng, xs, S, T, seed, cnt0, rank, world)
+                accumulate_share(eng, xs, S, T, seed, cnt0, rank, world, kind)
             st.synchronize()
             graph, out = torch.cuda.CUDAGraph(), {}
             try:
                 with torch.cuda.graph(graph, stream=st):
                     S.zero_()
-                    accumulate_share(eng, xs, S, T, seed, cnt0, rank, world)
+                    accumulate_share(eng, xs, S, T, seed, cnt0, rank, world, kind)
                     if world == 1:
                         out.update(eng.finalize(S, T))
             except Exception as exc:                              # (a launcher returned non-OK under capture, ...)

@@ -39,17 +39,20 @@ def accumulate_sharded(accumulate_fn, S, T, group=None, t_begin=0):
 
 def partition(T, B, rank, world, kind=None):
     """What rank ``rank`` of ``world`` runs of a batch of B images x T Monte-Carlo samples: ``("samples", lo, hi)`` — the
-    sample range [lo, hi) on all images — while there are at least as many samples as ranks, else ``("images", lo, hi)`` —
+    sample range [lo, hi) on all images — while there are more samples than ranks, else ``("images", lo, hi)`` —
     ALL T samples on images [lo, hi): the fallback of SURVEY.md §8.5 ("partition by images, pure DP") for T < G, where a
     sample split would leave ranks idle (T = 4 on 8 GPUs: half of them) and every rank would still recompute the whole
     once-per-batch prefix.  Either way the shares are disjoint and their moment buffers add up to the one-rank result.
-    T == world (config 4: one Masksembles mask per GPU) goes by samples: measured on one MI355X, a rank's share of
-    250 images x 1 sample against 31 images x 8 samples (tools/share_bench.py, profiles/r04_share_config4.txt).
-    ``kind`` forces one of the two (measurements, tests)."""
+    T == world (config 4: one Masksembles mask per GPU) also goes by images: measured on one MI355X, rank 0's share of eight as
+    32 images x 8 samples takes 0.61 ms per batch against 0.77 ms as 250 images x 1 sample (tools/share_bench.py,
+    profiles/r04_share_config4.txt: the prefix runs on 32 images instead of 250 and a head launch's 32-sample groups are full) —
+    every GPU then applies all M masks to its images instead of one mask to all images; the reduce is the same one all-reduce.
+    (T > world keeps the sample split the configs are written with — "T=512 sharded 64/GPU" — although the image split measured
+    6 % faster there too: 3.00 vs 3.18 ms for T = 100 over eight ranks; ``kind`` / ``bench.py --partition`` force either.)"""
     if kind not in (None, "samples", "images"):
         raise ValueError(f"kind must be 'samples' or 'images', got {kind!r}")
     if kind is None:
-        kind = "samples" if T >= world else "images"
+        kind = "samples" if world == 1 or ((T > world or B < world) and T >= world) else "images"
     return (kind,) + (shard_range(T, rank, world) if kind == "samples" else shard_range(B, rank, world))
 
 
@@ -83,12 +86,12 @@ def accumulate_share(engine, x, S, T, seed=0, cnt0=0, rank=0, world=1, kind=None
     return S
 
 
-def accumulate_partitioned(engine, x, S, T, seed=0, cnt0=0, group=None):
+def accumulate_partitioned(engine, x, S, T, seed=0, cnt0=0, group=None, kind=None):
     """This rank's share of batch ``x`` x T samples ADDED into the moment buffer ``S`` [3, E, B, C] (``accumulate_share``), then ONE
     all-reduce (sum) over the group."""
     import torch.distributed as dist
     rank, world = _rank_world(group)
-    accumulate_share(engine, x, S, T, seed, cnt0, rank, world)
+    accumulate_share(engine, x, S, T, seed, cnt0, rank, world, kind)
     if world > 1:
         dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
     return S

@@ -102,6 +102,8 @@ def parse():
                     help="each batch step (zero, prefix, suffix chunks, finalize) is ONE hipGraph replay (engine.BatchesInFlight.predict_graphed): "
                          "takes the launch floor out of the launch-bound small-model configs (VGG-11, one Masksembles mask per GPU); with more "
                          "than one rank the graph holds the rank's share and the all-reduce + finalize follow the replay eagerly")
+    ap.add_argument("--partition", choices=("auto", "samples", "images"), default="auto",
+                    help="how a batch x T samples is split over the ranks (sharding.partition): auto = by samples while T > ranks, by images otherwise")
     ap.add_argument("--dump-mean", default="", help="rank 0 writes the final predictive mean [E,B,C] float64 to this .npy (tests)")
     return ap.parse_args()
 
@@ -306,7 +308,8 @@ def main():
     pipe = BatchesInFlight(model, dev, n=a.in_flight, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
     eng = pipe.engines[0]
     x = synthetic_images(B, seed=1234).to(dev)
-    share = partition(T, B, rank, world)       # ("samples", lo, hi) while T >= world, else ("images", lo, hi): nobody idles
+    pkind = None if a.partition == "auto" else a.partition
+    share = partition(T, B, rank, world, pkind)       # ("samples", lo, hi) while T > world, else ("images", lo, hi): nobody idles
     t_lo, t_hi = (share[1], share[2]) if share[0] == "samples" else (0, T)
     Ss = [e.new_moments(B) for e in pipe.engines]
 
@@ -314,13 +317,13 @@ def main():
         S.zero_()
         # the library's N>1 path (bayesnn_fpga_amd/sharding.py): this rank's share into S, then ONE all-reduce (RCCL
         # over xGMI) of the [3,E,B,C] float64 buffer; a single rank skips the collective
-        accumulate_partitioned(e, x, S, T, a.seed)
+        accumulate_partitioned(e, x, S, T, a.seed, kind=pkind)
         return e.finalize(S, T)
 
     def step():
         # one step = one batch through the whole path; consecutive steps alternate between the engines / streams of `pipe`
         if a.graph:
-            return pipe.predict_graphed(x, T, a.seed)
+            return pipe.predict_graphed(x, T, a.seed, kind=pkind)
         i = pipe.slot()
         return pipe.submit(lambda e: one_batch(e, Ss[i]))
 
@@ -343,8 +346,11 @@ def main():
         evs[k].record(pipe.last_stream if pipe.last_stream is not None else torch.cuda.current_stream(dev))
     fence()
     dt = time.perf_counter() - t0
-    done_ms = [ev0.elapsed_time(e) for e in evs]              # completion time of step k since the start of the timed region
-    step_ms = sorted(b - a_ for a_, b in zip([0.0] + done_ms[:-1], done_ms))      # intervals between consecutive completions
+    done_ms = [0.0] * a.in_flight + [ev0.elapsed_time(e) for e in evs]     # completion time of step k since the start of the timed region
+    # steady-state time per step: with w batches in flight the steps complete in bunches of w (they share the GPU), so the interval is taken
+    # over a window of w completions: (done[k] - done[k - w]) / w
+    w = a.in_flight
+    step_ms = sorted((done_ms[k + w] - done_ms[k]) / w for k in range(len(evs)))
     median_ms = (step_ms[len(step_ms) // 2] + step_ms[(len(step_ms) - 1) // 2]) / 2 if step_ms else 0.0
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -382,8 +388,9 @@ def main():
                       else f"MCD-samples/sec (T x images/s) + ECE, {a.workload} T={T}",
             "value": round(value, 1), "unit": "MCD-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3),
-            # interval between consecutive step completions (HIP events on the steps' own streams), rank 0: median / min / max, and the rate
-            # the median implies (the first intervals of a short run sit on the clock ramp: SURVEY §8.4 asks for the median)
+            # time per step from the step completions (HIP events on the steps' own streams; windows of `batches_in_flight` completions), rank 0:
+            # median / min / max, and the rate the median implies (the first steps of a short run sit on the clock ramp: SURVEY §8.4 asks for
+            # the median of >= 10 timed iterations)
             "ms_per_step_median": round(median_ms, 3), "ms_per_step_min": round(step_ms[0], 3) if step_ms else None,
             "ms_per_step_max": round(step_ms[-1], 3) if step_ms else None,
             "value_at_median": round(B * T / (median_ms * 1e-3), 1) if median_ms > 0 else None,
@@ -392,7 +399,7 @@ def main():
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
                        "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight, "hipgraph": bool(a.graph),
-                       "sharding": (f"T over {world} rank(s)" if share[0] == "samples" else f"images over {world} ranks (T < ranks)") +
+                       "sharding": (f"T over {world} rank(s)" if share[0] == "samples" else f"images over {world} ranks (T <= ranks)") +
                                    ", one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
             "ece_note": "synthetic weights on uniform synthetic labels: plumbing (equal to the CPU oracle's at equal T), not calibration",

@@ -173,6 +173,10 @@ const char* bmi_error_string(int code);
  *                                           keep bits + one scaled copy of the B images; conv3x3_s2 / conv3x3_patch (fused shortcut input) clear the
  *                                           dropped elements in LDS, any other consumer makes the masked tensor appear first (1, default), or the
  *                                           masked tensor is always written (0); the same bits either way
+ *   "lazy_planar"                           0 | 1: a lazy site whose readers are all stride-2 consumers (conv3x3_s2 on 32x32 maps, the fused 1x1
+ *                                           stride-2 shortcut of conv3x3_patch) stores its scaled copy and keep bits as 32-channel planes with
+ *                                           the even columns of a row in front of the odd ones — what such a reader DMAs is then contiguous,
+ *                                           whole 128-byte lines (1, default) — or in NHWC (0); the same bits either way
  *   "conv_wide"                             0 | 1: 0 skips conv_igemm_wide (A/B against the per-tap kernel)
  *   "splitk"                                0 | 1, read by bmi_plan: 3x3 convs of the once-per-batch prefix whose grid is <= 64 tiles (VGG's convs on
  *                                           2x2 maps) run split-K: one workgroup per (tile, tap), fp32 partial sums, a finishing pass

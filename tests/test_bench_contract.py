@@ -155,13 +155,15 @@ def test_two_rank_bench_over_rccl(tmp_path, extra):
 @pytest.mark.gpu
 def test_graphed_share_on_the_sharded_path(tmp_path):
     """--graph with more than one rank: each rank's share (accumulate only) is ONE hipGraph replay, the all-reduce and finalize follow
-    eagerly.  Config 4's shape — T = world: one sample of the whole batch per rank — in dry run on one GPU (gloo); equal to the eager
-    two-rank run and to the one-rank run to 1e-12."""
+    eagerly.  Config 4's shape — T = world — in dry run on one GPU (gloo), by images (the default for T = world) and by samples
+    (one mask per rank, forced); equal to the eager two-rank run and to the one-rank run to 1e-12."""
     import numpy as np
     common = ["--workload", "resnet18_masksembles", "--T", "2", "--batch", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     fs = []
-    for n, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu"]), (2, ["--backend", "gloo", "--share-gpu", "--graph"])):
+    for n, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu"]), (2, ["--backend", "gloo", "--share-gpu", "--graph"]),
+                     (2, ["--backend", "gloo", "--share-gpu", "--partition", "samples"]),
+                     (2, ["--backend", "gloo", "--share-gpu", "--partition", "samples", "--graph"])):
         f = str(tmp_path / f"m{len(fs)}.npy")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *extra, *common, "--dump-mean", f],
                            capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -170,7 +172,8 @@ def test_graphed_share_on_the_sharded_path(tmp_path):
         assert d["config"]["hipgraph"] == ("--graph" in extra)
         fs.append(np.load(f))
     np.testing.assert_allclose(fs[1], fs[0], rtol=0, atol=1e-12)
-    assert np.array_equal(fs[2], fs[1])
+    np.testing.assert_allclose(fs[3], fs[0], rtol=0, atol=1e-12)
+    assert np.array_equal(fs[2], fs[1]) and np.array_equal(fs[4], fs[3])
 
 
 def test_bench_self_launch_starts_n_ranks_without_a_launcher(tmp_path):

@@ -114,7 +114,9 @@ def test_two_rank_gloo_masksembles_shards_the_mask_indices(tmp_path):
 # ---- fewer samples than ranks: the batch is partitioned by IMAGES (SURVEY.md §8.5 fallback) -----------------------------------
 def test_partition_switches_to_images_below_one_sample_per_rank():
     assert partition(100, 250, 3, 8) == ("samples",) + shard_range(100, 3, 8)
-    assert partition(8, 250, 7, 8) == ("samples", 7, 8)                   # BASELINE config 3: one mask per GPU
+    assert partition(8, 250, 7, 8) == ("images",) + shard_range(250, 7, 8)     # BASELINE configs[3] (T = M = 8 masks on 8 GPUs): by images, measured faster
+    assert partition(8, 250, 7, 8, "samples") == ("samples", 7, 8)          # ... one mask per GPU, forced
+    assert partition(1, 250, 0, 1) == ("samples", 0, 1) and partition(8, 4, 3, 8) == ("samples", 3, 4)
     spans = [partition(4, 250, r, 8) for r in range(8)]
     assert all(k == "images" for k, _, _ in spans) and spans[0][1] == 0 and spans[-1][2] == 250
     assert all(a[2] == b[1] for a, b in zip(spans, spans[1:])) and max(hi - lo for _, lo, hi in spans) == 32
@@ -185,4 +187,4 @@ def test_image_partition_is_refused_by_every_rank_together():
     eng = _OracleEngine(model, x, 42)
     eng.bad_offset = 0                     # world = 1: the only share starts at image 0
     with pytest.raises(ValueError, match="whole Philox call"):
-        ap(eng, x, torch.zeros(3, 4, 3, 10, dtype=torch.float64), 0, seed=42)     # T = 0 < world = 1 -> image partition
+        ap(eng, x, torch.zeros(3, 4, 3, 10, dtype=torch.float64), 2, seed=42, kind="images")

@@ -347,21 +347,16 @@ def _import_ref_converter():
     return ref_dropouts, ref_nn2bnn
 
 
-def gen_converter_resnet():
-    """The reference's nn2bnn._convert_model (Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45) applied to the reference's
-    own ResNet18Base (SA/models/resnet18/resnet18.py:189-204): every Conv2d — the stem, both convs of every BasicBlock, the
-    1x1 shortcut convs, the (unused) exit-head convs — becomes BayesianDropout2D, every Linear BayesianDropout; T passes of
-    the converted model's own forward.  Patched: only F.dropout / F.dropout2d (the Bernoulli source)."""
-    from models.resnet18.resnet18 import ResNet18Base
+def _run_reference_converter(net, fixture, B, T, seed, p, returns_list, extra=None):
+    """The reference's nn2bnn._convert_model (Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45) applied to ``net``, T passes of
+    the converted model's own forward on the seeded synthetic batch, written as tests/golden/<fixture>.npz.  Patched: only
+    F.dropout / F.dropout2d (the Bernoulli source), as for the other fixtures."""
     ref_dropouts, ref_nn2bnn = _import_ref_converter()
 
     def d2(x, p=0.5, training=True, inplace=False):
         assert training
         return philox_dropout(CTX, x, p, channelwise=True)
 
-    B, T, seed, p = 3, 4, 77, 0.25
-    torch.manual_seed(0)
-    net = ResNet18Base(n_exits=1, out_dim=10)
     init = state_checksum(net.state_dict())
     synthetic_weights_(net, 0)
     wsum = state_checksum(net.state_dict())
@@ -370,6 +365,7 @@ def gen_converter_resnet():
     x = synthetic_images(B, seed=1234)
     model.eval()
     outs = []
+    sites_per_pass = 0
     orig = ref_dropouts.F.dropout, ref_dropouts.F.dropout2d
     ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = _patched_dropout, d2
     try:
@@ -377,115 +373,72 @@ def gen_converter_resnet():
             for tt in range(T):
                 CTX.begin_forward(seed, tt)
                 out = model(x)
-                assert isinstance(out, list) and len(out) == 1
-                outs.append(out[0].numpy()[None])
+                if returns_list:
+                    assert isinstance(out, list)
+                    outs.append(np.stack([o.numpy() for o in out]))
+                else:
+                    outs.append(out.numpy()[None])
                 sites_per_pass = CTX.site
     finally:
         ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = orig
-    logits = np.stack(outs)                      # [T, 1, B, C]
-    np.savez(os.path.join(OUT, "converter_resnet18base.npz"), logits=logits, B=B, T=T, seed=seed, p=p, init_checksum=init,
-             weights_checksum=wsum, wrapper_classes=np.array(classes), keys=np.array(list(model.state_dict().keys())),
-             sites_per_pass=sites_per_pass)
-    print("converter_resnet18base", logits.shape, len(classes), "wrappers,", sites_per_pass, "sites per pass", float(np.abs(logits).max()))
+    logits = np.stack(outs)                      # [T, E, B, C]
+    fields = dict(logits=logits, B=B, T=T, seed=seed, p=p, init_checksum=init, weights_checksum=wsum,
+                  wrapper_classes=np.array(classes), keys=np.array(list(model.state_dict().keys())))
+    fields.update(extra(ref_dropouts) if extra else dict(sites_per_pass=sites_per_pass))
+    np.savez(os.path.join(OUT, fixture + ".npz"), **fields)
+    print(fixture, logits.shape, len(classes), "wrappers,", sites_per_pass, "sites per pass", float(np.abs(logits).max()))
+
+
+def gen_converter_resnet():
+    """... on the reference's own ResNet18Base (SA/models/resnet18/resnet18.py:189-204): every Conv2d — the stem, both convs of
+    every BasicBlock, the 1x1 shortcut convs, the (unused) exit-head convs — becomes BayesianDropout2D, every Linear
+    BayesianDropout."""
+    from models.resnet18.resnet18 import ResNet18Base
+    torch.manual_seed(0)
+    _run_reference_converter(ResNet18Base(n_exits=1, out_dim=10), "converter_resnet18base", 3, 4, 77, 0.25, True)
 
 
 def gen_converter_vgg():
-    """The same for the reference's VGG19 (SA/models/vgg19/vgg19.py:186-192; VGG.forward :107-119): 16 wrapped convs (site before
-    the BatchNorm), 5 wrapped MaxPool2d (elementwise), the wrapped classifier (logits).  The converter also wraps the second
+    """... on the reference's VGG19 (SA/models/vgg19/vgg19.py:186-192; VGG.forward :107-119): 16 wrapped convs (site before the
+    BatchNorm), 5 wrapped MaxPool2d (elementwise), the wrapped classifier (logits).  The converter also wraps the second
     references to the same layers in ``non_sequentialized_blocks`` (unused by the forward)."""
     from models.vgg19.vgg19 import VGG19
-    ref_dropouts, ref_nn2bnn = _import_ref_converter()
-
-    def d2(x, p=0.5, training=True, inplace=False):
-        assert training
-        return philox_dropout(CTX, x, p, channelwise=True)
-
-    B, T, seed, p = 3, 4, 55, 0.25
     torch.manual_seed(0)
-    net = VGG19(n_exits=1, out_dim=10)
-    init = state_checksum(net.state_dict())
-    synthetic_weights_(net, 0)
-    wsum = state_checksum(net.state_dict())
-    model = ref_nn2bnn._convert_model(net, p)
-    classes = [type(m).__name__ for m in model.modules() if isinstance(m, ref_dropouts._DropoutBase)]
-    x = synthetic_images(B, seed=1234)
-    model.eval()
-    outs = []
-    orig = ref_dropouts.F.dropout, ref_dropouts.F.dropout2d
-    ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = _patched_dropout, d2
-    try:
-        with torch.no_grad():
-            for tt in range(T):
-                CTX.begin_forward(seed, tt)
-                out = model(x)
-                assert isinstance(out, list) and len(out) == 1
-                outs.append(out[0].numpy()[None])
-                sites_per_pass = CTX.site
-    finally:
-        ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = orig
-    logits = np.stack(outs)                      # [T, 1, B, C]
-    np.savez(os.path.join(OUT, "converter_vgg19.npz"), logits=logits, B=B, T=T, seed=seed, p=p, init_checksum=init,
-             weights_checksum=wsum, wrapper_classes=np.array(classes), keys=np.array(list(model.state_dict().keys())),
-             sites_per_pass=sites_per_pass)
-    print("converter_vgg19", logits.shape, len(classes), "wrappers,", sites_per_pass, "sites per pass", float(np.abs(logits).max()))
+    _run_reference_converter(VGG19(n_exits=1, out_dim=10), "converter_vgg19", 3, 4, 55, 0.25, True)
+
+
+def gen_converter_multi_exit():
+    """... on the reference's own MULTI-EXIT classes (round 4): ResNet18EarlyExit (SA/models/resnet18/resnet18.py:182-186, forward
+    :144-180: 4 logits; the exit-head convs are live here, 27 sites per pass) and VGG19EarlyExit (SA/models/vgg19/vgg19.py:256-324:
+    5 logits; the wrapped MaxPool2d at the end of a block feeds both the next block and the exit in front of it)."""
+    from models.resnet18.resnet18 import ResNet18EarlyExit
+    from models.vgg19.vgg19 import VGG19EarlyExit
+    torch.manual_seed(0)
+    _run_reference_converter(ResNet18EarlyExit(n_exits=4, out_dim=10), "converter_resnet18ee", 3, 4, 91, 0.25, True)
+    torch.manual_seed(0)
+    _run_reference_converter(VGG19EarlyExit(n_exits=5, out_dim=10), "converter_vgg19ee", 3, 4, 92, 0.25, True)
+
+
+def gen_converter_custom():
+    """... on a small net with a HAND-WRITTEN forward (tests/helpers.py:converter_custom_net: a residual add, functional ReLU and
+    pooling, ``.view``, two outputs): the reference's _convert_model takes any nn.Module; the package compiles this one through
+    torch.fx (converter/pytorch/fx_frontend.py)."""
+    from tests.helpers import converter_custom_net
+    torch.manual_seed(0)
+    _run_reference_converter(converter_custom_net(), "converter_custom", 5, 6, 4321, 0.25, True)
 
 
 def gen_converter():
-    """Hardware_Artifact/converter/pytorch: the reference's own Dropouts.py classes and nn2bnn._convert_model applied
-    to a small CNN.  nn2bnn.py imports a file that is not in the repository (``test.ThreeLayerNet``, :5): an empty
-    module of that name is registered so that the import statement passes; nothing of it is used.  Patched: only
-    F.dropout / F.dropout2d (the Bernoulli source), as for the other fixtures."""
-    conv_dir = "/root/reference/Hardware_Artifact/converter/pytorch"
-    sys.path.insert(0, conv_dir)
-    saved_test = sys.modules.get("test"), sys.modules.get("test.ThreeLayerNet")
-    t = types.ModuleType("test")
-    tl = types.ModuleType("test.ThreeLayerNet")
-    tl.ThreeLayerNet = None
-    t.ThreeLayerNet = tl
-    sys.modules["test"], sys.modules["test.ThreeLayerNet"] = t, tl
-    import Dropouts as ref_dropouts
-    import nn2bnn as ref_nn2bnn
-    for k, v in zip(("test", "test.ThreeLayerNet"), saved_test):
-        if v is None:
-            sys.modules.pop(k, None)
-        else:
-            sys.modules[k] = v
-    sys.path.remove(conv_dir)
-
-    def d2(x, p=0.5, training=True, inplace=False):
-        assert training
-        return philox_dropout(CTX, x, p, channelwise=True)
-
-    B, T, seed, p = 5, 6, 1234, 0.25
+    """... on a small sequential CNN (tests/helpers.py:converter_cnn), plus the reference's ValueError text for p outside [0, 1]."""
+    def extra(ref_dropouts):
+        err = ""
+        try:
+            ref_dropouts.BayesianDropout(torch.nn.Linear(2, 2), p=1.5)
+        except ValueError as e:
+            err = str(e)
+        return dict(bad_p_error=err)
     torch.manual_seed(0)
-    net = converter_cnn()
-    init = state_checksum(net.state_dict())
-    synthetic_weights_(net, 0)
-    wsum = state_checksum(net.state_dict())
-    model = ref_nn2bnn._convert_model(net, p)
-    classes = [type(m).__name__ for m in model.modules() if isinstance(m, ref_dropouts._DropoutBase)]
-    x = synthetic_images(B, seed=1234)
-    model.eval()
-    outs = []
-    orig = ref_dropouts.F.dropout, ref_dropouts.F.dropout2d
-    ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = _patched_dropout, d2
-    try:
-        with torch.no_grad():
-            for tt in range(T):
-                CTX.begin_forward(seed, tt)
-                outs.append(model(x).numpy()[None])
-    finally:
-        ref_dropouts.F.dropout, ref_dropouts.F.dropout2d = orig
-    logits = np.stack(outs)                      # [T, 1, B, C]
-    err = ""
-    try:
-        ref_dropouts.BayesianDropout(torch.nn.Linear(2, 2), p=1.5)
-    except ValueError as e:
-        err = str(e)
-    np.savez(os.path.join(OUT, "converter_cnn.npz"), logits=logits, B=B, T=T, seed=seed, p=p, init_checksum=init,
-             weights_checksum=wsum, wrapper_classes=np.array(classes), keys=np.array(list(model.state_dict().keys())),
-             bad_p_error=err)
-    print("converter_cnn", logits.shape, classes, float(np.abs(logits).max()))
+    _run_reference_converter(converter_cnn(), "converter_cnn", 5, 6, 1234, 0.25, False, extra)
 
 
 if __name__ == "__main__":
@@ -494,6 +447,14 @@ if __name__ == "__main__":
         gen_converter()
         gen_converter_resnet()
         gen_converter_vgg()
+        gen_converter_multi_exit()
+        gen_converter_custom()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "converter_custom":
+        gen_converter_custom()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "converter_multi_exit":
+        gen_converter_multi_exit()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "converter_resnet":
         gen_converter_resnet()
@@ -504,6 +465,8 @@ if __name__ == "__main__":
     gen_converter()
     gen_converter_resnet()
     gen_converter_vgg()
+    gen_converter_multi_exit()
+    gen_converter_custom()
     gen_philox()
     gen_masksembles()
     gen_metrics()

@@ -27,6 +27,33 @@ from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synth
 from bayesnn_fpga_amd.train.results_analyzer import FullAnalysis  # noqa: E402
 
 
+def evaluate_route(a, wl, model, loader):
+    """train.evaluate over the host loader: `passes` outer passes, each model(X) a single-sample launch-bound step (25 launches on 250
+    images), metrics per batch.  Two figures: the mirror as shipped (the metric vectors stay on the device, one host synchronisation per
+    pass over the loader) and with the reference's per-batch host synchronisation (loss_f.metrics: nine .cpu() per batch)."""
+    from bayesnn_fpga_amd.engine import model_exits
+    from bayesnn_fpga_amd.train.evaluate import MultiExitAccuracy, evaluate
+
+    n_exits = model_exits(model)
+    out = {}
+    for name, defer in (("deferred_sync", True), ("per_batch_sync", False)):
+        loss = MultiExitAccuracy(n_exits)
+        loss.defer_host_sync = defer
+        evaluate(loss, loader, model, 0, "loop_bench", 1, create_log=False)          # warm-up
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(a.repeats):
+            t0 = time.perf_counter()
+            vec = evaluate(loss, loader, model, 0, "loop_bench", a.evaluate, create_log=False)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        out[name] = {"s": round(t, 4), "mcd_samples_per_s": round(a.images * a.evaluate / t, 1), "ms_per_model_call": round(1e3 * t / (a.evaluate * len(loader)), 4),
+                     "acc1_avg": round(float(vec[0]), 6)}
+    print(json.dumps({"what": "train.evaluate (SA/train/evaluate.py:8-22): T outer passes over a host loader, model(X) = one stochastic pass per call",
+                      "workload": wl[5], "images": a.images, "batch": a.batch, "passes": a.evaluate, "pinned_host_batches": bool(a.pin), **out}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="resnet18_me", choices=sorted(bench.WORKLOADS))
@@ -34,7 +61,13 @@ def main():
     ap.add_argument("--batch", type=int, default=250)
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=3)
-    ap.add_argument("--pin", type=int, default=1, help="pinned host batches (DataLoader pin_memory)")
+    ap.add_argument("--pin", type=int, default=0,
+                    help="pinned host batches (DataLoader pin_memory).  The reference's test loader pins (SA/datasets/dataset_loader.py:171); with 0 "
+                         "workers the pinning copy runs on the loader's — this — thread and costs ~10 ms per 250-image batch on the GPU box's host "
+                         "(tools/experiments/evaluate_profile.py): 0 is the loop at its best, 1 the reference's setting")
+    ap.add_argument("--evaluate", type=int, default=0,
+                    help="N > 0: time the reference's MCD use #1 instead — train.evaluate (SA/train/evaluate.py:8-22): N OUTER passes over the "
+                         "loader, every model(X) ONE stochastic pass, the multi-exit accuracy vector per batch")
     a = ap.parse_args()
     wl = bench.WORKLOADS[a.workload]
     dev = torch.device("cuda", 0)
@@ -46,6 +79,8 @@ def main():
     y = synthetic_labels(a.images, wl[2]["out_dim"], seed=1235)
     loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=a.batch, shuffle=False, num_workers=0,
                                          pin_memory=bool(a.pin))
+    if a.evaluate > 0:
+        return evaluate_route(a, wl, model, loader)
     fa = FullAnalysis(model, None, gpu=0, mc_dropout=True, mc_passes=T, seed=42)
     fa.loader = loader
     fa.sdn_get_detailed_results()                                                # warm-up: engines built, kernels loaded
