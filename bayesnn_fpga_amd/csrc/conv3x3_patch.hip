@@ -328,261 +328,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     STAMP(3);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// conv3x3_patch16p (round 4): the 16x16-map class (one image per tile, 128 channels, 4 waves, 16x16x32 MFMAs), PERSISTENT, for the launches
-// that finish in the plain epilogue (BN + ReLU; with or without the fused shortcut).  Two workgroups per CU walk the tiles; when a tile's
-// main loop ends the NEXT tile's first patch chunk is DMA'd into the patch region at once and lands under the epilogue, which therefore
-// stays out of that region: two rounds of 128 pixels through the 32 KB of the two weight buffers (conv3x3_s2's staging code), BN from an
-// LDS table (a global load in the epilogue would make every wave wait for the DMA in flight: vmcnt retires in order).  The next tile's first
-// weight tile is issued between round 1's LDS reads and its 8 global stores, so the step-0 wait of the next tile is vmcnt(8): the
-// stores stay in flight across the tile boundary.  Same K order, same arithmetic, same bits as conv3x3_patch_kernel<16, 16, 1, 4, PLAIN, 16>.
-template <bool BF, bool SHORTCUT>
-__global__ __launch_bounds__(256, 2) void conv3x3_patch16p_kernel(ConvArgs a, int n_tiles) {
-    using G = PatchGeom<16, 16, 1, 4>;
-    constexpr int TH = 16, TW = 16, TJ = 4, MS = 16;
-    constexpr int BC = G::BC, PH = G::PH, PW = G::PW, PWP = G::PWP, KA = G::KA;
-    constexpr int TI = 4, TP = 8, RW = 16, KSUB = 2, KQ = 4;
-    constexpr int BN_OFF = G::MAIN_BYTES;                     // fp32 scale[Cout] | bias[Cout] of the launch (Cout <= 256: 2 KB)
-    __shared__ __attribute__((aligned(16))) char smem[G::MAIN_BYTES + 2048];
-    char* const patch = smem;
-    char* const wbuf = smem + G::PATCH_BYTES;
-    char* const E = wbuf;                                     // epilogue staging: one round = 128 px x 128 ch fp16 = the two weight buffers
-    float* const bn_scale = (float*)(smem + BN_OFF);
-    float* const bn_bias = bn_scale + 256;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, kq = lane >> 4;
-    const int wc = wave >> 1, wp = wave & 1;
-    const int n_ctiles = a.Cout / BC;
-    const int n_ptiles = n_tiles / n_ctiles;
-    const int Ktot = 9 * a.Cin;
-
-    for (int c = tid; c < a.Cout; c += 256) {
-        bn_scale[c] = (a.scale ? a.scale[c] : 1.f) * a.out_mul;
-        bn_bias[c] = a.bias ? a.bias[c] : 0.f;
-    }
-    __syncthreads();   // (no LDS-DMA in flight yet)
-
-#define PSW(KEY) ((((KEY) >> 1) & 3) << 1)
-    // patch pieces: the in-image element offset of piece q = tid + 256 i at channel chunk 0 (-1: zero page) is the same for every tile and
-    // is recomputed at each issue (twice per tile: divisions by constants) — as eleven loop-invariant registers it was spilled
-    auto piece_off = [&](int i) -> int {
-        const int q = tid + 256 * i;
-        const int cell = q >> 3, cp = q & 7;
-        const int py = cell / PWP, px = cell - py * PWP;
-        const int c = cp ^ PSW(px + KA * py);
-        const int iy = py - 1, ix = px - 1;
-        const bool ok = cell < G::CELLS && px < PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        return ok ? (iy * a.W + ix) * a.Cin + c * 8 : -1;
-    };
-    const int w_row = tid >> 3;
-    const int w_sw = (w_row >> 1) & 7;
-    const int w_lane = (size_t)w_row * Ktot + ((tid & 7) ^ w_sw) * 8;
-    const int HWC = a.H * a.W * a.Cin;
-
-    // fragment geometry: pixel tile j of a wave is output row wp * 8 + j, lane r its column: cell = (wp * 8 + j) * PWP + r, swizzle key = r (KA = 0)
-    static_assert(KA == 0, "16-wide tiles: the swizzle key is the column");
-    const int bcell0 = (wp * 8) * PWP + r;
-    const int a_off = (wc * 64 + r) * 128;
-    const int a_sw = (r >> 1) & 7;
-    typedef float accv __attribute__((ext_vector_type(4)));
-
-#define ISSUE_PATCH_T(IMG_OFF, C0)                                                                \
-    {                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < G::ITER_P; ++i) {                                   \
-            const int po_ = piece_off(i);                                                         \
-            GLDS16(po_ >= 0 ? a.in + (size_t)(unsigned)((IMG_OFF) + po_) + (C0) : (const _Float16*)g_zero_page,   \
-                   patch + (i * 256 + wave * 64) * 16);                                           \
-        }                                                                                         \
-    }
-#define LOAD_W_T(WBASE, KOFF, BUF)                                                                \
-    {                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-            GLDS16((WBASE) + w_lane + (size_t)(32 * i) * Ktot + (KOFF),                           \
-                   wbuf + (BUF) * G::WTILE + (i * 256 + wave * 64) * 16);                         \
-    }
-    const int nchunks = a.Cin / 64;
-    const int nK = 9 * nchunks;
-    auto w_koff = [&](int st) { const int c = st / 9, t = st - 9 * c; return t * a.Cin + c * 64; };
-
-    int vb = blockIdx.x;
-    int n0, ctile;
-    xcd_tile_map(vb, n_ptiles, n_ctiles, n0, ctile, a.xcd_split);
-    ISSUE_PATCH_T((n0 % a.in_mod) * HWC, 0);
-    LOAD_W_T(a.wgt + (size_t)(ctile * BC) * Ktot, 0, 0);
-    bool first = true;
-    while (vb < n_tiles) {
-        const int ch0 = ctile * BC;
-        const int img_off = (n0 % a.in_mod) * HWC;
-        const _Float16* const wbase = a.wgt + (size_t)ch0 * Ktot;
-        accv acc[TI][TP];
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-        int step = 0;
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            for (int tap = 0; tap < 9; ++tap, ++step) {
-                const int buf = step & 1;
-                // step 0 of a later tile: everything but the previous tile's last 8 output stores (issued behind this tile's first DMAs)
-                if (step == 0 && !first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (step + 1 < nK) LOAD_W_T(wbase, w_koff(step + 1), buf ^ 1);
-                const int ky = tap / 3, kx = tap - 3 * ky;
-                const int coff = ky * PWP + kx, koff = kx + KA * ky;
-                const char* wt = wbuf + buf * G::WTILE;
-                const int boff0 = (bcell0 + coff) * 128, bsw = PSW(r + koff);
-#pragma unroll
-                for (int kk = 0; kk < KSUB; ++kk) {
-                    const int ch = KQ * kk + kq;
-                    half8 af[TI], bf[TP];
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wt + a_off + i * RW * 128 + ((ch ^ a_sw) << 4));
-                    const char* pb = patch + boff0 + ((ch ^ bsw) << 4);
-#pragma unroll
-                    for (int j = 0; j < TP; ++j) bf[j] = *(const half8*)(pb + j * (PWP * 128));
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int j = 0; j < TP; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
-                }
-                if (tap == 8 && chunk + 1 < nchunks) {
-                    lds_barrier();
-                    ISSUE_PATCH_T(img_off, (chunk + 1) * 64);
-                }
-            }
-        }
-        if constexpr (SHORTCUT) {
-            // fused 1x1 strided shortcut: extra K-steps on the block input at the output pixels' positions (conv3x3_patch_kernel's arithmetic;
-            // 32-bit in-image offsets and the eight keep bytes of a thread packed in two registers: the generic form spilled here)
-            const int nch2 = a.Cin2 / 64;
-            const int img_e = a.H2 * a.W2 * a.Cin2, hw2 = a.H2 * a.W2;
-            const _Float16* const in2_img = a.in2 + (size_t)(n0 % a.in2_mod) * img_e;
-            const uint8_t* const bits_img = a.in2_bits ? a.in2_bits + (((size_t)n0 * img_e) >> 3) : nullptr;
-            const bool planar = a.in2_bits && a.lazy_planar;
-            for (int c2 = 0; c2 < nch2; ++c2) {
-                lds_barrier();
-                unsigned kbw[2] = {0xffffffffu, 0xffffffffu};
-#pragma unroll
-                for (int i = 0; i < 2 * TJ; ++i) {
-                    const int q = tid + 256 * i;
-                    const int p = q >> 3, cp = q & 7;
-                    const int oy = p >> 4, ox = p & 15;
-                    const int c = c2 * 64 + (cp ^ PSW(ox)) * 8;
-                    const int y2 = oy * a.stride2, x2 = ox * a.stride2;
-                    const int eoff = planar ? (c >> 5) * hw2 * 32 + (y2 * a.W2 + (x2 & 1) * (a.W2 >> 1) + (x2 >> 1)) * 32 + (c & 31)
-                                            : (y2 * a.W2 + x2) * a.Cin2 + c;
-                    GLDS16(in2_img + eoff, patch + (i * 256 + wave * 64) * 16);
-                    if (bits_img) {
-                        const unsigned b = bits_img[eoff >> 3];
-                        kbw[i >> 2] = (kbw[i >> 2] & ~(0xffu << (8 * (i & 3)))) | (b << (8 * (i & 3)));
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    GLDS16(a.wgt2 + (size_t)(ch0 + w_row + 32 * i) * a.Cin2 + c2 * 64 + ((tid & 7) ^ w_sw) * 8, wbuf + (i * 256 + wave * 64) * 16);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (bits_img) {
-#pragma unroll
-                    for (int i = 0; i < 2 * TJ; ++i) {
-                        u32x4* const pp = (u32x4*)(patch + (i * 256 + tid) * 16);
-                        u32x4 v = *pp;
-                        const int b = (int)(kbw[i >> 2] >> (8 * (i & 3)));
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(b, 2 * jj, 1), hi = (unsigned)__builtin_amdgcn_sbfe(b, 2 * jj + 1, 1);
-                            v[jj] &= (lo & 0xffffu) | (hi & 0xffff0000u);
-                        }
-                        *pp = v;
-                    }
-                }
-                lds_barrier();
-#pragma unroll
-                for (int kk = 0; kk < KSUB; ++kk) {
-                    const int ch = KQ * kk + kq;
-                    half8 af[TI], bf[TP];
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wbuf + a_off + i * RW * 128 + ((ch ^ a_sw) << 4));
-                    const char* pb2 = patch + (wp * 128 + r) * 128 + ((ch ^ PSW(r)) << 4);
-#pragma unroll
-                    for (int j = 0; j < TP; ++j) bf[j] = *(const half8*)(pb2 + j * (RW * 128));
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int j = 0; j < TP; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
-                }
-            }
-        }
-        lds_barrier();                       // every wave is done with the patch and the weight buffers
-
-        // ---- the next tile's first patch chunk lands under this tile's epilogue ----
-        const int nvb = vb + (int)gridDim.x;
-        int nn0 = 0, nctile = 0;
-        const bool more = nvb < n_tiles;
-        if (more) {
-            xcd_tile_map(nvb, n_ptiles, n_ctiles, nn0, nctile, a.xcd_split);
-            ISSUE_PATCH_T((nn0 % a.in_mod) * HWC, 0);
-        }
-        // ---- epilogue: BN + ReLU on the accumulators, fp16 through the 32 KB of the weight buffers, two rounds of 128 pixels ----
-        _Float16* const orow = a.out + (size_t)n0 * (TH * TW) * a.Cout + ch0;
-        const int k = tid & 15;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            if (rr) lds_barrier();            // round 0's reads are done
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c4 = ch0 + wc * 64 + 16 * i + 4 * kq;
-                const f32x4_e sc = *(const f32x4_e*)(bn_scale + c4), bi = *(const f32x4_e*)(bn_bias + c4);
-                const int cq = wc * 8 + 2 * i + (kq >> 1);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int p = wp * 64 + jj * 16 + r;                       // pixel inside the round
-                    half4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][4 * rr + jj][e] * sc[e] + bi[e];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        o[e] = a16_from_f32<BF>(v);
-                    }
-                    *(half4*)(E + p * 256 + ((cq ^ r) << 4) + (((kq ^ jj) & 1) << 3)) = o;
-                }
-            }
-            lds_barrier();
-            half8_e o8[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int pl = (tid >> 4) + 16 * it;
-                o8[it] = *(const half8_e*)(E + pl * 256 + ((k ^ (pl & 15)) << 4));
-            }
-            if (rr == 1) {
-                lds_barrier();                // round 1's reads are done: the weight buffers are free
-                if (more) LOAD_W_T(a.wgt + (size_t)(nctile * BC) * Ktot, 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int pl = (tid >> 4) + 16 * it;
-                const int p = (pl >> 6) * 128 + rr * 64 + (pl & 63);           // tile pixel = oy * 16 + ox
-                half8_e v = o8[it];
-                if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
-                *(half8_e*)(orow + (size_t)p * a.Cout + 8 * k) = v;
-            }
-        }
-        first = false;
-        vb = nvb; n0 = nn0; ctile = nctile;
-    }
-#undef ISSUE_PATCH_T
-#undef LOAD_W_T
-#undef PSW
-}
-
-int& opt_patch_persist() { static int v = 1; return v; }
-
 template <int TH, int TW, int IMGS, int TJ>
 static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
@@ -593,29 +338,6 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     if (a.in2_bits && (ms != 16 || TW != 16)) return BMI_ERR_UNSUPPORTED;   // keep bits on the shortcut's input: the 16x16-map, 16x16x32 form
     if (a.lazy_planar && (!a.in2_bits || (a.W2 & 1) || a.Cin2 % 32 != 0)) return BMI_ERR_UNSUPPORTED;
     const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, ms) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
-    if constexpr (TH == 16 && TW == 16 && IMGS == 1) {
-        // the persistent form: plain-epilogue launches of the 16x16 class with enough tiles for two rounds per workgroup slot.  The rule looks
-        // at the engine's planned image count (n_ref) like every selection rule; the bits are conv3x3_patch_kernel's either way.
-        static const int n_cu = [] {
-            int dev = 0, cu = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
-            return cu > 0 ? cu : 256;
-        }();
-        const long tiles_sel = (long)(a.n_ref > 0 ? a.n_ref : a.N) * (a.Cout / 128);
-        if (opt_patch_persist() && epi == BMI_EPI_PLAIN && ms == 16 && !a.imap && a.Cout <= 256 && a.in_mod >= 1 &&
-            (opt_patch_persist() == 2 || tiles_sel >= 4L * n_cu) && (size_t)a.in_mod * a.H * a.W * a.Cin < 0x7fffffffull) {
-            const dim3 pgrid((unsigned)(tiles < 2L * n_cu ? tiles : 2L * n_cu)), pblock(256);
-            if (a.in2) {
-                if (a.bf16) hipLaunchKernelGGL((conv3x3_patch16p_kernel<true, true>), pgrid, pblock, 0, s, a, (int)tiles);
-                else hipLaunchKernelGGL((conv3x3_patch16p_kernel<false, true>), pgrid, pblock, 0, s, a, (int)tiles);
-            } else {
-                if (a.bf16) hipLaunchKernelGGL((conv3x3_patch16p_kernel<true, false>), pgrid, pblock, 0, s, a, (int)tiles);
-                else hipLaunchKernelGGL((conv3x3_patch16p_kernel<false, false>), pgrid, pblock, 0, s, a, (int)tiles);
-            }
-            BMI_CHECK_LAUNCH();
-            return BMI_OK;
-        }
-    }
     const dim3 grid((unsigned)tiles), block(256);
 #define PATCH_LAUNCH(EPI_, MS_, BF_, IMAP_) \
     hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, EPI_, MS_, BF_, IMAP_>), grid, block, 0, s, a)
