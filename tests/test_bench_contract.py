@@ -24,11 +24,17 @@ def test_bench_prints_the_contract_line():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f16" and "workload" in d["config"]
     assert d["value"] > 1e5 and abs(d["value"] - 250 * 100 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    # the median of the timed steps beside the mean (completion events on the steps' own streams)
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"] and 0.5 < d["ms_per_step_median"] / d["ms_per_step"] < 1.5
+    assert "plumbing" in d["ece_note"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and rf["unit"] == "TFLOP/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 300 and rf["kernel"] in rf["by_kernel"]
     assert rf["all_conv_launches"]["frac"] > 0.3 and rf["whole_step"]["frac"] > 0.3
     assert set(rf["by_kernel"]) >= {"conv3x3_patch_kernel", "conv3x3_pw_kernel", "conv3x3_s2_kernel"}
+    assert "fabric bytes" in rf["traffic_unit"]
+    if rf["traffic"] is not None:            # the committed PMC figure is quoted: it can only be >= what the launches were priced at
+        assert rf["traffic"] >= 0.95 * rf["algorithmic_bytes_per_launch"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_mean_diff_gpu_vs_cpu"] < 1e-3
 

@@ -285,3 +285,29 @@ def test_exact_engine_on_the_unpinned_configs(cls, ocls, kw, B, T):
     print(f"{cls.__name__} exact engine: B={B} T={T} max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
     assert err_m <= PROB_TOL and err_v <= PROB_TOL
     assert float(np.abs(r["logit_mean"].cpu().numpy() - ref["logit_mean"]).max()) <= LOGIT_TOL * max(1.0, float(np.abs(ref["logits"]).max()) / 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,T,cnt0", [
+    (dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10), 3, 0),                                          # BASELINE configs[2]
+    (dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=100, mask_type="mask", num_masks=8, mask_scale=4.0), 3, 6),   # configs[3], mask wrap-around
+], ids=["resnet18_block_exit", "resnet18_masksembles_m8_c100"])
+def test_exact_engine_at_the_reference_batch(kw, T, cnt0):
+    """The two reference-pinned BASELINE configs at the reference's REAL test batch (B = 250, hyperparameters.py:265-266) on the exact engine
+    against the fp32 CPU oracle: the twins of tests/test_full_batch.py::test_real_batch_against_oracle (fp16: 3.6e-4 / 1.1e-5) at 2e-5."""
+    from oracle import resnet18 as oresnet
+    B, seed = 250, 42
+    m, o = build_seeded(ResNet18MCEarlyExit, kw), build_seeded(oresnet.ResNet18MCEarlyExit, kw)
+    synthetic_weights_(m, 0)
+    synthetic_weights_(o, 0)
+    if cnt0:
+        for mod in o.modules():
+            if hasattr(mod, "cnt") and hasattr(mod, "masks"):
+                mod.cnt = cnt0
+    x = synthetic_images(B, seed=1234)
+    ref = mcd.mcd_predict(o, x, T, seed)
+    r = _exact(m).engine(torch.device(DEV), max_batch=B).predict(x.to(DEV), T, seed=seed, cnt0=cnt0)
+    err_m = float(np.abs(r["mean"].cpu().numpy() - ref["mean"]).max())
+    err_v = float(np.abs(r["var"].cpu().numpy() - ref["var"]).max())
+    print(f"exact engine, B=250 T={T}: max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
+    assert err_m <= PROB_TOL and err_v <= PROB_TOL
