@@ -139,6 +139,25 @@ def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
         assert ms_lazy < 0.7 * ms_plain                  #  consumers: nothing takes keep bits there and the op runs as before)
 
 
+def test_p_one_drops_everything_like_the_reference():
+    """dropout_p = 1.0 (F.dropout zeroes every element): the drop-all path of every site kernel.  Block sites zero the stage outputs, exit
+    sites the pooled features: every logit is its classifier's bias, the predictive mean softmax(bias) for every image, the variance 0 —
+    as the oracle (and the reference's F.dropout) have it."""
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=1.0, out_dim=10)
+    Bs, T, seed = 16, 2, 3
+    model, o = build_seeded(ResNet18MCEarlyExit, kw), build_seeded(oresnet.ResNet18MCEarlyExit, kw)
+    synthetic_weights_(model, 0)
+    synthetic_weights_(o, 0)
+    x = synthetic_images(Bs, seed=1234)
+    ref = mcd.mcd_predict(o, x, T, seed)
+    r = model.to(DEV).eval().engine(torch.device(DEV), max_batch=Bs).predict(x.to(DEV), T, seed=seed)
+    mean = r["mean"].cpu().numpy()
+    assert np.isfinite(mean).all() and float(np.abs(mean - ref["mean"]).max()) <= 1e-6
+    assert float(r["var"].max()) <= 1e-12
+    bias = torch.softmax(model.linear.bias.detach().double().cpu(), 0).numpy()
+    np.testing.assert_allclose(mean[-1], np.broadcast_to(bias, mean[-1].shape), atol=1e-6)
+
+
 def test_lazy_first_site_with_p_zero_keeps_everything():
     """dropout_p = 0.0: every site resolves to 2 bits per element with threshold 0 — keep all.  The 2-bit fast paths (mask_apply_lb1,
     mask_bits_call<1>) test their fields with bit tricks that only covered thresholds 1..3 and kept HALF the elements (round-3 advisor
