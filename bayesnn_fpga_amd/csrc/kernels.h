@@ -75,8 +75,8 @@ struct ConvArgs {
 //     (c >> 5) * hw * 32 + (y * w + (x & 1) * (w >> 1) + (x >> 1)) * 32 + (c & 31)
 // — 32-channel planes, and inside a row the even columns in front of the odd ones.  A stride-2 reader takes every other column of a
 // row: its 64-byte cells (32 channels) are then CONTIGUOUS, whole 128-byte lines that nobody asks for twice; in NHWC a 32-channel
-// chunk is half of a pixel's line and the other half is requested nine K-steps later (round 3: 6.7 GB of fabric fetch per launch for
-// 33 MB of unique input).  The keep bits follow the same permutation (bit index = element index), so a piece's 16 bytes and its bits
+// chunk is half of a pixel's line and the other half is requested nine K-steps later (rocprofv3 FETCH_SIZE of the headline's pair launch:
+// 6.68 GB in NHWC, 3.67 GB planar = one fetch of each tile's image + the bits).  The keep bits follow the same permutation (bit index = element index), so a piece's 16 bytes and its bits
 // byte stay at "activation byte offset / 16" of each other.
 __host__ __device__ inline long lazy_planar_off(int c, int y, int x, int hw, int w) {
     return (long)(c >> 5) * hw * 32 + ((long)y * w + (x & 1) * (w >> 1) + (x >> 1)) * 32 + (c & 31);
