@@ -311,3 +311,23 @@ def test_exact_engine_at_the_reference_batch(kw, T, cnt0):
     err_v = float(np.abs(r["var"].cpu().numpy() - ref["var"]).max())
     print(f"exact engine, B=250 T={T}: max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
     assert err_m <= PROB_TOL and err_v <= PROB_TOL
+
+
+@pytest.mark.gpu
+def test_layer_trace_reads_both_workspaces():
+    """tools/layer_trace.py (bmi_tensor_info + "ws_no_reuse"): every activation tensor of the fp16 engine against the exact engine on the converted
+    toy CNN — the relative rms error of each layer is fp16 rounding (< 2e-3), the first layers' well under 1e-3, nothing jumps."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "layer_trace.py"), "--model", "converter_cnn", "--batch", "5", "--T", "3"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [ln.split("|")[1].split() for ln in r.stdout.splitlines() if re.match(r"\s+\d+ (stem|conv|mask|maxpool|dense)", ln)]
+    assert len(rows) >= 6
+    rel = [float(x[-1]) for x in rows]
+    assert max(rel) < 2e-3 and rel[0] < 1e-3 and all(v > 0 for v in rel)
+    m = re.search(r"# mean: max\|f16 - exact\| = ([0-9.e+-]+)", r.stdout)
+    assert m and float(m.group(1)) < 1e-3
