@@ -182,6 +182,29 @@ def test_graphed_share_on_the_sharded_path(tmp_path):
     assert np.array_equal(fs[2], fs[1]) and np.array_equal(fs[4], fs[3])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,extra", [(100, []), (8, []), (8, ["--partition", "samples"])], ids=["T100-samples", "T8-images", "T8-one-mask-per-rank"])
+def test_eight_rank_dry_run(tmp_path, T, extra):
+    """The driver's widest launch — eight ranks — end to end in dry run on ONE GPU (gloo, all ranks on cuda:0, a 16-image batch): T = 100
+    splits 13 / 13 / 13 / 13 / 12 / 12 / 12 / 12 samples; T = 8 = ranks goes by images (2 images each) or, forced, one sample (one Masksembles
+    mask of config 4) per rank.  The reduced mean equals the one-rank run to 1e-12."""
+    import numpy as np
+    wl = ["--workload", "resnet18_masksembles"] if T == 8 else []
+    common = [*wl, "--T", str(T), "--batch", "16", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    f1, f8 = str(tmp_path / "m1.npy"), str(tmp_path / "m8.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--dump-mean", f1],
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu", *common, *extra,
+                         "--dump-mean", f8], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    d8 = json.loads([ln for ln in r8.stdout.strip().split("\n") if ln.startswith("{")][0])
+    assert d8["n_gpus"] == 8 and d8["config"]["T"] == T
+    assert ("images over 8 ranks" in d8["config"]["sharding"]) == (T == 8 and not extra)
+    np.testing.assert_allclose(np.load(f8), np.load(f1), rtol=0, atol=1e-12)
+
+
 def test_bench_self_launch_starts_n_ranks_without_a_launcher(tmp_path):
     """CPU box: the launch mechanics alone.  `bench.py --gpus 2` with no WORLD_SIZE in the environment must start two rank
     processes (each then refuses to run without a GPU: the HIP path has no CPU fallback) and pass their failure on.
