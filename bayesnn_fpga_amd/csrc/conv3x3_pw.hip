@@ -549,6 +549,330 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     epilogue_coalesced<4, EPI, 16, BF>(a, *(acc_half*)&acc[4], smem, tid, ch0 + 128, pixmap, offmap);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv3x3_pwp (round 4): conv3x3_pw made PERSISTENT for the launches that finish in the plain epilogue (BN + ReLU, with or without the fused
+// shortcut).  One workgroup per CU walks the tiles and the main loop simply CONTINUES across them: in the last chunk of a tile the K-steps
+// that would prefetch "the next chunk" — the weight stages of steps 0 / 1 (issued at taps 7 / 8) and the pieces of sub-patch 0 (taps
+// 1..ITER_P) — fetch the NEXT TILE's instead, with the unchanged counted-vmcnt schedule; Cin % 64 == 0 makes the last chunk odd, so what it
+// prefetches lands in stages 0 / 1 and sub-patch buffer 0.  The LDS map [W0 | W1 | P0 | W2 | P1 | pad] keeps those three outside the
+// 64 KB [W2 | P1 | pad] the epilogue (conv3x3_s2's: two rounds of 128 pixels per channel half, BN from an LDS table — a global load there
+// would wait for every DMA in flight) and the shortcut's K-steps work in.  A full tile leaves its 16 output stores per thread in flight
+// across the tile boundary (vmcnt(16)).  Why: per-tile fixed cost of conv3x3_pw from its own K = 2304 / 4608 rates (1308 / 1422 TFLOP/s, corrected
+// for the last partial round of tiles): 14-21 K-steps' worth per tile, of which the prologue's HBM round trip and the workgroup hand-over are
+// what a persistent walk removes.  Same K order, same arithmetic, same bits as conv3x3_pw_kernel<TW, PLAIN>.
+template <int TW>
+struct PwpGeom {
+    using G = PwGeom<TW>;
+    static constexpr int WST = G::WST, PBUF = G::PBUF;
+    __host__ __device__ static constexpr int w_off(int st) { return st < 2 ? st * WST : 2 * WST + PBUF; }
+    __host__ __device__ static constexpr int p_off(int b) { return b == 0 ? 2 * WST : 3 * WST + PBUF; }
+    static constexpr int E_OFF = 2 * WST + PBUF;                                        // [W2 | P1 | pad]
+    static constexpr int MAIN_END = 3 * WST + 2 * PBUF;
+    static constexpr int E_END = E_OFF + 65536 > MAIN_END ? E_OFF + 65536 : MAIN_END;
+    static constexpr int BN_OFF = E_END;                                                // fp32 scale[512] | bias[512]
+    static constexpr int LDS_BYTES = BN_OFF + 4096;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int TW, bool BF, bool SHORTCUT>
+__global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_tiles) {
+    using G = PwGeom<TW>;
+    using L = PwpGeom<TW>;
+    constexpr int CT = G::CT, TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
+    constexpr int TI = 4, TP = 8;
+    typedef float accv __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) char smem[L::LDS_BYTES];
+    float* const bn_scale = (float*)(smem + L::BN_OFF);
+    float* const bn_bias = bn_scale + 512;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int g = wave >> 2, wc = (wave >> 1) & 1, wp = wave & 1;
+    const int n_ctiles = a.Cout / CT;
+    const int n_ptiles = (a.N + IMGS - 1) / IMGS;
+    const int Ktot = 9 * a.Cin;
+    const int nC = a.Cin / 32;                                   // even (launcher: Cin % 64 == 0)
+
+    for (int c = tid; c < a.Cout; c += 512) {
+        bn_scale[c] = (a.scale ? a.scale[c] : 1.f) * a.out_mul;
+        bn_bias[c] = a.bias ? a.bias[c] : 0.f;
+    }
+    __syncthreads();   // (no LDS-DMA in flight yet)
+
+    // Every DMA is a buffer_load ... lds through a per-tile buffer descriptor (wave-uniform, SGPRs) with a 32-bit per-lane byte offset that
+    // is computed ONCE per kernel (conv3x3_s2's scheme: with per-tile 64-bit sources the persistent loop spilled 30-60 VGPRs): what a piece
+    // reads is the same for every tile up to the tile's first image, and a lane whose offset lies beyond the descriptor loads ZEROS — the
+    // padding ring, the cells of the pitch, the images of a last tile beyond N.
+    // weights: piece q = tid + 512 i -> row (tid >> 2) + 128 i of the channel tile, position tid & 3 holds chunk pos ^ 2 ((row >> 2) & 1)
+    unsigned woff[G::WROWS];
+#pragma unroll
+    for (int i = 0; i < G::WROWS; ++i) {
+        const int row = (tid >> 2) + 128 * i;
+        woff[i] = 2u * ((unsigned)row * Ktot + (((tid & 3) ^ (((row >> 2) & 1) << 1)) << 3));
+    }
+    const unsigned wbytes = 2u * (unsigned)CT * Ktot;
+    const unsigned HWC = (unsigned)a.H * a.W * a.Cin;
+    constexpr unsigned OOB = 0xfffffff0u;
+    // sub-patch: piece q = tid + 512 i -> cell q >> 2, position q & 3 holds chunk pos ^ 2 (y & 1): byte offset relative to the tile's image 0
+    unsigned pre[G::ITER_P];
+#pragma unroll
+    for (int i = 0; i < G::ITER_P; ++i) {
+        const int q = tid + 512 * i;
+        const int cell = q >> 2, pos = q & 3;
+        const int rowc = cell / PWP, x = cell - rowc * PWP;
+        const int img = rowc / PH, y = rowc - img * PH;
+        const int iy = y - 1, ix = x - 1;
+        const bool ok = cell < G::CELLS && x < PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        pre[i] = ok ? 2u * ((unsigned)img * HWC + (unsigned)((iy * a.W + ix) * a.Cin + ((pos ^ ((y & 1) << 1)) << 3))) : OOB;
+    }
+    __amdgpu_buffer_rsrc_t rs_w, rs_wn, rs_in;
+#define BLDS16(RSRC, VOFF, SOFF, LDSPTR) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((RSRC), (__attribute__((address_space(3))) void*)(LDSPTR), 16, (int)(VOFF), (int)(SOFF), 0, 0)
+#define ISSUE_W(RS, KOFF, ST)                                                                      \
+    {                                                                                              \
+        const unsigned so_ = __builtin_amdgcn_readfirstlane(2u * (unsigned)(KOFF));                \
+        _Pragma("unroll") for (int i = 0; i < G::WROWS; ++i)                                       \
+            BLDS16(RS, woff[i], so_, smem + L::w_off(ST) + (i * 512 + wave * 64) * 16);            \
+    }
+#define ISSUE_P(I, C0, PB) \
+    BLDS16(rs_in, pre[I], __builtin_amdgcn_readfirstlane(2u * (unsigned)(C0)), smem + L::p_off(PB) + ((I) * 512 + wave * 64) * 16)
+#define TILE_RSRC_W(RS, CH0) RS = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wgt + (size_t)(CH0) * Ktot), 0, wbytes, 0x00020000)
+#define TILE_RSRC_IN(N0)                                                                                                      \
+    {                                                                                                                         \
+        const int nimg_ = a.N - (N0) < IMGS ? a.N - (N0) : IMGS;                                                              \
+        rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)(N0) * HWC), 0, 2u * (unsigned)nimg_ * HWC, 0x00020000); \
+    }
+
+    // ---- per-lane fragment geometry (tile-independent) ----
+    const int a_off = (g * 128 + wc * 64 + l16) * 64;
+    const int pbase = wp * 128;
+    const int a_byte = (kq ^ (((l16 >> 2) & 1) << 1)) << 4;
+    const int wave_cell = (G::p_img(pbase) * PH + G::p_oy(pbase)) * PWP + G::p_ox(pbase);
+    int boff[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+        boff[ky] = (wave_cell + (l16 >> 2) * PWP + (l16 & 3)) * 64 + ((kq ^ ((((l16 >> 2) + ky) & 1) << 1)) << 4);
+
+#define RAW_BARRIER()                                  \
+    {                                                  \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_sched_barrier(0);             \
+    }
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+    // (step 0 of a tile that follows a full tile: what step 1 reads — weight stage 1 — was issued BEFORE the previous tile's 16 output stores and
+    //  has landed at the tile's start; only this step's own weight DMA is younger than the stores, so the stores may stay in flight one step longer)
+#define END_OF_STEP_WAIT(TAP)                                                                                  \
+    {                                                                                                          \
+        constexpr int pieces_ = ((TAP) >= 1 && (TAP) <= G::ITER_P ? 1 : 0) + ((TAP) >= 2 && (TAP) <= G::ITER_P + 1 ? 1 : 0); \
+        if ((TAP) == 0 && chunk == 0 && stores16) { WAIT_VM(16 + G::WROWS); }                                  \
+        else if (!last) { WAIT_VM(G::WROWS + pieces_); }                                                       \
+        else if ((TAP) >= 7) { WAIT_VM(0); }                                                                   \
+        else { WAIT_VM(G::WROWS); }                                                                            \
+    }
+    // One K-step (conv3x3_pw's PW_STEP): what it prefetches for "the next chunk" comes from (nx_w, nx_k, nx_p): this tile's next chunk, or
+    // chunk 0 of the next tile
+#define PWP_STEP(TAP)                                                                                          \
+    {                                                                                                          \
+        constexpr int ky_ = (TAP) / 3, kx_ = (TAP) - 3 * ky_;                                                  \
+        const char* ws_ = smem + L::w_off((TAP) % 3) + a_off + a_byte;                                         \
+        const char* pb_ = pb + (ky_ * PWP + kx_) * 64;                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+            if (kk == 0) {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(pb_ + boff[ky_] + G::cell_delta(4 * kk + j) * 64); \
+            if (kk == 0) {                                                                                     \
+                if ((TAP) < 7) { ISSUE_W(rs_w, ((TAP) + 2) * a.Cin + c32, ((TAP) + 2) % 3); }                  \
+                else if (!last) {                                                                              \
+                    if (tile_last) { ISSUE_W(rs_wn, ((TAP) - 7) * a.Cin, ((TAP) + 2) % 3); }                   \
+                    else { ISSUE_W(rs_w, ((TAP) - 7) * a.Cin + c32 + 32, ((TAP) + 2) % 3); }                   \
+                }                                                                                              \
+                if ((TAP) >= 1 && (TAP) <= G::ITER_P && !last) {                                               \
+                    constexpr int i_ = (TAP) >= 1 && (TAP) <= G::ITER_P ? (TAP) - 1 : 0;                       \
+                    ISSUE_P(i_, nx_k, nb);                                                                     \
+                }                                                                                              \
+            }                                                                                                  \
+            if (kk == 1 && g == 1) END_OF_STEP_WAIT(TAP);                                                      \
+            RAW_BARRIER();                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+            __builtin_amdgcn_s_setprio(1);                                                                     \
+            _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+                    acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);                  \
+            __builtin_amdgcn_s_setprio(0);                                                                     \
+            if (kk == 1 && g == 0) END_OF_STEP_WAIT(TAP);                                                      \
+            RAW_BARRIER();                                                                                     \
+        }                                                                                                      \
+    }
+
+    int vb = blockIdx.x;
+    int ptile, ctile;
+    xcd_tile_map(vb, n_ptiles, n_ctiles, ptile, ctile, a.xcd_split);
+    int ch0 = ctile * CT, n0 = ptile * IMGS;
+    TILE_RSRC_W(rs_w, ch0);
+    TILE_RSRC_W(rs_wn, ch0);          // (descriptors are rebuilt, never copied: the opaque type has no host-side copy and the host pass drops the kernel)
+    TILE_RSRC_IN(n0)
+    ISSUE_W(rs_w, 0, 0);
+#pragma unroll
+    for (int i_ = 0; i_ < G::ITER_P; ++i_) { ISSUE_P(i_, 0, 0); }
+    ISSUE_W(rs_w, a.Cin, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    bool stores16 = false;
+    while (true) {
+        const int nvb = vb + (int)gridDim.x;
+        const bool more = nvb < n_tiles;
+        int ch0n = 0, n0n = 0;
+        if (more) {
+            int pt, ct;
+            xcd_tile_map(nvb, n_ptiles, n_ctiles, pt, ct, a.xcd_split);
+            ch0n = ct * CT; n0n = pt * IMGS;
+            TILE_RSRC_W(rs_wn, ch0n);
+        }
+        accv acc[TI][TP];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+        // weight stages 0, 1 and sub-patch 0 have landed; the previous tile's 16 output stores per thread were issued behind them
+        if (!stores16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        RAW_BARRIER();
+        if (g == 1) RAW_BARRIER();          // stagger
+        half8 af[TI], bf[4];
+        for (int chunk = 0; chunk < nC; ++chunk) {
+            const bool tile_last = chunk + 1 == nC;
+            const bool last = tile_last && !more;
+            const int c32 = chunk * 32;
+            const int nb = (chunk + 1) & 1;
+            const char* pb = smem + L::p_off(chunk & 1);
+            const int nx_k = tile_last ? 0 : c32 + 32;
+            // the last chunk of a tile issues no piece of its own tile any more: the input descriptor becomes the next tile's here
+            if (tile_last && more) { TILE_RSRC_IN(n0n) }
+            PWP_STEP(0) PWP_STEP(1) PWP_STEP(2) PWP_STEP(3) PWP_STEP(4) PWP_STEP(5) PWP_STEP(6) PWP_STEP(7) PWP_STEP(8)
+        }
+        if (g == 0) RAW_BARRIER();          // re-align the two groups: every wave is past its last fragment reads
+
+        if constexpr (SHORTCUT) {
+            // fused 1x1 strided shortcut (conv3x3_pw's: Cin2 / 32 lock-step K-steps, two [weights | pixels] stages) in the epilogue's 64 KB
+            const int nC2 = a.Cin2 / 32;
+            constexpr int XROWS = G::PX / 128, SST = G::WST + G::PX * 64;
+            char* const sbase = smem + L::E_OFF;
+            const int lg = ((tid & 3) ^ (((tid >> 4) & 1) << 1)) * 8;
+            int x2off[XROWS];
+#pragma unroll
+            for (int i = 0; i < XROWS; ++i) {
+                const int row = (tid >> 2) + 128 * i;
+                const int n = n0 + G::p_img(row);
+                x2off[i] = n < a.N ? (int)((((size_t)(n % a.in2_mod) * a.H2 + (size_t)G::p_oy(row) * a.stride2) * a.W2 +
+                                            (size_t)G::p_ox(row) * a.stride2) * a.Cin2 + lg)
+                                   : -1;
+            }
+#define ISSUE_S(C2, ST)                                                                                        \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < G::WROWS; ++i)                                                   \
+            GLDS16(a.wgt2 + (size_t)(ch0 + (tid >> 2) + 128 * i) * a.Cin2 + lg + (C2) * 32, sbase + (ST) * SST + (i * 512 + wave * 64) * 16); \
+        _Pragma("unroll") for (int i = 0; i < XROWS; ++i)                                                      \
+            GLDS16(x2off[i] >= 0 ? a.in2 + (size_t)(unsigned)x2off[i] + (C2) * 32 : (const _Float16*)g_zero_page_pw, \
+                   sbase + (ST) * SST + G::WST + (i * 512 + wave * 64) * 16);                                  \
+    }
+            ISSUE_S(0, 0);
+            for (int c2 = 0; c2 < nC2; ++c2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                if (c2 + 1 < nC2) ISSUE_S(c2 + 1, (c2 + 1) & 1);
+                const char* ss = sbase + (c2 & 1) * SST;
+                half8 sa[TI], sb[TP];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) sa[i] = *(const half8*)(ss + a_off + i * 16 * 64 + a_byte);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) sb[j] = *(const half8*)(ss + G::WST + (pbase + 16 * j + l16) * 64 + a_byte);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) acc[i][j] = mfma_16x16x32<BF>(sa[i], sb[j], acc[i][j]);
+            }
+#undef ISSUE_S
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            RAW_BARRIER();
+        }
+
+        // ---- epilogue (conv3x3_s2's): BN + ReLU on the accumulators, fp16 through LDS, 32 KB per channel half, two rounds of 128 pixels ----
+        {
+            char* const E = smem + L::E_OFF + g * 32768;
+            int tl = tid & 255;
+            asm volatile("" : "+v"(tl));
+            const int chl = ch0 + 128 * g;
+            const int k = tl & 15;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr) lds_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c4 = chl + wc * 64 + 16 * i + 4 * kq;
+                    const f32x4_e sc = *(const f32x4_e*)(bn_scale + c4), bi = *(const f32x4_e*)(bn_bias + c4);
+                    const int cq = wc * 8 + 2 * i + (kq >> 1);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int p = wp * 64 + jj * 16 + l16;
+                        half4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][4 * rr + jj][e] * sc[e] + bi[e];
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            o[e] = a16_from_f32<BF>(v);
+                        }
+                        *(half4*)(E + p * 256 + ((cq ^ l16) << 4) + (((kq ^ jj) & 1) << 3)) = o;
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    half8_e o8[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int pl = (tl >> 4) + 16 * (4 * hb + it);
+                        o8[it] = *(const half8_e*)(E + pl * 256 + ((k ^ (pl & 15)) << 4));
+                    }
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int pl = (tl >> 4) + 16 * (4 * hb + it);
+                        const int p = (pl >> 6) * 128 + rr * 64 + (pl & 63);
+                        const int n = n0 + G::p_img(p);
+                        if (n >= a.N) continue;
+                        half8_e v = o8[it];
+                        if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+                        *(half8_e*)(a.out + ((size_t)n * (TH * TW) + G::p_oy(p) * TW + G::p_ox(p)) * a.Cout + chl + 8 * k) = v;
+                    }
+                }
+            }
+            lds_barrier();      // the staging area (W2 | P1) is free again for the next tile's K-steps
+        }
+        stores16 = n0 + IMGS <= a.N;
+        if (!more) break;
+        vb = nvb; ch0 = ch0n; n0 = n0n;
+        TILE_RSRC_W(rs_w, ch0);
+    }
+#undef PWP_STEP
+#undef END_OF_STEP_WAIT
+#undef WAIT_VM
+#undef RAW_BARRIER
+#undef ISSUE_P
+#undef TILE_RSRC_IN
+#undef TILE_RSRC_W
+#undef ISSUE_W
+#undef BLDS16
+}
+
+int& opt_pw_persist() { static int v = 1; return v; }
+
 // Shapes this kernel takes: 3x3 / stride 1 / pad 1 on 8x8 or 4x4 maps with Cout % 256 == 0.
 bool conv_takes_pw_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo) {
     return ksize == 3 && stride == 1 && pad == 1 && cin % 64 == 0 && cout % 256 == 0 && ho == wo && (ho == 8 || ho == 4);
@@ -575,6 +899,25 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
         } else {
             return BMI_ERR_UNSUPPORTED;
         }
+    }
+    if (opt_pw_persist() && opt_conv_pw() < 3 && epi == BMI_EPI_PLAIN && !a.imap && a.Cin % 64 == 0 && a.Cout <= 512 && (!a.in2 || a.Cin2 % 32 == 0) &&
+        a.in_mod >= a.N /* a tile's images are consecutive tensor rows */ && (size_t)a.H * a.W * a.Cin * PwGeom<TW>::IMGS * 2 < 0xfffffff0ull) {
+        // the persistent form (conv3x3_pwp): one workgroup per CU walks the tiles; the same bits
+        static const int n_cu = [] {
+            int dev = 0, cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+            return cu > 0 ? cu : 256;
+        }();
+        const dim3 pgrid((unsigned)(tiles < n_cu ? tiles : n_cu));
+        if (a.in2) {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, true, true>), pgrid, block, 0, s, a, (int)tiles);
+            else hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, false, true>), pgrid, block, 0, s, a, (int)tiles);
+        } else {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, true, false>), pgrid, block, 0, s, a, (int)tiles);
+            else hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, false, false>), pgrid, block, 0, s, a, (int)tiles);
+        }
+        BMI_CHECK_LAUNCH();
+        return BMI_OK;
     }
     if (opt_conv_pw() >= 3 && !a.in2 && !a.imap && !a.bf16 && epi != BMI_EPI_GENERAL && a.Cin % 64 == 0) {   // the four-wave form ("conv_pw" = 3 | 4)
         const dim3 block4(256);

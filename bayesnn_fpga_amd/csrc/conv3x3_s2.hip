@@ -44,6 +44,10 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef S2_RELAX0
+#define S2_RELAX0 0          // 1: the previous tile's 16 output stores may stay in flight through step 0 of the next tile (see END_OF_STEP_WAIT).
+                             // Built and measured in round 4 (same-box A/B on the five stride-2 classes, bit-identical): neutral (+-0.5 %): off
+#endif
 #ifndef S2_DRAIN_STORES
 #define S2_DRAIN_STORES 0    // 1 (diagnostic): every tile starts with vmcnt(0)
 #endif
@@ -485,9 +489,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     // issued this step) and the patch pieces issued this step and the step before; everything older — in particular the next
     // step's weights and every piece issued two or more steps ago — has landed.  In the last chunk no next-chunk piece (steps
     // 5-8) and no weights beyond the tile's last step (steps 7, 8) are issued.
+    // (Step 0 of a tile that follows a full tile, round 4: everything step 1 reads — weight stage 1, the A / B pieces — was issued BEFORE the
+    //  previous tile's 16 output stores and has landed at the tile's start; only this step's own DMAs are younger than the stores, which may
+    //  therefore stay in flight one step longer.)
 #define END_OF_STEP_WAIT(S)                                                                                    \
     {                                                                                                          \
-        if (!last) { WAIT_VM(G::wait_n(S, false)); }                                                           \
+        if (S2_RELAX0 && (S) == 0 && chunk == 0 && stores16 && !IMAP && !S2_DRAIN_STORES) { WAIT_VM(16 + G::wait_n(0, false)); } \
+        else if (!last) { WAIT_VM(G::wait_n(S, false)); }                                                      \
         else { WAIT_VM(G::wait_n(S, true)); }                                                                  \
     }
     // One K-step = step S of the chunk's period (one tap x this chunk's 32 channels).  Two phases (LOAD part, barrier, MFMA part,

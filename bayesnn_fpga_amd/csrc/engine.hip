@@ -207,6 +207,11 @@ int bmi_set_option(const char* name, int32_t value) {
         opt_unit_dtype() = value;
         return BMI_OK;
     }
+    if (std::strcmp(name, "pw_persist") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_pw_persist() = value;
+        return BMI_OK;
+    }
     if (std::strcmp(name, "lazy_planar") == 0) {
         if (value != 0 && value != 1) return BMI_ERR_INVALID;
         opt_lazy_planar() = value;

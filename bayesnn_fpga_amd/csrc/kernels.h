@@ -145,6 +145,7 @@ int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t,
 int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s, int planar_w = 0);
 // out = round16(in * scale); planar_w > 0: images of planar_hw pixels x planar_c channels stored in the planar layout
 int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, int bf16, hipStream_t s, int planar_hw = 0, int planar_w = 0, int planar_c = 0);
+int& opt_pw_persist();         // 1: plain-epilogue launches of conv3x3_pw run in its persistent form (conv3x3_pwp_kernel), 0: never
 int& opt_lazy_planar();        // 1: lazy sites whose readers are all stride-2 consumers store their scaled copy + bits in the planar layout
 int launch_splitk_finish(const ConvArgs& a, hipStream_t s);   // after a split-K conv_igemm launch
 int launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);

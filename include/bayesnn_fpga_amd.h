@@ -173,6 +173,10 @@ const char* bmi_error_string(int code);
  *                                           keep bits + one scaled copy of the B images; conv3x3_s2 / conv3x3_patch (fused shortcut input) clear the
  *                                           dropped elements in LDS, any other consumer makes the masked tensor appear first (1, default), or the
  *                                           masked tensor is always written (0); the same bits either way
+ *   "pw_persist"                            0 | 1: plain-epilogue launches of conv3x3_pw (BN + ReLU, with or without the fused shortcut) run in its
+ *                                           persistent form — one workgroup per CU walks the tiles, the last chunk of a tile prefetches the next tile's
+ *                                           first weight stages and sub-patch, the epilogue stages through 64 KB beside them (1, default: -3..-5 % per
+ *                                           launch) — or one workgroup per tile (0); the same bits either way
  *   "lazy_planar"                           0 | 1: a lazy site whose readers are all stride-2 consumers (conv3x3_s2 on 32x32 maps, the fused 1x1
  *                                           stride-2 shortcut of conv3x3_patch) stores its scaled copy and keep bits as 32-channel planes with
  *                                           the even columns of a row in front of the odd ones — what such a reader DMAs is then contiguous,

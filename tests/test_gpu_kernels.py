@@ -433,6 +433,46 @@ def test_conv_pair_one_launch_two_outputs(cin, ca, cb, H, k, s, p, n, in_mod):
         assert torch.equal(alone, outs[i])
 
 
+@pytest.mark.parametrize("name,n,shortcut,dt", [("S3", 1031, False, "f16"), ("S4", 4101, False, "f16"), ("S3", 1500, True, "f16"), ("S4", 4500, True, "f16"),
+                                                ("S3", 2050, False, "bf16"), ("S4", 5000, True, "bf16"), ("S4", 37, False, "f16")])
+def test_persistent_pw_equals_the_per_tile_kernel_bit_for_bit(name, n, shortcut, dt):
+    """conv3x3_pwp (round 4): conv3x3_pw's plain-epilogue launches as ONE persistent workgroup per CU whose main loop continues across tiles (the
+    last chunk of a tile prefetches the next tile's first weight stages and sub-patch, the epilogue runs in two 32 KB rounds beside them).  Same K
+    order and arithmetic: identical bits — several tiles per CU (1031 / 4 = 258 tiles ... 4500 / 16 x 2), ragged last tiles, with and without the
+    fused shortcut, fp16 and bf16, and fewer tiles than CUs (n = 37)."""
+    lib = _lib.lib()
+    cin, cout, H, k, s, p = SHAPES[name]
+    g = _gen(17)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    x = torch.randn(n, H, H, cin, generator=g).to(tdt).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(tdt).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    x2 = torch.randn(n, 2 * H, 2 * H, cin // 2, generator=g).to(tdt).to(DEV) if shortcut else None
+    w2 = (torch.randn(cout, cin // 2, generator=g) * (2.0 / cin) ** 0.5).to(tdt).to(DEV) if shortcut else None
+    if dt == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    _lib.set_option("conv_pw", 2)                       # (no minimum-grid rule: n = 37 too)
+    outs = []
+    try:
+        for persist in (0, 1):
+            _lib.set_option("pw_persist", persist)
+            out = torch.full((n, H, H, cout), float("nan"), dtype=tdt, device=DEV)
+            if shortcut:
+                _lib.check(lib.bmi_conv3x3_shortcut_fwd(gh.ptr(x), gh.ptr(w), gh.ptr(x2), gh.ptr(w2), gh.ptr(bias), gh.ptr(out), n, H, H, cin, cout, cin // 2, 1,
+                                                        gh.stream()), "bmi_conv3x3_shortcut_fwd")
+            else:
+                _lib.check(lib.bmi_conv_igemm_fwd(gh.ptr(x), None, 1.0, gh.ptr(w), gh.ptr(scale), gh.ptr(bias), None, gh.ptr(out), n, n, n, H, H, cin, cout, k, s, p, 1,
+                                                  None, n, 0, 0, 0, gh.stream()), "bmi_conv_igemm_fwd")
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        _lib.set_option("pw_persist", 1)
+        _lib.set_option("conv_pw", 1)
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_conv_pair_rejects_bad_splits():
     lib = _lib.lib()
     z = torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=DEV)
