@@ -41,12 +41,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // thread fetches the keep byte of each pixel piece it DMAs and clears the dropped elements of ITS 16 bytes in LDS between the K-step's
 // wait and its barrier (the K-steps are lock-step with a full vmcnt(0) anyway).
 template <int EPI, bool BF, int TJ = 4, bool MSK = false>
-__global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == BMI_EPI_LITE) || STREAM_KD == 128 ? 2 : 3)) void conv1x1_stream_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_epilogue_is_lite(EPI)) || STREAM_KD == 128 ? 2 : 3)) void conv1x1_stream_kernel(ConvArgs a) {
     static_assert(!MSK || (TJ == 2 && STREAM_KD == 64), "masked input: the default form only");
     constexpr int SBP = 64 * TJ;
     constexpr int NSUB = TJ == 2 ? STREAM_KD / 64 : 1;
     constexpr int SUB = (TJ == 4 ? BMI_EPILOGUE_LDS_BYTES : BMI_EPILOGUE_LDS_BYTES / 2);     // one [weights | pixels] sub-tile = the epilogue's tile
-    constexpr bool RPRE = STREAM_RES_PREFETCH && EPI == BMI_EPI_LITE && TJ == 2 && NSUB == 1;
+    constexpr bool RPRE = STREAM_RES_PREFETCH && conv_epilogue_is_lite(EPI) && TJ == 2 && NSUB == 1;
     __shared__ __attribute__((aligned(16))) char smem[NSUB * SUB + (RPRE ? SUB : 0)];
     constexpr int XBASE = SBC * 128;   // pixel tile behind the weight tile
     const int tid = threadIdx.x;
@@ -71,16 +71,34 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
     for (int i = 0; i < 4; ++i) wsrc[i] = a.wgt + (size_t)(ch0 + 32 * i + rowt) * a.Cin + srcchunk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) GLDS16(wsrc[i], smem + (i * 256 + wave * 64) * 16);
+    // Input row of output pixel m.  The general map costs three integer divisions per piece (pixel -> image, row, image % in_mod) — with
+    // the residual rows of the epilogue, a third of this kernel's instructions.  Two launch-uniform shortcuts cover every launch of the
+    // path: (1) stride 1 on a tensor with an image per output image: the row IS m; (2) a tile inside ONE image (Ho Wo % tile == 0: the
+    // 32x32 / 16x16 maps): the image comes from one scalar division per workgroup, and row / column from nothing (stride 1) or a shift
+    // (Wo a power of two).
+    const bool lin_in = a.stride == 1 && a.in_mod >= a.N;
+    const bool one_img = HoWo % SBP == 0 && (a.stride == 1 || (a.Wo & (a.Wo - 1)) == 0);
+    const int n_tile = pix0 / HoWo, rem_tile = pix0 - n_tile * HoWo;     // (scalar)
+    const int wo_log2 = 31 - __builtin_clz(a.Wo);
 #pragma unroll
     for (int i = 0; i < 2 * TJ; ++i) {
         const int m = pix0 + 32 * i + rowt;
         const int mm = m < a.M ? m : 0;               // rows beyond the tensor read pixel 0: computed, never stored
-        const int n = mm / HoWo;
-        const int rem = mm - n * HoWo;
-        const int oy = rem / a.Wo;
-        const int ox = rem - oy * a.Wo;
-        xsrc[i] = a.in + ((size_t)(n % a.in_mod) * a.H * a.W + (size_t)(oy * a.stride) * a.W + ox * a.stride) * a.Cin + srcchunk;
-        if constexpr (MSK) bsrc[i] = m < a.M ? (int)((((size_t)n * a.H + (size_t)(oy * a.stride)) * a.W + ox * a.stride) * (a.Cin >> 3) + (srcchunk >> 3)) : -1;
+        if (lin_in && !MSK) {
+            xsrc[i] = a.in + (size_t)mm * a.Cin + srcchunk;
+        } else if (one_img) {                         // (M is a multiple of Ho Wo: the whole tile lies inside the tensor)
+            const int rem = rem_tile + 32 * i + rowt;
+            const int pix_in = a.stride == 1 ? rem : ((rem >> wo_log2) * a.stride) * a.W + (rem & (a.Wo - 1)) * a.stride;
+            xsrc[i] = a.in + ((size_t)(n_tile % a.in_mod) * a.H * a.W + pix_in) * a.Cin + srcchunk;
+            if constexpr (MSK) bsrc[i] = (int)(((size_t)n_tile * a.H * a.W + pix_in) * (a.Cin >> 3) + (srcchunk >> 3));
+        } else {
+            const int n = mm / HoWo;
+            const int rem = mm - n * HoWo;
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            xsrc[i] = a.in + ((size_t)(n % a.in_mod) * a.H * a.W + (size_t)(oy * a.stride) * a.W + ox * a.stride) * a.Cin + srcchunk;
+            if constexpr (MSK) bsrc[i] = m < a.M ? (int)((((size_t)n * a.H + (size_t)(oy * a.stride)) * a.W + ox * a.stride) * (a.Cin >> 3) + (srcchunk >> 3)) : -1;
+        }
     }
     uint32_t kb[MSK ? 2 * TJ : 1];
 #define LOAD_KB(KS)                                                                               \
@@ -121,8 +139,11 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
             for (int i = 0; i < 4 * TJ; ++i) {
                 const int q = i * 256 + tid, p = q >> 4, pos = q & 15;
                 const int m = pix0 + p;
-                const _Float16* src = m < a.M ? a.res + ((size_t)((m / HoWo) % a.res_mod) * HoWo + (m % HoWo)) * a.Cout + ch0 + ((pos ^ (p & 15)) << 3)
-                                              : a.res;
+                const _Float16* src;
+                if constexpr (conv_epilogue_is_lite(EPI) && EPI != BMI_EPI_LITE)   // (one residual row per output row)
+                    src = m < a.M ? a.res + (size_t)m * a.Cout + ch0 + ((pos ^ (p & 15)) << 3) : a.res;
+                else
+                    src = m < a.M ? a.res + ((size_t)((m / HoWo) % a.res_mod) * HoWo + (m % HoWo)) * a.Cout + ch0 + ((pos ^ (p & 15)) << 3) : a.res;
                 GLDS16(src, smem + SUB + (i * 256 + wave * 64) * 16);
             }
         }
@@ -185,6 +206,11 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
 
     auto pixmap = [&](int p, int& n, int& rem) -> bool {
         const int m = pix0 + p;
+        if (HoWo % SBP == 0) {                        // the tile lies inside one image
+            n = n_tile;
+            rem = rem_tile + p;
+            return true;
+        }
         n = m / HoWo;
         rem = m - n * HoWo;
         return m < a.M;
@@ -193,7 +219,8 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && EPI == 
         off = (size_t)(pix0 + p) * a.Cout;
         return pix0 + p < a.M;
     };
-    if constexpr (RPRE) epilogue_lite<TJ, BF, true>(a, acc, smem + SUB, tid, ch0, pixmap, offmap);
+    constexpr int SK = EPI == BMI_EPI_LITE_RES ? BMI_SITE_NONE : (EPI == BMI_EPI_LITE_RES_MC ? BMI_SITE_ELEMENTWISE : -1);
+    if constexpr (RPRE) epilogue_lite<TJ, BF, true, false, SK>(a, acc, smem + SUB, tid, ch0, pixmap, offmap);
     else epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
 }
 
@@ -220,7 +247,7 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
     }();
     const long tiles_sel = a.n_ref > 0 ? (((long)a.n_ref * a.Ho * a.Wo + SBP - 1) / SBP) * (a.Cout / SBC) : tiles;
     if (opt_conv_stream() != 2 && tiles_sel < (n_cu > 0 ? 3 * n_cu / 2 : 384)) return BMI_ERR_UNSUPPORTED;
-    const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+    const int epi = opt_epilogue_lite() ? conv_epilogue_kind_launch(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
     // (the general epilogue — Masksembles / channel sites, 4-16-bit probabilities — spills 16 VGPRs next to this kernel's twelve
     //  DMA row pointers: those launches stay with conv_igemm_wide)
     if (epi == BMI_EPI_GENERAL) return BMI_ERR_UNSUPPORTED;
@@ -238,6 +265,8 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
             else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_, 2, true>), grid, block, 0, s, a);                 \
         } else if (SBP == 128) {                                                                                                       \
             if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_, 2>), grid, block, 0, s, a); \
+            else if (epi == BMI_EPI_LITE_RES) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE_RES, BF_, 2>), grid, block, 0, s, a); \
+            else if (epi == BMI_EPI_LITE_RES_MC) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE_RES_MC, BF_, 2>), grid, block, 0, s, a); \
             else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_, 2>), grid, block, 0, s, a);                       \
         } else if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_PLAIN, BF_>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((conv1x1_stream_kernel<BMI_EPI_LITE, BF_>), grid, block, 0, s, a);                              \

@@ -355,6 +355,17 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
         } else {
             return BMI_ERR_UNSUPPORTED;
         }
+    } else if (ms == 16 && TH == 16 && TW == 16 && epi == BMI_EPI_LITE && conv_epilogue_kind_launch(a, 16) != BMI_EPI_LITE) {
+        // the BasicBlock tails of the 16x16 maps: the lite epilogue with its launch-uniform terms compiled in (conv_epilogue.h; same bits)
+        if constexpr (TH == 16 && TW == 16) {
+            if (conv_epilogue_kind_launch(a, 16) == BMI_EPI_LITE_RES) {
+                if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES, 16, true, false);
+                else PATCH_LAUNCH(BMI_EPI_LITE_RES, 16, false, false);
+            } else {
+                if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES_MC, 16, true, false);
+                else PATCH_LAUNCH(BMI_EPI_LITE_RES_MC, 16, false, false);
+            }
+        }
     } else if (a.bf16) {
         PATCH_LAUNCH_EPI16(true, false)
     } else if (ms == 16) {     // bmi_set_option / BMI_MFMA_SHAPE; default chosen by measured wall time

@@ -886,6 +886,7 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)tiles), block(512);
     const int epi = opt_epilogue_lite() ? conv_epilogue_kind(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+    const int epi_fine = opt_epilogue_lite() && !a.imap && opt_conv_pw() < 3 ? conv_epilogue_kind_launch(a, 16) : epi;   // (the specialised lite forms: same bits)
     if (a.pool) {   // fp32 means over the 4x4 map instead of the map (the conv feeds one exit head only): the lite epilogue on the registers
         if constexpr (TW == 4) {
             if (epi == BMI_EPI_GENERAL) return BMI_ERR_UNSUPPORTED;
@@ -923,6 +924,17 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
         const dim3 block4(256);
         if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv3x3_pw4_kernel<TW, BMI_EPI_PLAIN, false, false>), grid, block4, 0, s, a);
         else hipLaunchKernelGGL((conv3x3_pw4_kernel<TW, BMI_EPI_LITE, false, false>), grid, block4, 0, s, a);
+        BMI_CHECK_LAUNCH();
+        return BMI_OK;
+    }
+    if (epi_fine == BMI_EPI_LITE_RES || epi_fine == BMI_EPI_LITE_RES_MC) {
+        if (epi_fine == BMI_EPI_LITE_RES) {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES, true, false>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES, false, false>), grid, block, 0, s, a);
+        } else {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES_MC, true, false>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES_MC, false, false>), grid, block, 0, s, a);
+        }
         BMI_CHECK_LAUNCH();
         return BMI_OK;
     }

@@ -318,6 +318,13 @@ __device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px
 #define BMI_EPI_GENERAL 0   // anything: two fp32 rounds through LDS (epilogue_coalesced)
 #define BMI_EPI_PLAIN 1     // BN + ReLU (epilogue_plain)
 #define BMI_EPI_LITE 2      // BN + residual + ReLU + elementwise 2-bit or Masksembles site, one fp16 trip through LDS (epilogue_lite)
+// The lite epilogue with its launch-uniform terms as COMPILE-TIME constants (same arithmetic, same bits).  As run-time values hipcc
+// if-converts them inside the 64-128 times unrolled element loop: every element of a launch without a site still executes the
+// compare / select / multiply of both site kinds (2 + 3 vector instructions), and a residual row costs two integer divisions
+// (pixel -> image, image % res_mod).  On conv1x1_stream's Bottleneck tails that is most of the instruction stream: 3 400 instructions
+// per 128 x 128 tile against 64 MFMAs, twelve waves per CU issuing 36 % of their cycles each — the kernel was issue-bound, not HBM-bound.
+#define BMI_EPI_LITE_RES 3      // residual with one row per output row (res_mod >= N), ReLU, no site
+#define BMI_EPI_LITE_RES_MC 4   // ... and the elementwise 2-bit MC-dropout site
 __host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_shape) {
     if (conv_epilogue_is_plain(a)) return BMI_EPI_PLAIN;
     const bool site_ok = a.site.kind == BMI_SITE_NONE || a.site.kind == BMI_SITE_MASKSEMBLE ||
@@ -325,6 +332,18 @@ __host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_sh
     if (mfma_shape == 16 && site_ok && !a.site_inner && !a.bias_post) return BMI_EPI_LITE;
     return BMI_EPI_GENERAL;
 }
+// ... for the kernels that instantiate the specialised forms (the others keep BMI_EPI_LITE)
+__host__ __device__ inline int conv_epilogue_kind_fine(const ConvArgs& a, int mfma_shape) {
+    const int k = conv_epilogue_kind(a, mfma_shape);
+    if (k != BMI_EPI_LITE || !a.res || a.res_mod < a.N || a.pool || !a.relu) return k;
+    if (a.site.kind == BMI_SITE_NONE) return BMI_EPI_LITE_RES;
+    if (a.site.kind == BMI_SITE_ELEMENTWISE) return BMI_EPI_LITE_RES_MC;
+    return k;
+}
+inline int conv_epilogue_kind_launch(const ConvArgs& a, int mfma_shape) {   // host: "epilogue_lite" = 2 keeps the unspecialised form (A/B)
+    return opt_epilogue_lite() == 2 ? conv_epilogue_kind(a, mfma_shape) : conv_epilogue_kind_fine(a, mfma_shape);
+}
+__host__ __device__ constexpr bool conv_epilogue_is_lite(int epi) { return epi == BMI_EPI_LITE || epi == BMI_EPI_LITE_RES || epi == BMI_EPI_LITE_RES_MC; }
 
 // "Lite" general epilogue (16x16x32 accumulators): the common non-plain launch of the path is a BasicBlock tail — BN,
 // residual add, ReLU, and (p = 0.25 MC-dropout) an elementwise site drawn at 2 bits per element.  epilogue_coalesced
@@ -347,15 +366,19 @@ __host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_sh
 // POOL (conv3x3_pw on 4x4 maps, ConvArgs::pool): the 16 pixels of an accumulator tile are one image; instead of the fp16 map the
 // launch stores fp32 means over the map, [row][Cout] — the tile's 16 lanes are a DPP row: four v_add_f32 with DPP modifiers leave the
 // sum in every lane, lane 0 stores 4 consecutive channels.  The conv feeds nothing but an exit head (relu -> avg_pool2d(4) -> Linear).
-template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, class ACC, class PixMap, class OffMap>
+// SK: the site kind as a compile-time constant (BMI_SITE_NONE | BMI_SITE_ELEMENTWISE), or -1 = whatever the launch carries.  SK >= 0
+// also says the launch HAS a residual whose rows are the output's rows (BMI_EPI_LITE_RES / _RES_MC): its address comes from `offmap`.
+template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, int SK = -1, class ACC, class PixMap, class OffMap>
 __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
                                               PixMap pixmap, OffMap offmap) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wp = wave & 1;
     const int l16 = lane & 15, q4 = lane >> 4;
     const int HoWo = a.Ho * a.Wo;
-    const bool masked = a.site.kind == BMI_SITE_ELEMENTWISE;
-    const bool msk = a.site.kind == BMI_SITE_MASKSEMBLE;      // Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M
+    const bool masked = SK >= 0 ? SK == BMI_SITE_ELEMENTWISE : a.site.kind == BMI_SITE_ELEMENTWISE;
+    const bool msk = SK >= 0 ? false : a.site.kind == BMI_SITE_MASKSEMBLE;      // Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M
+    const bool has_res = SK >= 0 ? true : a.res != nullptr;
+    const bool relu = SK >= 0 ? true : a.relu != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c4 = ch0 + wc * 64 + 16 * i + 4 * q4;
@@ -369,14 +392,20 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
             for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * sc[e] + bi[e];
     }
     lds_barrier();   // the main loop is done with the LDS
-    if (a.res && !RES_IN_LDS) {
+    if (has_res && !RES_IN_LDS) {
 #pragma unroll
         for (int i = 0; i < 4 * TJ; ++i) {
             const int q = i * 256 + tid, p = q >> 4, pos = q & 15;
-            int n, rem;
-            const bool ok = pixmap(p, n, rem);
-            const _Float16* src = ok ? a.res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout + ch0 + ((pos ^ (p & 15)) << 3)
-                                     : a.res;   // rows beyond the tensor are never stored
+            const _Float16* src;
+            if constexpr (SK >= 0) {
+                size_t off;
+                src = offmap(p, off) ? a.res + off + ch0 + ((pos ^ (p & 15)) << 3) : a.res;
+            } else {
+                int n, rem;
+                const bool ok = pixmap(p, n, rem);
+                src = ok ? a.res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout + ch0 + ((pos ^ (p & 15)) << 3)
+                         : a.res;   // rows beyond the tensor are never stored
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
         }
@@ -397,7 +426,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
 #pragma unroll
     for (int jb = 0; jb < 2 * TJ; jb += 4) {
         half4 r4[4][4];
-        if (a.res) {
+        if (has_res) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -432,8 +461,8 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[i][j][e];
-                    if (a.res) v += a16_to_f32<BF>(r4[jj][i][e]);
-                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (has_res) v += a16_to_f32<BF>(r4[jj][i][e]);
+                    if (relu) v = fmaxf(v, 0.f);
                     if (masked) v = ((fields >> (2 * e)) & 3u) >= a.site.thresh ? v * a.site.scale : 0.f;
                     if (msk) v = mk[e] == 0.f ? 0.f : v * mk[e];
                     asm("" : "+v"(v));   // keep the fp32 product: fused into v_fma_mixlo_f16 it is rounded once instead of twice,
@@ -490,9 +519,10 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, 
         epilogue_plain<TJ, MS, BF>(a, acc, lds, tid, ch0, offmap);
         return;
     }
-    if constexpr (EPI == BMI_EPI_LITE) {
+    if constexpr (conv_epilogue_is_lite(EPI)) {
         static_assert(MS == 16, "the lite epilogue reads the 16x16x32 accumulator layout");
-        epilogue_lite<TJ, BF>(a, acc, lds, tid, ch0, pixmap, offmap);
+        constexpr int SK = EPI == BMI_EPI_LITE_RES ? BMI_SITE_NONE : (EPI == BMI_EPI_LITE_RES_MC ? BMI_SITE_ELEMENTWISE : -1);
+        epilogue_lite<TJ, BF, false, false, SK>(a, acc, lds, tid, ch0, pixmap, offmap);
         return;
     }
     constexpr int NR = TJ / 2;

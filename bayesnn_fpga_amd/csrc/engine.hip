@@ -268,7 +268,7 @@ int bmi_set_option(const char* name, int32_t value) {
         return BMI_OK;
     }
     if (std::strcmp(name, "epilogue_lite") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        if (value != 0 && value != 1 && value != 2) return BMI_ERR_INVALID;
         opt_epilogue_lite() = value;
         return BMI_OK;
     }

@@ -187,9 +187,10 @@ const char* bmi_error_string(int code);
  *   "dense_exact"                           0 | 1: hidden dense layers (BMI_OP_DENSE / bmi_dense_f32) on the exact-f32 MFMA (1) or as
  *                                           fp16 head + tail products on the fp16 MFMA with fp32 accumulation (0, default: fp32-equivalent
  *                                           to a few 1e-7, 2.5x faster)
- *   "epilogue_lite"                         0 | 1: BN + residual + ReLU + 2-bit elementwise-site launches finish on the accumulator
- *                                           registers with one fp16 trip through LDS (1, default) or in the general two-round fp32
- *                                           epilogue (0); the same bits either way
+ *   "epilogue_lite"                         0 | 1 | 2: BN + residual + ReLU + 2-bit elementwise-site launches finish on the accumulator
+ *                                           registers with one fp16 trip through LDS (1, default; 2: without the forms that have the
+ *                                           site kind and the residual compiled in) or in the general two-round fp32 epilogue (0);
+ *                                           the same bits every way
  *   "wide_persist_min_x10"                  10..1000: conv_igemm_wide runs persistent (one workgroup per CU walking the tiles)
  *                                           when tiles * 10 > value * CUs
  *   "unit_entry_dtype"                      BMI_DTYPE_*: how the single-kernel entry points below (unit tests) interpret
