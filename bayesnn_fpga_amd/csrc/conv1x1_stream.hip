@@ -34,6 +34,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef STREAM_RES_PREFETCH
 #define STREAM_RES_PREFETCH 0   // 1: the residual tile is DMA'd into its own 16*TJ KB right behind the first K-step's operands
 #endif
+#ifndef STREAM_MAX_CIN
+#define STREAM_MAX_CIN 512
+#endif
 #ifndef STREAM_KD
 #define STREAM_KD 64            // channels per barrier pair: 64 | 128 (two [weights | pixels] sub-tiles per wait)
 #endif
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
 }
 
 bool conv_takes_stream_kernel(int ksize, int stride, int pad, int cin, int cout) {
-    return ksize == 1 && pad == 0 && (stride == 1 || stride == 2) && cin % 64 == 0 && cin <= 512 && cout % SBC == 0;
+    return ksize == 1 && pad == 0 && (stride == 1 || stride == 2) && cin % 64 == 0 && cin <= STREAM_MAX_CIN && cout % SBC == 0;
 }
 
 // BMI_ERR_UNSUPPORTED -> the caller goes on to conv_igemm_wide / conv_igemm.

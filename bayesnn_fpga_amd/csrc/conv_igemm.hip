@@ -39,7 +39,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TILE = (BC + BP) * 128;
     constexpr int MAIN_BYTES = (DBUF ? 2 : 1) * TILE;
     constexpr int LDS_BYTES = (BC == 128 && MAIN_BYTES < BMI_EPILOGUE_LDS_BYTES) ? BMI_EPILOGUE_LDS_BYTES : MAIN_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    // XMASK: keep byte -> the four dword masks of its 8 halves, a 256-entry table behind the tiles (conv3x3_s2's S2_MASK_LUT: one
+    // ds_read_b128 instead of ~20 vector instructions per staged row — this kernel's masked form was issue-bound, see GLOAD)
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + (XMASK ? 4096 : 0)];
+    if constexpr (XMASK) {
+        const int t = threadIdx.x;
+        u32x4 m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = (((t >> (2 * i)) & 1) ? 0xffffu : 0u) | (((t >> (2 * i + 1)) & 1) ? 0xffff0000u : 0u);
+        *(u32x4*)(smem + LDS_BYTES + t * 16) = m;       // (256 threads)
+        __syncthreads();
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -61,8 +71,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int st_off = r0 * 128 + ((chunk ^ ((r0 >> 1) & 7)) << 4);
     const _Float16* wptr = a.wgt + (size_t)(ch0 + r0) * Ktot + chunk * 8;
 
+    // Per staged pixel row: the tap-independent part of its input address — image base + the element offset of input pixel
+    // (iy0, ix0) (negative inside the padding ring) — so that a K-step adds ONE launch-uniform offset ((ky W + kx) Cin + c0) per row
+    // instead of recomputing (iy W + ix) Cin in 64 bits, twice with keep bits.  (rocprofv3 on ResNet-50's 256 -> 128 stride-2 reader:
+    // waves issuing 41 % of their cycles at two per SIMD, MFMA-busy 0.29: the loop was bound by its address and mask arithmetic.)
     int iy0[XROWS], ix0[XROWS];
-    int bbase[XMASK ? XROWS : 1];
+    const uint8_t* kbase[XMASK ? XROWS : 1];
     const _Float16* xbase[XROWS];
     bool vm[XROWS];
 #pragma unroll
@@ -77,8 +91,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int ox = rem - oy * a.Wo;
         iy0[j] = oy * a.stride - a.pad;
         ix0[j] = ox * a.stride - a.pad;
-        xbase[j] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + chunk * 8;
-        if constexpr (XMASK) bbase[j] = n * a.H * a.W;   // pixel index base of the FOLDED image (keep bits are per sample)
+        const int e0 = (iy0[j] * a.W + ix0[j]) * a.Cin;               // |e0| < H W Cin < 2^31 (launch_conv_igemm)
+        xbase[j] = a.in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + chunk * 8 + (ptrdiff_t)e0;
+        // keep bits are per sample: the FOLDED image's rows; 8 elements per byte and e0 % 8 == 0
+        if constexpr (XMASK) kbase[j] = a.in_bits + (size_t)n * a.H * a.W * (a.Cin >> 3) + chunk + (ptrdiff_t)(e0 >> 3);
     }
 
     // NOTE: staging registers are filled/drained by macros, not lambdas: with by-reference lambda
@@ -89,18 +105,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #define GLOAD(KY, KX, C0)                                                                                  \
     {                                                                                                      \
         const int koff_ = ((KY) * a.ksize + (KX)) * a.Cin + (C0);                                          \
+        const int toff_ = ((KY) * a.W + (KX)) * a.Cin + (C0);       /* launch-uniform */                   \
         _Pragma("unroll") for (int j = 0; j < WROWS; ++j)                                                  \
             wreg[j] = *(const u32x4*)(wptr + (size_t)(32 * j) * Ktot + koff_);                             \
         _Pragma("unroll") for (int j = 0; j < XROWS; ++j) {                                                \
             const int iy_ = iy0[j] + (KY), ix_ = ix0[j] + (KX);                                            \
             const bool ok_ = vm[j] && (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;      \
             u32x4 v_ = {0u, 0u, 0u, 0u};                                                                   \
-            if (ok_) v_ = *(const u32x4*)(xbase[j] + (size_t)(iy_ * a.W + ix_) * a.Cin + (C0));           \
+            if (ok_) v_ = *(const u32x4*)(xbase[j] + toff_);                                               \
             if constexpr (XMASK) {                                                                         \
                 /* input-side MC-dropout: fetch the keep byte now, apply it at LSTORE time so the */       \
                 /* loads stay in flight under the MFMAs of the current step */                             \
                 uint32_t kb_ = 0;                                                                          \
-                if (ok_) kb_ = a.in_bits[(size_t)(bbase[j] + iy_ * a.W + ix_) * (a.Cin >> 3) + ((C0) >> 3) + chunk]; \
+                if (ok_) kb_ = kbase[j][toff_ >> 3];                                                       \
                 kreg[j] = kb_;                                                                             \
             }                                                                                              \
             xreg[j] = v_;                                                                                  \
@@ -113,8 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         _Pragma("unroll") for (int j = 0; j < XROWS; ++j) {                                                \
             u32x4 xv_ = xreg[j];                                                                           \
             if constexpr (XMASK) {   /* zero the dropped halves (1/(1-p) is folded into out_mul) */        \
-                _Pragma("unroll") for (int d = 0; d < 4; ++d)                                              \
-                    xv_[d] &= ((kreg[j] >> (2 * d)) & 1u ? 0xFFFFu : 0u) | ((kreg[j] >> (2 * d + 1)) & 1u ? 0xFFFF0000u : 0u); \
+                xv_ &= *(const u32x4*)(smem + LDS_BYTES + ((kreg[j] & 255u) << 4));                        \
             }                                                                                              \
             *(u32x4*)(base_ + BC * 128 + st_off + j * 32 * 128) = xv_;                                     \
         }                                                                                                  \
@@ -316,6 +332,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.Cin % BK != 0 || a.Cout % 64 != 0 || a.in2) return BMI_ERR_UNSUPPORTED;   // the fused shortcut is a patch-kernel feature
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
     if (a.res && a.res_mod <= 0) return BMI_ERR_INVALID;
+    if ((size_t)a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit in-image element offsets
     static const int big = [] { const char* v = std::getenv("BMI_IGEMM_BP256"); return v ? std::atoi(v) : 1; }();
     if (a.partial) {   // split-K: 128 x 128 tiles, nsplit workgroups per tile, then the finishing pass
         if (a.nsplit < 2 || a.nsplit > a.ksize * a.ksize * (a.Cin / BK) || !conv_epilogue_is_plain(a) || a.Cout % 128 != 0 || a.in_bits || a.imap)
