@@ -119,6 +119,12 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} reports C-ABI version {l.bmi_version()}, this binding expects {ABI_VERSION}: "
                                "rebuild the library (python -m bayesnn_fpga_amd._build)")
         _lib = l
+        # BMI_OPTIONS="name=value,name=value": bmi_set_option pairs applied once at load (profiling arms: rocprofv3 wraps bench.py,
+        # which has no option flag of its own)
+        for kv in filter(None, os.environ.get("BMI_OPTIONS", "").split(",")):
+            nm, _, val = kv.partition("=")
+            if l.bmi_set_option(nm.strip().encode(), int(val)) != BMI_OK:
+                raise RuntimeError(f"BMI_OPTIONS: bmi_set_option({nm.strip()}, {val}) failed")
     return _lib
 
 

@@ -59,10 +59,14 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
     const int wc = wave >> 1, wp = wave & 1;
 
     int ptile, ctile;
-    xcd_tile_map(blockIdx.x, (a.M + SBP - 1) / SBP, a.Cout / SBC, ptile, ctile, a.xcd_split);
+    const int HoWo = a.Ho * a.Wo;
+    if (MSK && a.lazy_order) {                        // (launcher: Ho Wo % SBP == 0, N % in_mod == 0)
+        if (!lazy_tile_map(blockIdx.x, a.in_mod, a.N / a.in_mod, HoWo / SBP, a.Cout / SBC, ptile, ctile)) return;
+    } else {
+        xcd_tile_map(blockIdx.x, (a.M + SBP - 1) / SBP, a.Cout / SBC, ptile, ctile, a.xcd_split);
+    }
     const int ch0 = ctile * SBC;
     const int pix0 = ptile * SBP;
-    const int HoWo = a.Ho * a.Wo;
 
     // DMA piece q = tid + 256*i -> tile row (q >> 3) = 32*i + (tid >> 3), 16-byte slot tid & 7 (swizzled on the source side)
     const int rowt = tid >> 3;
@@ -260,7 +264,9 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
     // Where the wide kernel cannot go (Cout % 256 != 0: the 256 -> 128 / 64 -> 128 reduce and downsample convs) the alternative is the
     // per-tap conv_igemm, and this kernel wins plain launches too: 256 -> 128 on 32x32 2723 -> 2310 us, 64 -> 128 stride 2 455 -> 312 us.
     if (epi == BMI_EPI_PLAIN && a.Cout % 256 == 0 && opt_conv_stream() != 2 && !a.in_bits) return BMI_ERR_UNSUPPORTED;   // (keep bits: the wide kernel has no place to apply them)
-    const dim3 grid((unsigned)tiles), block(256);
+    // keep bits on a deterministic input: the samples of one activation tile back to back on one XCD (lazy_tile_map)
+    a.lazy_order = a.in_bits && opt_lazy_order() && a.N % a.in_mod == 0 && (a.Ho * a.Wo) % SBP == 0 && a.in_mod < a.N;
+    const dim3 grid((unsigned)(a.lazy_order ? lazy_tile_grid(tiles) : tiles)), block(256);
 #define STREAM_LAUNCH(BF_)                                                                                                      \
     {                                                                                                                           \
         if (a.in_bits) {                                                                                                        \

@@ -445,7 +445,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #define SETUP_TILE(VB)                                                                                       \
     {                                                                                                        \
         int ptile_, ctile_;                                                                                  \
-        xcd_tile_map((VB), n_ptiles, n_ctiles, ptile_, ctile_, a.xcd_split);                                 \
+        if (MSK && a.lazy_order) {          /* position = id ((b T + t) n_ct + ct): sample-minor, one image per tile */ \
+            const unsigned T_ = (unsigned)(a.N / a.in_mod), r_ = (unsigned)(VB) / (unsigned)n_ctiles;       \
+            ctile_ = (int)((unsigned)(VB) - r_ * (unsigned)n_ctiles);                                        \
+            const unsigned b_ = r_ / T_;                                                                     \
+            ptile_ = (int)((r_ - b_ * T_) * (unsigned)a.in_mod + b_);                                        \
+        } else {                                                                                             \
+            xcd_tile_map((VB), n_ptiles, n_ctiles, ptile_, ctile_, a.xcd_split);                             \
+        }                                                                                                    \
         ch0 = ctile_ * CT;                                                                                   \
         n0 = ptile_ * IMGS;                                                                                  \
         const _Float16* w0_ = ch0 < split ? a.wgt + (size_t)ch0 * Ktot : a.wgt_b + (size_t)(ch0 - split) * Ktot; \
@@ -597,10 +604,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         }                                                                                                      \
     }
 
-    int vb = blockIdx.x;
+    // The walk: tile positions blockIdx.x, + gridDim.x, ... through xcd_tile_map — or, reading a deterministic input through keep bits
+    // (MSK, ConvArgs::lazy_order), a CONTIGUOUS run of the sample-minor numbering: this workgroup takes one image's patch for sample after
+    // sample, from its XCD's L2 after the first (in the plain order every sample's read of an image is a miss there).
+    int vb = blockIdx.x, v_step = (int)gridDim.x, v_end = n_tiles;
+    if (MSK && a.lazy_order) {
+        const int L = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+        vb = (int)blockIdx.x * L;
+        v_step = 1;
+        v_end = vb + L < n_tiles ? vb + L : n_tiles;
+        if (vb >= v_end) return;
+    }
     SETUP_TILE(vb);
     bool stores16 = false;                                 // the tile before this one issued exactly 16 stores per thread
-    while (vb < n_tiles) {
+    while (vb < v_end) {
         const int cur_ch0 = ch0, cur_n0 = n0, cur_tsel = tsel;
         accv acc[TI][TP];
 #pragma unroll
@@ -632,8 +649,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---- next tile's first weight stages and A / B pieces; they land during the epilogue below ----
-        const int nvb = vb + (int)gridDim.x;
-        if (nvb < n_tiles) SETUP_TILE(nvb);
+        const int nvb = vb + v_step;
+        if (nvb < v_end) SETUP_TILE(nvb);
 
         // ---- epilogue of the current tile: BN + ReLU on the accumulators, fp16 through LDS, 32 KB per channel half,
         //      two rounds of 128 pixels (conv_igemm_wide_persist's, with this kernel's tile-pixel order) ----
@@ -776,8 +793,10 @@ static int launch_s2(const ConvArgs& a, int n_cu, hipStream_t s) {
 #define S2_LAUNCH(BF_, IMAP_) hipLaunchKernelGGL((conv3x3_s2_kernel<TW, BF_, IMAP_>), grid, block, 0, s, a, (int)tiles)
     if (a.in_bits) {
         if constexpr (TW == 16) {
-            if (a.bf16) hipLaunchKernelGGL((conv3x3_s2_kernel<16, true, false, true>), grid, block, 0, s, a, (int)tiles);
-            else hipLaunchKernelGGL((conv3x3_s2_kernel<16, false, false, true>), grid, block, 0, s, a, (int)tiles);
+            ConvArgs al = a;
+            al.lazy_order = opt_lazy_order() && a.in_mod < a.N && a.N % a.in_mod == 0;
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_s2_kernel<16, true, false, true>), grid, block, 0, s, al, (int)tiles);
+            else hipLaunchKernelGGL((conv3x3_s2_kernel<16, false, false, true>), grid, block, 0, s, al, (int)tiles);
         } else {
             return BMI_ERR_UNSUPPORTED;
         }

@@ -67,6 +67,29 @@ __device__ __forceinline__ void xcd_tile_map(int bid, int n_pt, int n_ct, int& p
     }
 }
 
+// Tile order of a launch that reads a DETERMINISTIC input of B images through a lazy site (keep bits per sample, engine.hip).  In the
+// plain order tile -> pixel m = (t B + b) Ho Wo + ..: neighbours in time are different IMAGES of one sample, and the T samples' reads of
+// one image's activations lie B Ho Wo / tile workgroups apart — each of them a miss in the XCD's 4 MB L2 (rocprofv3, ResNet-50's 1x1
+// readers: 5.7 GB fetched per launch for 0.13 GB of activations + 0.5 GB of bits; its 3x3 stride-2 reader 19.6 GB).  Here the tiles are
+// numbered sample-MINOR, id = ((b PT + pxt) T + t) n_ct + ct (PT pixel tiles per image, n_ct channel tiles), and XCD x (blocks = x mod 8)
+// takes the contiguous ids [x L, (x + 1) L), L = ceil(total / 8), in block order: the T n_ct workgroups that read one activation tile run
+// back to back on one XCD and all but the first find it in L2.  Grid = 8 L blocks (lazy_tile_grid); false = no tile for this block.
+// Placement only: results do not change.
+__device__ __forceinline__ bool lazy_tile_map(int bid, int B, int T, int PT, int n_ct, int& ptile, int& ctile) {
+    const unsigned total = (unsigned)B * PT * T * n_ct;          // (launcher: < 2^31)
+    const unsigned L = (total + 7u) >> 3;
+    const unsigned x = (unsigned)bid & 7u, s = (unsigned)bid >> 3;
+    const unsigned id = x * L + s;
+    if (s >= L || id >= total) return false;
+    unsigned r = id;
+    ctile = (int)(r % (unsigned)n_ct); r /= (unsigned)n_ct;
+    const unsigned t = r % (unsigned)T; r /= (unsigned)T;
+    const unsigned pxt = r % (unsigned)PT, b = r / (unsigned)PT;
+    ptile = (int)((t * B + b) * PT + pxt);
+    return true;
+}
+inline long lazy_tile_grid(long total) { return 8 * ((total + 7) / 8); }
+
 // Dynamic early exit: compact image index of this launch -> row of the tensors / Philox image index (see ConvArgs::imap).
 // IMAP is a KERNEL TEMPLATE PARAMETER: the ordinary instantiations (IMAP = false) contain no trace of it.  As a run-time
 // `a.imap ? a.imap[n] : n` inside the epilogue's load loops it made hipcc wait vmcnt(0) around every conditional load and

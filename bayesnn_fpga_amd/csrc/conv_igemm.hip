@@ -58,11 +58,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     const int n_ctiles = a.Cout / BC;
     int ptile, ctile;
-    xcd_tile_map(blockIdx.x, (a.M + BP - 1) / BP, n_ctiles, ptile, ctile);
+    const int HoWo = a.Ho * a.Wo;
+    if (XMASK && a.lazy_order) {                      // (launcher: Ho Wo % BP == 0, N % in_mod == 0) the samples of one activation tile
+        if (!lazy_tile_map(blockIdx.x, a.in_mod, a.N / a.in_mod, HoWo / BP, n_ctiles, ptile, ctile)) return;   // back to back on one XCD
+    } else {
+        xcd_tile_map(blockIdx.x, (a.M + BP - 1) / BP, n_ctiles, ptile, ctile);
+    }
     const int ch0 = ctile * BC;
     const int pix0 = ptile * BP;
 
-    const int HoWo = a.Ho * a.Wo;
     const int Ktot = a.ksize * a.ksize * a.Cin;
 
     // ---- staging geometry (per thread: one 16-byte chunk of WROWS + XROWS rows) -------------
@@ -262,12 +266,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 }
 
 template <int BC, int BP, int WC, int WP, bool DBUF, bool XMASK = false>
-static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+static int launch_cfg(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
     const int n_ctiles = a.Cout / BC;
     const long n_ptiles = ((long)a.M + BP - 1) / BP;
     const long blocks = n_ptiles * n_ctiles;
-    if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_INVALID;
-    const dim3 grid((unsigned)blocks), block(256);
+    if (blocks <= 0 || blocks > 0x7ffffff0L) return BMI_ERR_INVALID;
+    a.lazy_order = XMASK && a.in_bits && opt_lazy_order() && !a.imap && a.in_mod < a.N && a.N % a.in_mod == 0 && (a.Ho * a.Wo) % BP == 0;
+    const dim3 grid((unsigned)(a.lazy_order ? lazy_tile_grid(blocks) : blocks)), block(256);
     const bool plain = BC == 128 && conv_epilogue_is_plain(a);   // the 64-channel tiles use the per-quad epilogue: one instantiation
     if (a.imap) {   // dynamic early exit: the double-buffered 128-pixel configurations only
         if constexpr (DBUF && !XMASK && BP == 128) {

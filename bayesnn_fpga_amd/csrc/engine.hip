@@ -174,6 +174,7 @@ int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nu
 int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
 int& opt_conv_pw() { static int v = 1; return v; }
 int& opt_epilogue_lite() { static int v = 1; return v; }
+int& opt_lazy_order() { static int v = 1; return v; }
 int& opt_dense_exact() { static int v = 0; return v; }
 int& opt_splitk() { static int v = 1; return v; }
 int& opt_conv_stream() { static int v = 1; return v; }
@@ -265,6 +266,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "dense_exact") == 0) {
         if (value != 0 && value != 1) return BMI_ERR_INVALID;
         opt_dense_exact() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "lazy_order") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_lazy_order() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "epilogue_lite") == 0) {

@@ -68,6 +68,7 @@ struct ConvArgs {
                              // conv3x3_pw's 4x4 bf16 instantiations from 0 to 212 bytes of scratch.)
     int lazy_planar;         // the operand that comes with keep bits (in + in_bits: conv3x3_s2; in2 + in2_bits: conv3x3_patch) and its bits are
                              // stored in the lazy site's PLANAR layout (lazy_planar_off below) instead of NHWC
+    int lazy_order;          // (set by the launcher) a launch that reads `in` through keep bits walks its tiles sample-minor: lazy_tile_map (conv_epilogue.h)
 };
 
 // Layout of a lazy site's scaled copy and keep bits when every reader is a stride-2 consumer (conv3x3_s2 on 32x32 maps, the fused 1x1
@@ -164,6 +165,7 @@ int& opt_conv_s2();            // 1: plain 3x3 stride-2 convs run in conv3x3_s2 
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
 int& opt_splitk();             // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch
 int& opt_dense_exact();        // 1: hidden dense layers on the exact-f32 MFMA instead of the split-fp16 form
+int& opt_lazy_order();         // 1: the readers of a lazy site walk their tiles sample-minor (lazy_tile_map): speed only, never results
 int& opt_epilogue_lite();      // 1: BN + residual + ReLU + 2-bit elementwise-site launches finish in epilogue_lite
 int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
 int xcd_split_for(int n_ctiles, size_t weight_bytes);

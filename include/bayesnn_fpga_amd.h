@@ -187,6 +187,9 @@ const char* bmi_error_string(int code);
  *   "dense_exact"                           0 | 1: hidden dense layers (BMI_OP_DENSE / bmi_dense_f32) on the exact-f32 MFMA (1) or as
  *                                           fp16 head + tail products on the fp16 MFMA with fp32 accumulation (0, default: fp32-equivalent
  *                                           to a few 1e-7, 2.5x faster)
+ *   "lazy_order"                            0 | 1: the kernels that read a deterministic tensor through a lazy site's keep bits walk their
+ *                                           tiles sample-minor — the samples of one activation tile back to back on one XCD, which finds it
+ *                                           in its L2 (1, default) — or in the plain order (0).  Placement only: the same bits
  *   "epilogue_lite"                         0 | 1 | 2: BN + residual + ReLU + 2-bit elementwise-site launches finish on the accumulator
  *                                           registers with one fp16 trip through LDS (1, default; 2: without the forms that have the
  *                                           site kind and the residual compiled in) or in the general two-round fp32 epilogue (0);

@@ -217,6 +217,29 @@ def test_lazy_first_site_resnet50():
     assert ms_lazy < 0.7 * ms_plain
 
 
+@pytest.mark.parametrize("arch,batch,T", [("resnet18", 60, 7), ("resnet18", 250, 3), ("resnet50", 250, 3), ("resnet50", 36, 9)])
+def test_lazy_tile_order_is_placement_only(arch, batch, T):
+    """`lazy_order` (conv_epilogue.h lazy_tile_map; conv3x3_s2's contiguous walk): the readers of a lazy site take their tiles sample-minor so
+    that one activation tile's samples run back to back on one XCD.  Placement only: every bit equals the plain order — with ragged
+    runs (420 tiles over 256 workgroups: runs of two, the last workgroups empty), with grids rounded up to eight blocks, for conv3x3_s2 /
+    conv1x1_stream / conv_igemm's masked-input forms."""
+    from bayesnn_fpga_amd import _lib
+    cls = ResNet18MCEarlyExit if arch == "resnet18" else bx.ResNet50MCEarlyExit
+    model = build_seeded(cls, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    synthetic_weights_(model, 0)
+    eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=batch)
+    x = synthetic_images(batch, seed=77).to(DEV)
+    out = {}
+    try:
+        for v in (0, 1):
+            _lib.set_option("lazy_order", v)
+            out[v] = eng.predict(x, T, seed=5)
+    finally:
+        _lib.set_option("lazy_order", 1)
+    for k in ("mean", "var"):
+        assert torch.equal(out[0][k], out[1][k]), k
+
+
 @pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
 def test_lazy_first_site_bf16_engine(arch):
     """The bf16 instantiations of the lazy path (scaled copy rounded to bf16, conv3x3_s2 / conv3x3_patch / conv1x1_stream masking in
