@@ -237,7 +237,7 @@ bool conv_takes_stream_kernel(int ksize, int stride, int pad, int cin, int cout)
 
 // BMI_ERR_UNSUPPORTED -> the caller goes on to conv_igemm_wide / conv_igemm.
 int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
-    if (!opt_conv_stream() || a_in.wgt_b || a_in.in2 || a_in.imap) return BMI_ERR_UNSUPPORTED;
+    if (!opt_conv_stream() || a_in.wgt_b || a_in.in2 || a_in.imap || (a_in.in_bits && a_in.lazy_planar)) return BMI_ERR_UNSUPPORTED;
     if (a_in.in_bits && (a_in.out_mul != 1.f || (size_t)a_in.N * a_in.H * a_in.W * (a_in.Cin >> 3) >= 0x7fffffffull)) return BMI_ERR_UNSUPPORTED;
     if (!conv_takes_stream_kernel(a_in.ksize, a_in.stride, a_in.pad, a_in.Cin, a_in.Cout)) return BMI_ERR_UNSUPPORTED;
     if (a_in.N <= 0 || a_in.M <= 0 || a_in.in_mod <= 0 || a_in.B <= 0 || (a_in.res && a_in.res_mod <= 0)) return BMI_ERR_INVALID;

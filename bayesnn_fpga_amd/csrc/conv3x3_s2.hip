@@ -121,14 +121,20 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // MSK = masked input (ConvArgs::in_bits): the patch is DMA'd from the deterministic (pre-scaled) tensor, a piece's keep bits ride
 // along as one more DMA (a dword per lane into a 2 KB slot), and the thread that issued a piece clears the dropped elements of
 // ITS 16 bytes in LDS one K-step after the piece has landed — a piece is readable one step later than without the mask.
-template <int TW, int NST_ = (TW == 4 ? 3 : S2_NST_BIG), bool MSK_ = false>
+// CT_ = channels per tile: 256, or 128 (round 4, 16x16 output maps only: ResNet-50's Cout = 128 stride-2 convs).  With 128 the two wave groups
+// split the tile's PIXELS (output rows 0-7 / 8-15) instead of its channels: a wave tile is 64 ch x 64 px (4 x 4 MFMA tiles), both groups read the
+// same 8 KB weight stage, a K-step's two phases take two pixel blocks each (8 MFMAs per phase instead of 16; the barrier schedule, the patch and
+// its refill windows are the same), and a group's 128 ch x 128 px are ONE round of the epilogue.
+template <int TW, int NST_ = (TW == 4 ? 3 : S2_NST_BIG), bool MSK_ = false, int CT_ = 256>
 struct S2Geom {
+    static_assert(CT_ == 256 || (CT_ == 128 && TW == 16), "128-channel tiles: the 16x16 output maps");
     static constexpr int NST = NST_;
     static constexpr bool MSK = MSK_;
     static constexpr int LAND = NST + (MSK ? 1 : 0);              // a piece issued in step s is readable from step s + LAND on
     static_assert(NST == 3 || NST == 4, "weight stages");
     static constexpr int BN_MAX = TW == 4 ? 1024 : 512;           // channels of the launch (both convs of a pair): the BN table
-    static constexpr int CT = 256, PX = 256, IMGS = PX / (TW * TW);
+    static constexpr int CT = CT_, PX = 256, IMGS = PX / (TW * TW);
+    static constexpr int WPI = CT / 128;                          // weight DMA instructions per thread and K-step
     static_assert(IMGS >= 1 && IMGS * TW * TW == PX, "whole output maps per tile");
     // planes in tap-use order: 0 = A (odd input rows, odd columns), 1 = B (odd, even), 2 = C (even, odd), 3 = D (even, even).
     // Plane row y of an odd-row plane is input row 2 y - 1 (y = 0: the padding row), of an even-row plane input row 2 y.
@@ -197,7 +203,7 @@ struct S2Geom {
             const bool prev = j < 0;
             const int sj = prev ? j + 9 : j;
             const bool lastj = last && !prev;
-            if (j > S - (NST - 2)) n += w_issued(sj, lastj) ? 2 : 0;
+            if (j > S - (NST - 2)) n += w_issued(sj, lastj) ? WPI : 0;
             n += p_issued(sj, lastj);
         }
         return n;
@@ -247,12 +253,13 @@ __host__ __device__ constexpr int s2_tap(int s) {
     return t[s];
 }
 
-template <int TW, bool BF, bool IMAP, bool MSK = false>
+template <int TW, bool BF, bool IMAP, bool MSK = false, int CT_ = 256>
 __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_tiles) {
-    using G = S2Geom<TW, (TW == 4 ? 3 : S2_NST_BIG), MSK>;
+    using G = S2Geom<TW, (TW == 4 ? 3 : S2_NST_BIG), MSK, CT_>;
     static_assert(!MSK || (TW == 16 && !IMAP), "masked input: one image per tile, the ordinary form");
     constexpr int CT = G::CT, IMGS = G::IMGS, NPT = G::NPT, PRO = G::PRO, NST = G::NST;
-    constexpr int TI = 4, TP = 8;
+    constexpr bool HALF = CT == 128;
+    constexpr int TI = 4, TP = HALF ? 4 : 8, JB = TP / 2;        // JB pixel blocks per phase of a K-step
     typedef float accv __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     char* const pbuf = smem + G::P_OFF;
@@ -293,10 +300,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 
     // ---- per-lane fragment geometry (tile-independent) ----
     // weights: row (g*128 + wc*64 + l16 + 16 i), chunk kq at position kq ^ 2 ((row >> 2) & 1) = kq ^ 2 ((l16 >> 2) & 1)
-    const int a_off = (g * 128 + wc * 64 + l16) * 64 + ((kq ^ (((l16 >> 2) & 1) << 1)) << 4);
+    const int a_off = ((HALF ? 0 : g * 128) + wc * 64 + l16) * 64 + ((kq ^ (((l16 >> 2) & 1) << 1)) << 4);
     // pixels: lane (by, bx) = (l16 >> 2, l16 & 3) of each 4 x 4 block; plane row parity of the cell = (by + dy) & 1
     const int by = l16 >> 2, bx = l16 & 3;
-    const int pbase = wp * 128;                                   // first tile pixel of this wave
+    const int pbase = HALF ? (g * 2 + wp) * 64 : wp * 128;        // first tile pixel of this wave
     // (a tap with dy = 1 reads the cell one plane row further down: + cols * 64 as an immediate, and the chunk sits at the
     // other position of its pair: the same per-lane address with bit 5 flipped)
     int boff[4];
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #define ISSUE_W(KOFF, ST)                                                                                    \
     {                                                                                                        \
         ISSUE_W_HALF(KOFF, ST, 0);                                                                           \
-        ISSUE_W_HALF(KOFF, ST, 1);                                                                           \
+        if (!HALF) ISSUE_W_HALF(KOFF, ST, 1);                                                                \
     }
 #define ISSUE_P(K, C0)                                                                                       \
     {                                                                                                        \
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         const _Float16* w0_ = ch0 < split ? a.wgt + (size_t)ch0 * Ktot : a.wgt_b + (size_t)(ch0 - split) * Ktot; \
         const _Float16* w1_ = ch0 + 128 < split ? a.wgt + (size_t)(ch0 + 128) * Ktot : a.wgt_b + (size_t)(ch0 + 128 - split) * Ktot; \
         rs_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)w0_, 0, wbytes, 0x00020000);                        \
-        rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)w1_, 0, wbytes, 0x00020000);                        \
+        if (!HALF) rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)w1_, 0, wbytes, 0x00020000);             \
         if constexpr (IMAP) {                                                                                \
             rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 2u * (unsigned)a.in_mod * HWC, 0x00020000); \
         } else {                                                                                             \
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     //  therefore stay in flight one step longer.)
 #define END_OF_STEP_WAIT(S)                                                                                    \
     {                                                                                                          \
-        if (S2_RELAX0 && (S) == 0 && chunk == 0 && stores16 && !IMAP && !S2_DRAIN_STORES) { WAIT_VM(16 + G::wait_n(0, false)); } \
+        if (S2_RELAX0 && (S) == 0 && chunk == 0 && stores16 && !IMAP && !S2_DRAIN_STORES) { WAIT_VM(NSTORES + G::wait_n(0, false)); } \
         else if (!last) { WAIT_VM(G::wait_n(S, false)); }                                                      \
         else { WAIT_VM(G::wait_n(S, true)); }                                                                  \
     }
@@ -532,8 +539,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             if (kk == 0) {                                                                                     \
                 _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
             }                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
-                if (!S2_ABL_HALFREADS || !(j & 1)) bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, 4 * kk + j) * 64); \
+            _Pragma("unroll") for (int j = 0; j < JB; ++j)                                                     \
+                if (!S2_ABL_HALFREADS || !(j & 1)) bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, JB * kk + j) * 64); \
                 else bf[j] = bf[j - 1];                                                                        \
             if constexpr (MSK && due0_ >= 0) {                                                                 \
                 if (kk == S2_MASK_PHASE) {                                                                     \
@@ -590,13 +597,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[3][j] = mfma_16x16x32<BF>(af[3], bf[j], acc[3][j]); \
                 } else {                                                                                       \
                     _Pragma("unroll") for (int i = 0; i < TI; ++i)                                             \
-                        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
-                            acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);          \
+                        _Pragma("unroll") for (int j = 0; j < JB; ++j)                                         \
+                            acc[i][JB * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][JB * kk + j]);        \
                 }                                                                                              \
             } else {                                                                                           \
                 _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                 \
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
-                        acc[i][4 * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][4 * kk + j]);              \
+                    _Pragma("unroll") for (int j = 0; j < JB; ++j)                                             \
+                        acc[i][JB * kk + j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][JB * kk + j]);            \
             }                                                                                                  \
             __builtin_amdgcn_s_setprio(0);                                                                     \
             if (kk == 1 && g == 0) END_OF_STEP_WAIT(S);        /* interval 4T+3, group 0: MFMA part */         \
@@ -616,7 +623,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         if (vb >= v_end) return;
     }
     SETUP_TILE(vb);
-    bool stores16 = false;                                 // the tile before this one issued exactly 16 stores per thread
+    constexpr int NSTORES = HALF ? 8 : 16;                 // output stores per thread of a full tile
+    bool stores16 = false;                                 // the tile before this one issued exactly NSTORES stores per thread
     while (vb < v_end) {
         const int cur_ch0 = ch0, cur_n0 = n0, cur_tsel = tsel;
         accv acc[TI][TP];
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         // issued BEHIND them (vmcnt retires in order): a full tile leaves them in flight, a ragged one (some stores skipped:
         // the count is not known) and the dynamic-exit form drain everything.
         if (IMAP || !stores16 || S2_DRAIN_STORES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORES) : "memory");
         if constexpr (MSK) {                               // the A / B pieces of chunk 0 (issued by SETUP_TILE)
 #pragma unroll
             for (int k = 0; k < PRO; ++k) MASK_P(k);
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
             char* const E = smem + G::E_OFF + g * 32768;
             int tl = tid & 255;
             asm volatile("" : "+v"(tl));                    // (per tile: hoisted out of the tile loop, what derives from it is spilled)
-            const int chl = cur_ch0 + 128 * g;              // launch-wide channel of this half's channel 0 (BN table index)
+            const int chl = cur_ch0 + (HALF ? 0 : 128 * g);    // launch-wide channel of this group's channel 0 (BN table index)
             _Float16* outp = a.out;
             int oc = a.Cout, chg = chl;
             if (a.wgt_b) {
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                 lds_barrier(); lds_barrier(); lds_barrier();
             } else
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
+            for (int rr = 0; rr < (HALF ? 1 : 2); ++rr) {   // (128-channel tiles: a group's 128 ch x 128 px are one round)
                 if (rr) lds_barrier();                      // round 0's reads are done
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int pl = (tl >> 4) + 16 * (4 * hb + it);
-                        const int p = (pl >> 6) * 128 + rr * 64 + (pl & 63);     // tile pixel
+                        const int p = HALF ? g * 128 + pl : (pl >> 6) * 128 + rr * 64 + (pl & 63);     // tile pixel
                         int n = cur_n0 + G::p_img(p);
                         if constexpr (IMAP) n = row_tabs[cur_tsel * 16 + G::p_img(p)];      // tensor row, -1 beyond N
                         else if (n >= a.N) n = -1;
@@ -780,16 +788,39 @@ int& opt_conv_s2() { static int v = 1; return v; }
 // Shapes this kernel takes: 3x3 / stride 2 / pad 1, 32x32 -> 16x16, 16x16 -> 8x8 or 8x8 -> 4x4, Cout % 256 == 0 (both convs of
 // a pair together), BN + ReLU epilogue.
 bool conv_takes_s2_kernel(int ksize, int stride, int pad, int cin, int cout, int h, int w, int ho, int wo) {
-    return ksize == 3 && stride == 2 && pad == 1 && cin % 32 == 0 && cout % 256 == 0 && cout <= (ho == 4 ? 1024 : 512) && ho == wo &&
-           (ho == 16 || ho == 8 || ho == 4) && h == 2 * ho && w == 2 * wo;
+    // (Cout % 256 != 0: the 128-channel tiles of the 16x16 output maps)
+    return ksize == 3 && stride == 2 && pad == 1 && cin % 32 == 0 && (cout % 256 == 0 || (cout % 128 == 0 && ho == 16)) &&
+           cout <= (ho == 4 ? 1024 : 512) && ho == wo && (ho == 16 || ho == 8 || ho == 4) && h == 2 * ho && w == 2 * wo;
 }
 
 template <int TW>
 static int launch_s2(const ConvArgs& a, int n_cu, hipStream_t s) {
     using G = S2Geom<TW>;
-    const long tiles = (long)((a.N + G::IMGS - 1) / G::IMGS) * (a.Cout / 256);
+    const bool half = a.Cout % 256 != 0;      // 128-channel tiles (TW == 16)
+    const long tiles = (long)((a.N + G::IMGS - 1) / G::IMGS) * (a.Cout / (half ? 128 : 256));
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     const dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu)), block(512);
+    if (half) {
+        if constexpr (TW == 16) {
+            if (a.wgt_b || (a.imap && a.in_bits)) return BMI_ERR_UNSUPPORTED;
+            ConvArgs al = a;
+            al.lazy_order = a.in_bits && opt_lazy_order() && a.in_mod < a.N && a.N % a.in_mod == 0;
+            if (a.imap) {      // dynamic early exit: the same kernel family as the full run (the same bits for the images that go on)
+                if (a.bf16) hipLaunchKernelGGL((conv3x3_s2_kernel<16, true, true, false, 128>), grid, block, 0, s, al, (int)tiles);
+                else hipLaunchKernelGGL((conv3x3_s2_kernel<16, false, true, false, 128>), grid, block, 0, s, al, (int)tiles);
+            } else if (a.in_bits) {
+                if (a.bf16) hipLaunchKernelGGL((conv3x3_s2_kernel<16, true, false, true, 128>), grid, block, 0, s, al, (int)tiles);
+                else hipLaunchKernelGGL((conv3x3_s2_kernel<16, false, false, true, 128>), grid, block, 0, s, al, (int)tiles);
+            } else {
+                if (a.bf16) hipLaunchKernelGGL((conv3x3_s2_kernel<16, true, false, false, 128>), grid, block, 0, s, al, (int)tiles);
+                else hipLaunchKernelGGL((conv3x3_s2_kernel<16, false, false, false, 128>), grid, block, 0, s, al, (int)tiles);
+            }
+            BMI_CHECK_LAUNCH();
+            return BMI_OK;
+        } else {
+            return BMI_ERR_UNSUPPORTED;
+        }
+    }
 #define S2_LAUNCH(BF_, IMAP_) hipLaunchKernelGGL((conv3x3_s2_kernel<TW, BF_, IMAP_>), grid, block, 0, s, a, (int)tiles)
     if (a.in_bits) {
         if constexpr (TW == 16) {
@@ -832,8 +863,8 @@ int launch_conv3x3_s2(const ConvArgs& a_in, hipStream_t s) {
     }();
     if (opt_conv_s2() != 2) {
         const int imgs = 256 / (a.Ho * a.Wo), n_sel = a.n_ref > 0 ? a.n_ref : a.N;
-        if ((long)((n_sel + imgs - 1) / imgs) * (a.Cout / 256) < 3 * n_cu / 4) return BMI_ERR_UNSUPPORTED;
+        if ((long)((n_sel + imgs - 1) / imgs) * (a.Cout / (a.Cout % 256 ? 128 : 256)) < 3 * n_cu / 4) return BMI_ERR_UNSUPPORTED;
     }
-    a.xcd_split = xcd_split_for(a.Cout / 256, (size_t)a.Cout * 9 * a.Cin * 2);
+    a.xcd_split = xcd_split_for(a.Cout / (a.Cout % 256 ? 128 : 256), (size_t)a.Cout * 9 * a.Cin * 2);
     return a.Ho == 16 ? launch_s2<16>(a, n_cu, s) : (a.Ho == 8 ? launch_s2<8>(a, n_cu, s) : launch_s2<4>(a, n_cu, s));
 }

@@ -352,6 +352,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         return launch_splitk_finish(a, s);
     }
     if (a.in_bits && a.imap) return BMI_ERR_UNSUPPORTED;   // (no dynamic-exit instantiation of the masked-input variant: the engine writes the masked tensor then)
+    if (a.in_bits && a.lazy_planar) return BMI_ERR_UNSUPPORTED;   // the planar layout is conv3x3_s2's / conv3x3_patch's: a launch they refuse is materialised
     if (a.in_bits) {   // masked-input variant (register budget: 128-pixel tiles only)
         if (a.Cout % 128 == 0) return launch_cfg<128, 128, 2, 2, true, true>(a, s);
         return launch_cfg<64, 128, 1, 4, true, true>(a, s);

@@ -743,7 +743,7 @@ def test_lite_epilogue_equals_general_bit_for_bit(name, n, k1, dt, use_res, use_
     if dt == "bf16":
         _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
     try:
-        for lite in (0, 1):
+        for lite in (0, 1, 2):     # general | lite with the residual / ReLU / site kind compiled in where such a form exists (round 4) | lite, run-time terms
             _lib.set_option("epilogue_lite", lite)
             outs.append(gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=7, t0=3, seed=9, cnt0=2, out_dtype=tdt))
     finally:
@@ -751,6 +751,7 @@ def test_lite_epilogue_equals_general_bit_for_bit(name, n, k1, dt, use_res, use_
         _lib.set_option("epilogue_lite", 1)
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
 
 
 @pytest.mark.parametrize("cin,cout,H,stride,n,dt", [(128, 512, 16, 1, 37, "f16"), (256, 1024, 8, 1, 131, "f16"), (64, 256, 32, 1, 5, "bf16"),

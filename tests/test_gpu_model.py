@@ -136,17 +136,20 @@ def test_full_size_batch_properties():
     torch.testing.assert_close(r1["mean"][:, 0], r["mean"][:, 0], rtol=0, atol=1e-4)
 
 
-def test_pair_fusion_is_invisible(monkeypatch):
-    """layerN[0].conv1 + ex{N-1}conv1 as one launch (engine.hip pair fusion) vs BMI_CONV_PAIR=0: identical moments."""
+@pytest.mark.parametrize("B,chunk", [(9, 2), (70, 4)])
+def test_pair_fusion_is_invisible(monkeypatch, B, chunk):
+    """layerN[0].conv1 + ex{N-1}conv1 as one launch (engine.hip pair fusion) vs BMI_CONV_PAIR=0: identical moments — on a small grid (the pair in
+    conv_igemm_wide, the two convs alone in conv_igemm) and on one that fills the chip (the pair in conv3x3_s2's 256-channel tiles reading the
+    lazy site in the planar layout; alone, the 64 -> 128 convs in its 128-channel tiles: the same K order, the same bits)."""
     kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
     model = _product(ResNet18MCEarlyExit, kw)
-    B, T, seed = 9, 4, 11
+    T, seed = 4, 11
     x = synthetic_images(B, seed=3).to(DEV)
-    eng = model.engine(x.device, max_batch=B, chunk_samples=2)
+    eng = model.engine(x.device, max_batch=B, chunk_samples=chunk)
     S_fused = eng.accumulate(x, eng.new_moments(B), 0, T, seed).cpu()
     n_fused = eng.n_suffix_ops
     monkeypatch.setenv("BMI_CONV_PAIR", "0")
-    eng2 = type(eng)(model, x.device, max_batch=B, chunk_samples=2)
+    eng2 = type(eng)(model, x.device, max_batch=B, chunk_samples=chunk)
     assert eng2.n_suffix_ops == n_fused + 3                     # three pairs in ResNet-18 multi-exit with block dropout
     S_plain = eng2.accumulate(x, eng2.new_moments(B), 0, T, seed).cpu()
     assert torch.equal(S_fused, S_plain)
