@@ -254,7 +254,8 @@ int launch_conv1x1_stream(const ConvArgs& a_in, hipStream_t s) {
     }();
     const long tiles_sel = a.n_ref > 0 ? (((long)a.n_ref * a.Ho * a.Wo + SBP - 1) / SBP) * (a.Cout / SBC) : tiles;
     if (opt_conv_stream() != 2 && tiles_sel < (n_cu > 0 ? 3 * n_cu / 2 : 384)) return BMI_ERR_UNSUPPORTED;
-    const int epi = opt_epilogue_lite() ? conv_epilogue_kind_launch(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+    int epi = opt_epilogue_lite() ? conv_epilogue_kind_launch(a, 16) : (conv_epilogue_is_plain(a) ? BMI_EPI_PLAIN : BMI_EPI_GENERAL);
+    if (epi == BMI_EPI_LITE_RES_MSK) epi = BMI_EPI_LITE;      // (no Masksembles instantiation of this kernel)
     // (the general epilogue — Masksembles / channel sites, 4-16-bit probabilities — spills 16 VGPRs next to this kernel's twelve
     //  DMA row pointers: those launches stay with conv_igemm_wide)
     if (epi == BMI_EPI_GENERAL) return BMI_ERR_UNSUPPORTED;

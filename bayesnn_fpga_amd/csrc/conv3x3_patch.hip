@@ -361,6 +361,9 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
             if (conv_epilogue_kind_launch(a, 16) == BMI_EPI_LITE_RES) {
                 if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES, 16, true, false);
                 else PATCH_LAUNCH(BMI_EPI_LITE_RES, 16, false, false);
+            } else if (conv_epilogue_kind_launch(a, 16) == BMI_EPI_LITE_RES_MSK) {
+                if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES_MSK, 16, true, false);
+                else PATCH_LAUNCH(BMI_EPI_LITE_RES_MSK, 16, false, false);
             } else {
                 if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES_MC, 16, true, false);
                 else PATCH_LAUNCH(BMI_EPI_LITE_RES_MC, 16, false, false);

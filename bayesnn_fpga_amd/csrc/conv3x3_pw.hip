@@ -927,10 +927,13 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
         BMI_CHECK_LAUNCH();
         return BMI_OK;
     }
-    if (epi_fine == BMI_EPI_LITE_RES || epi_fine == BMI_EPI_LITE_RES_MC) {
+    if (epi_fine == BMI_EPI_LITE_RES || epi_fine == BMI_EPI_LITE_RES_MC || epi_fine == BMI_EPI_LITE_RES_MSK) {
         if (epi_fine == BMI_EPI_LITE_RES) {
             if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES, true, false>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES, false, false>), grid, block, 0, s, a);
+        } else if (epi_fine == BMI_EPI_LITE_RES_MSK) {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES_MSK, true, false>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES_MSK, false, false>), grid, block, 0, s, a);
         } else {
             if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES_MC, true, false>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((conv3x3_pw_kernel<TW, BMI_EPI_LITE_RES_MC, false, false>), grid, block, 0, s, a);

@@ -348,6 +348,7 @@ __device__ __forceinline__ void site_mult8(const ConvArgs& a, const PixelCtx& px
 // per 128 x 128 tile against 64 MFMAs, twelve waves per CU issuing 36 % of their cycles each — the kernel was issue-bound, not HBM-bound.
 #define BMI_EPI_LITE_RES 3      // residual with one row per output row (res_mod >= N), ReLU, no site
 #define BMI_EPI_LITE_RES_MC 4   // ... and the elementwise 2-bit MC-dropout site
+#define BMI_EPI_LITE_RES_MSK 5  // ... or the Masksembles2D site (conv3x3_pw / conv3x3_patch: BASELINE configs[3])
 __host__ __device__ inline int conv_epilogue_kind(const ConvArgs& a, int mfma_shape) {
     if (conv_epilogue_is_plain(a)) return BMI_EPI_PLAIN;
     const bool site_ok = a.site.kind == BMI_SITE_NONE || a.site.kind == BMI_SITE_MASKSEMBLE ||
@@ -361,12 +362,15 @@ __host__ __device__ inline int conv_epilogue_kind_fine(const ConvArgs& a, int mf
     if (k != BMI_EPI_LITE || !a.res || a.res_mod < a.N || a.pool || !a.relu) return k;
     if (a.site.kind == BMI_SITE_NONE) return BMI_EPI_LITE_RES;
     if (a.site.kind == BMI_SITE_ELEMENTWISE) return BMI_EPI_LITE_RES_MC;
+    if (a.site.kind == BMI_SITE_MASKSEMBLE) return BMI_EPI_LITE_RES_MSK;
     return k;
 }
 inline int conv_epilogue_kind_launch(const ConvArgs& a, int mfma_shape) {   // host: "epilogue_lite" = 2 keeps the unspecialised form (A/B)
     return opt_epilogue_lite() == 2 ? conv_epilogue_kind(a, mfma_shape) : conv_epilogue_kind_fine(a, mfma_shape);
 }
-__host__ __device__ constexpr bool conv_epilogue_is_lite(int epi) { return epi == BMI_EPI_LITE || epi == BMI_EPI_LITE_RES || epi == BMI_EPI_LITE_RES_MC; }
+__host__ __device__ constexpr bool conv_epilogue_is_lite(int epi) {
+    return epi == BMI_EPI_LITE || epi == BMI_EPI_LITE_RES || epi == BMI_EPI_LITE_RES_MC || epi == BMI_EPI_LITE_RES_MSK;
+}
 
 // "Lite" general epilogue (16x16x32 accumulators): the common non-plain launch of the path is a BasicBlock tail — BN,
 // residual add, ReLU, and (p = 0.25 MC-dropout) an elementwise site drawn at 2 bits per element.  epilogue_coalesced
@@ -389,7 +393,7 @@ __host__ __device__ constexpr bool conv_epilogue_is_lite(int epi) { return epi =
 // POOL (conv3x3_pw on 4x4 maps, ConvArgs::pool): the 16 pixels of an accumulator tile are one image; instead of the fp16 map the
 // launch stores fp32 means over the map, [row][Cout] — the tile's 16 lanes are a DPP row: four v_add_f32 with DPP modifiers leave the
 // sum in every lane, lane 0 stores 4 consecutive channels.  The conv feeds nothing but an exit head (relu -> avg_pool2d(4) -> Linear).
-// SK: the site kind as a compile-time constant (BMI_SITE_NONE | BMI_SITE_ELEMENTWISE), or -1 = whatever the launch carries.  SK >= 0
+// SK: the site kind as a compile-time constant (BMI_SITE_NONE | BMI_SITE_ELEMENTWISE | BMI_SITE_MASKSEMBLE), or -1 = whatever the launch carries.  SK >= 0
 // also says the launch HAS a residual whose rows are the output's rows (BMI_EPI_LITE_RES / _RES_MC): its address comes from `offmap`.
 template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, int SK = -1, class ACC, class PixMap, class OffMap>
 __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
@@ -399,7 +403,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
     const int l16 = lane & 15, q4 = lane >> 4;
     const int HoWo = a.Ho * a.Wo;
     const bool masked = SK >= 0 ? SK == BMI_SITE_ELEMENTWISE : a.site.kind == BMI_SITE_ELEMENTWISE;
-    const bool msk = SK >= 0 ? false : a.site.kind == BMI_SITE_MASKSEMBLE;      // Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M
+    const bool msk = SK >= 0 ? SK == BMI_SITE_MASKSEMBLE : a.site.kind == BMI_SITE_MASKSEMBLE;      // Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M
     const bool has_res = SK >= 0 ? true : a.res != nullptr;
     const bool relu = SK >= 0 ? true : a.relu != 0;
 #pragma unroll
@@ -544,7 +548,7 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, 
     }
     if constexpr (conv_epilogue_is_lite(EPI)) {
         static_assert(MS == 16, "the lite epilogue reads the 16x16x32 accumulator layout");
-        constexpr int SK = EPI == BMI_EPI_LITE_RES ? BMI_SITE_NONE : (EPI == BMI_EPI_LITE_RES_MC ? BMI_SITE_ELEMENTWISE : -1);
+        constexpr int SK = EPI == BMI_EPI_LITE_RES ? BMI_SITE_NONE : (EPI == BMI_EPI_LITE_RES_MC ? BMI_SITE_ELEMENTWISE : (EPI == BMI_EPI_LITE_RES_MSK ? BMI_SITE_MASKSEMBLE : -1));
         epilogue_lite<TJ, BF, false, false, SK>(a, acc, lds, tid, ch0, pixmap, offmap);
         return;
     }
