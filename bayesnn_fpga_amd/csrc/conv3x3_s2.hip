@@ -612,14 +612,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     }
 
     // The walk: tile positions blockIdx.x, + gridDim.x, ... through xcd_tile_map — or, reading a deterministic input through keep bits
-    // (MSK, ConvArgs::lazy_order), a CONTIGUOUS run of the sample-minor numbering: this workgroup takes one image's patch for sample after
-    // sample, from its XCD's L2 after the first (in the plain order every sample's read of an image is a miss there).
+    // (MSK, ConvArgs::lazy_order), the sample-minor numbering id = (b T + t) n_ct + ct dealt per XCD: XCD x (workgroups = x mod 8, J of
+    // them) owns the contiguous ids [x L, (x + 1) L) and its workgroup j takes x L + j, + J, ...: at any moment the XCD's workgroups read
+    // ONE image's patch (consecutive samples of it), which therefore stays in the XCD's 4 MB L2 — with a run of ids per WORKGROUP (first
+    // version) 32 different images of 131-512 KB each pass through it and every sample's read is a miss again.
     int vb = blockIdx.x, v_step = (int)gridDim.x, v_end = n_tiles;
     if (MSK && a.lazy_order) {
-        const int L = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-        vb = (int)blockIdx.x * L;
-        v_step = 1;
-        v_end = vb + L < n_tiles ? vb + L : n_tiles;
+        if ((gridDim.x & 7) == 0) {
+            const int L = (n_tiles + 7) >> 3, J = (int)gridDim.x >> 3;
+            vb = (int)(blockIdx.x & 7) * L + (int)(blockIdx.x >> 3);
+            v_step = J;
+            v_end = (int)((blockIdx.x & 7) + 1) * L < n_tiles ? (int)((blockIdx.x & 7) + 1) * L : n_tiles;
+        }                                                   // (a grid that is not a multiple of eight — fewer tiles than CUs: the ids in order)
         if (vb >= v_end) return;
     }
     SETUP_TILE(vb);
