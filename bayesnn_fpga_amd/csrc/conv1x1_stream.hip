@@ -34,6 +34,15 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef STREAM_RES_PREFETCH
 #define STREAM_RES_PREFETCH 0   // 1: the residual tile is DMA'd into its own 16*TJ KB right behind the first K-step's operands
 #endif
+#ifndef STREAM_ABL_NOMFMA
+#define STREAM_ABL_NOMFMA 0   // timing probes (wrong results by construction): no MFMAs | no activation DMA | no keep-byte loads and masking
+#endif
+#ifndef STREAM_ABL_NOX
+#define STREAM_ABL_NOX 0
+#endif
+#ifndef STREAM_ABL_NOKB
+#define STREAM_ABL_NOKB 0
+#endif
 #ifndef STREAM_MAX_CIN
 #define STREAM_MAX_CIN 512
 #endif
@@ -109,11 +118,11 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
     }
     uint32_t kb[MSK ? 2 * TJ : 1];
 #define LOAD_KB(KS)                                                                               \
-    if constexpr (MSK) {                                                                          \
+    if constexpr (MSK && !STREAM_ABL_NOKB) {                                                                          \
         _Pragma("unroll") for (int i = 0; i < 2 * TJ; ++i) kb[i] = bsrc[i] >= 0 ? a.in_bits[(size_t)(unsigned)bsrc[i] + (KS) * 8] : 0xffu; \
     }
 #define APPLY_KB()                                                                                \
-    if constexpr (MSK) {                                                                          \
+    if constexpr (MSK && !STREAM_ABL_NOKB) {                                                                          \
         typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));                         \
         _Pragma("unroll") for (int i = 0; i < 2 * TJ; ++i) {                                      \
             u32x4_s* const pp = (u32x4_s*)(smem + XBASE + (i * 256 + tid) * 16);                  \
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
     }
     LOAD_KB(0);
 #pragma unroll
-    for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i], smem + XBASE + (i * 256 + wave * 64) * 16);
+    for (int i = 0; i < 2 * TJ; ++i) if (!STREAM_ABL_NOX) GLDS16(xsrc[i], smem + XBASE + (i * 256 + wave * 64) * 16);
     const int nK = a.Cin / 64;
 #pragma unroll
     for (int u = 1; u < NSUB; ++u)
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2 * TJ; ++j) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < 2 * TJ; ++j) if (!STREAM_ABL_NOMFMA || (i == 0 && j == 0)) acc[i][j] = mfma_16x16x32<BF>(af[i], bf[j], acc[i][j]);
             }
         }
         if (ks + NSUB < nK) {
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
 #pragma unroll
                 for (int i = 0; i < 4; ++i) GLDS16(wsrc[i] + koff, smem + u * SUB + (i * 256 + wave * 64) * 16);
 #pragma unroll
-                for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i] + koff, smem + u * SUB + XBASE + (i * 256 + wave * 64) * 16);
+                for (int i = 0; i < 2 * TJ; ++i) if (!STREAM_ABL_NOX) GLDS16(xsrc[i] + koff, smem + u * SUB + XBASE + (i * 256 + wave * 64) * 16);
             }
             LOAD_KB(ks + NSUB);
         }

@@ -200,6 +200,13 @@ typedef float f32x4_e __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
 
 #define BMI_EPILOGUE_LDS_BYTES 65536
+// Timing probes (tools/ab_build.py name:-DBMI_ABL_...=1; wrong results by construction, never in the product build)
+#ifndef BMI_ABL_NORES
+#define BMI_ABL_NORES 0      // the lite epilogue neither fetches nor adds the residual
+#endif
+#ifndef BMI_ABL_NOSTORE
+#define BMI_ABL_NOSTORE 0    // the plain / lite epilogues store nothing
+#endif
 #ifndef BMI_DEFAULT_MFMA_SHAPE
 #define BMI_DEFAULT_MFMA_SHAPE 16   // v_mfma_f32_16x16x32_f16 (same-process A/B on the headline step: 26.04 vs 26.82 ms with 32x32x16, bit-identical results)
 #endif
@@ -309,7 +316,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, ACC& acc, char
     for (int it = 0; it < 4 * TJ; ++it) {
         const int pl = (tid >> 4) + 16 * it;
         size_t off;
-        if (!offmap(pl, off)) continue;
+        if (!offmap(pl, off) || BMI_ABL_NOSTORE) continue;
         half8_e v = o[it];
         if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);   // (pl >> 4) & 1 == it & 1: quads swapped
         *(half8_e*)(a.out + off + ch0 + 8 * k) = v;
@@ -404,7 +411,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
     const int HoWo = a.Ho * a.Wo;
     const bool masked = SK >= 0 ? SK == BMI_SITE_ELEMENTWISE : a.site.kind == BMI_SITE_ELEMENTWISE;
     const bool msk = SK >= 0 ? SK == BMI_SITE_MASKSEMBLE : a.site.kind == BMI_SITE_MASKSEMBLE;      // Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M
-    const bool has_res = SK >= 0 ? true : a.res != nullptr;
+    const bool has_res = BMI_ABL_NORES ? false : (SK >= 0 ? true : a.res != nullptr);
     const bool relu = SK >= 0 ? true : a.relu != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -528,7 +535,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
     for (int it = 0; it < 4 * TJ; ++it) {
         const int pl = (tid >> 4) + 16 * it;
         size_t off;
-        if (!offmap(pl, off)) continue;
+        if (!offmap(pl, off) || BMI_ABL_NOSTORE) continue;
         *(half8_e*)(a.out + off + ch0 + 8 * k) = o[it];
     }
 }
