@@ -34,6 +34,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef STREAM_RES_PREFETCH
 #define STREAM_RES_PREFETCH 0   // 1: the residual tile is DMA'd into its own 16*TJ KB right behind the first K-step's operands
 #endif
+#ifndef STREAM_RES_REGS
+#define STREAM_RES_REGS 0       // 1: the specialised residual forms load the residual straight into registers (accumulator layout) at the START of the
+                                // tile: no residual DMA, no wait for it, one barrier less.  Measured 13-17 % SLOWER (128 -> 512 tails 1.90 -> 2.15 ms,
+                                // 256 -> 1024 1.14 -> 1.29, 512 -> 2048 0.76 -> 0.89): 148 VGPRs = three workgroups per CU instead of four, and 8-byte
+                                // loads at a 1 KB stride; same bits (profiles/experiments/r4_stream_ablation.log)
+#endif
 #ifndef STREAM_ABL_NOMFMA
 #define STREAM_ABL_NOMFMA 0   // timing probes (wrong results by construction): no MFMAs | no activation DMA | no keep-byte loads and masking
 #endif
@@ -148,6 +154,19 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
 #pragma unroll
             for (int i = 0; i < 2 * TJ; ++i) GLDS16(xsrc[i] + u * 64, smem + u * SUB + XBASE + (i * 256 + wave * 64) * 16);
         }
+    // (STREAM_RES_REGS, off) the residual quads of this lane's accumulator positions, in flight from the start of the tile
+    constexpr bool RREG = STREAM_RES_REGS && !RPRE && TJ == 2 && (EPI == BMI_EPI_LITE_RES || EPI == BMI_EPI_LITE_RES_MC);
+    typedef half4 rres_t[4][2 * TJ];
+    rres_t rres;
+    if constexpr (RREG) {
+#pragma unroll
+        for (int j = 0; j < 2 * TJ; ++j) {
+            const int m = pix0 + wp * (32 * TJ) + 16 * j + r;
+            const _Float16* rp = a.res + (size_t)(m < a.M ? m : 0) * a.Cout + ch0 + wc * 64 + 4 * kq;    // (rows beyond the tensor: row 0, never stored)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rres[i][j] = *(const half4*)(rp + 16 * i);
+        }
+    }
     if constexpr (RPRE) {
         // the residual tile, in epilogue_lite's layout (chunk q of pixel row p at q ^ (p & 15)), behind the first K-step's operands
         if (a.res) {
@@ -236,7 +255,8 @@ __global__ __launch_bounds__(256, TJ == 4 ? 2 : ((STREAM_RES_PREFETCH && conv_ep
         return pix0 + p < a.M;
     };
     constexpr int SK = EPI == BMI_EPI_LITE_RES ? BMI_SITE_NONE : (EPI == BMI_EPI_LITE_RES_MC ? BMI_SITE_ELEMENTWISE : -1);
-    if constexpr (RPRE) epilogue_lite<TJ, BF, true, false, SK>(a, acc, smem + SUB, tid, ch0, pixmap, offmap);
+    if constexpr (RREG) epilogue_lite<TJ, BF, false, false, SK>(a, acc, smem, tid, ch0, pixmap, offmap, &rres);
+    else if constexpr (RPRE) epilogue_lite<TJ, BF, true, false, SK>(a, acc, smem + SUB, tid, ch0, pixmap, offmap);
     else epilogue_coalesced<TJ, EPI, 16, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
 }
 

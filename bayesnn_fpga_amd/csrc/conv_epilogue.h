@@ -402,9 +402,14 @@ __host__ __device__ constexpr bool conv_epilogue_is_lite(int epi) {
 // sum in every lane, lane 0 stores 4 consecutive channels.  The conv feeds nothing but an exit head (relu -> avg_pool2d(4) -> Linear).
 // SK: the site kind as a compile-time constant (BMI_SITE_NONE | BMI_SITE_ELEMENTWISE | BMI_SITE_MASKSEMBLE), or -1 = whatever the launch carries.  SK >= 0
 // also says the launch HAS a residual whose rows are the output's rows (BMI_EPI_LITE_RES / _RES_MC): its address comes from `offmap`.
-template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, int SK = -1, class ACC, class PixMap, class OffMap>
+// RREG (conv1x1_stream's specialised forms): the caller has loaded the residual quads of this lane's accumulator positions into `rreg`
+// (half4 [4][2 TJ], [i][j] = channels ch0 + wc 64 + 16 i + 4 (lane >> 4) .. of pixel wp 32 TJ + 16 j + (lane & 15)) at the START of its tile:
+// no residual DMA, no wait for it and one barrier less here.
+struct NoResRegs {};
+template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, int SK = -1, class ACC, class PixMap, class OffMap, class RREG = NoResRegs>
 __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
-                                              PixMap pixmap, OffMap offmap) {
+                                              PixMap pixmap, OffMap offmap, RREG* rreg = nullptr) {
+    constexpr bool RES_REGS = !__is_same(RREG, NoResRegs);
     const int lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wp = wave & 1;
     const int l16 = lane & 15, q4 = lane >> 4;
@@ -426,7 +431,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
             for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * sc[e] + bi[e];
     }
     lds_barrier();   // the main loop is done with the LDS
-    if (has_res && !RES_IN_LDS) {
+    if (has_res && !RES_IN_LDS && !RES_REGS) {
 #pragma unroll
         for (int i = 0; i < 4 * TJ; ++i) {
             const int q = i * 256 + tid, p = q >> 4, pos = q & 15;
@@ -455,12 +460,19 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
             mine[r] = philox_site_call(a.site, e0, (uint32_t)(a.t0 + tl));
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
+    if constexpr (!RES_REGS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
 #pragma unroll
     for (int jb = 0; jb < 2 * TJ; jb += 4) {
         half4 r4[4][4];
-        if (has_res) {
+        if constexpr (RES_REGS) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r4[jj][i] = (*rreg)[i][jb + jj];
+        } else if (has_res) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
