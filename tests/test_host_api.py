@@ -177,3 +177,17 @@ def test_one_hip_runtime_in_the_process():
     with open("/proc/self/maps") as f:
         paths = {line.split()[-1] for line in f if "libamdhip64" in line}
     assert len(paths) == 1, paths
+
+
+def test_bmi_options_environment_is_applied_at_load():
+    """BMI_OPTIONS="name=value,..." (bayesnn_fpga_amd/_lib.py): bmi_set_option pairs applied once when the library is loaded — the way a
+    profiling arm is selected under rocprofv3, which wraps bench.py.  A name the library does not know fails loudly."""
+    import subprocess
+    import sys
+    code = "from bayesnn_fpga_amd import _lib; _lib.lib(); print('loaded')"
+    env = dict(os.environ, BMI_OPTIONS="lazy_order=0, pw_persist=1,epilogue_lite=2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "loaded" in r.stdout, r.stderr[-500:]
+    env = dict(os.environ, BMI_OPTIONS="no_such_option=1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "BMI_OPTIONS" in r.stderr
