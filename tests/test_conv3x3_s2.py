@@ -98,11 +98,12 @@ def test_s2_pair_mode(s2_always, cin, ca, cb, H, n):
             assert torch.equal(outs[i], gh.run_conv(x, ws[i], scs[i], bis[i], None, True, 2, 1, n, n, 1))
 
 
-def test_s2_bf16(s2_always):
+@pytest.mark.parametrize("cin,cout,H", [(128, 256, 16), (128, 128, 32)])
+def test_s2_bf16(s2_always, cin, cout, H):
     _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
     try:
         g = _gen(3)
-        n, cin, cout, H = 9, 128, 256, 16
+        n = 9
         x = torch.randn(n, H, H, cin, generator=g).to(torch.bfloat16).to(DEV)
         w = (torch.randn(cout, 3, 3, cin, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(torch.bfloat16).to(DEV)
         scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)

@@ -54,6 +54,26 @@ def test_device_exit_equals_posthoc_rule_on_the_full_run(name):
             assert (got == 3).all() and act[2] == B
 
 
+def test_device_exit_resnet50_bottleneck_net():
+    """ResNet-50 multi-exit (models/extra.py): after the first tested exit the Bottleneck convs carry a row table — the 1x1 convs leave
+    conv1x1_stream for conv_igemm_wide / conv_igemm (the same K order), `layer2[0].conv2` (128 -> 128, stride 2) runs in the dynamic-exit
+    form of conv3x3_s2's 128-channel tiles: every image's prediction at its exit equals the full run's."""
+    from bayesnn_fpga_amd.models import extra as bx
+    B, T, seed = 45, 6, 13
+    m = build_seeded(bx.ResNet50MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10))
+    synthetic_weights_(m, 0)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    x = synthetic_images(B, seed=23).to(DEV)
+    full = eng.predict(x, T, seed=seed)
+    p_full = full["mean"].cpu().numpy()
+    conf = p_full.max(-1)
+    for thr in (float(np.median(conf[1])), float(np.quantile(conf[2], 0.3)), 1.0):
+        want = cex.exit_layer(p_full.copy(), thr)
+        r = eng.predict_with_exit(x, T, thr, seed=seed)
+        np.testing.assert_array_equal(r["exit_layer"].cpu().numpy(), want)
+        np.testing.assert_allclose(r["best_preds"].cpu().numpy(), p_full[want, np.arange(B)], rtol=0, atol=1e-13)
+
+
 @pytest.mark.parametrize("B,chunk", [(1, None), (4, None), (11, None), (45, 6)])
 def test_device_exit_on_small_batches(B, chunk):
     """Batches whose full-chunk grid is too small for conv3x3_pw (B <= 11 with the default chunk, or an explicit small chunk)
