@@ -574,6 +574,12 @@ struct PwpGeom {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+#ifndef PWP_DIRECT
+#define PWP_DIRECT 1      // the MFMA rows of a wave's four channel tiles are a PERMUTATION of its 64 channels — row r of tile i is channel
+                          // 32 (i >> 1) + 8 (r >> 2) + 4 (i & 1) + (r & 3) — so that a lane's accumulators are, per pixel, two runs of 8 consecutive
+                          // channels: the epilogue stores them straight from the registers (two 16-byte stores per pixel tile; the four lanes of a
+                          // pixel write 64 contiguous bytes per store) with no trip through LDS and no barrier.  0: conv3x3_s2's epilogue through LDS
+#endif
 template <int TW, bool BF, bool SHORTCUT>
 __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_tiles) {
     using G = PwGeom<TW>;
@@ -610,7 +616,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
 #pragma unroll
     for (int i = 0; i < G::WROWS; ++i) {
         const int row = (tid >> 2) + 128 * i;
-        woff[i] = 2u * ((unsigned)row * Ktot + (((tid & 3) ^ (((row >> 2) & 1) << 1)) << 3));
+        // (PWP_DIRECT: a fragment's 16 lanes read rows 8 a + b + const, a = 0..3, b = 0..3: the chunk position alternates with row >> 3)
+        woff[i] = 2u * ((unsigned)row * Ktot + (((tid & 3) ^ (((row >> (PWP_DIRECT ? 3 : 2)) & 1) << 1)) << 3));
     }
     const unsigned wbytes = 2u * (unsigned)CT * Ktot;
     const unsigned HWC = (unsigned)a.H * a.W * a.Cin;
@@ -646,7 +653,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
     }
 
     // ---- per-lane fragment geometry (tile-independent) ----
-    const int a_off = (g * 128 + wc * 64 + l16) * 64;
+    const int a_off = (g * 128 + wc * 64 + (PWP_DIRECT ? 8 * (l16 >> 2) + (l16 & 3) : l16)) * 64;
+    // byte offset of channel tile i's row of this lane relative to a_off
+#define A_TILE(I) (PWP_DIRECT ? (32 * ((I) >> 1) + 4 * ((I) & 1)) * 64 : (I) * 16 * 64)
     const int pbase = wp * 128;
     const int a_byte = (kq ^ (((l16 >> 2) & 1) << 1)) << 4;
     const int wave_cell = (G::p_img(pbase) * PH + G::p_oy(pbase)) * PWP + G::p_ox(pbase);
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
         const char* pb_ = pb + (ky_ * PWP + kx_) * 64;                                                         \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
             if (kk == 0) {                                                                                     \
-                _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
+                _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + A_TILE(i));       \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(pb_ + boff[ky_] + G::cell_delta(4 * kk + j) * 64); \
             if (kk == 0) {                                                                                     \
@@ -765,7 +774,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
             const int nC2 = a.Cin2 / 32;
             constexpr int XROWS = G::PX / 128, SST = G::WST + G::PX * 64;
             char* const sbase = smem + L::E_OFF;
-            const int lg = ((tid & 3) ^ (((tid >> 4) & 1) << 1)) * 8;
+            const int lg = ((tid & 3) ^ (((tid >> 4) & 1) << 1)) * 8;                                  // pixel rows: chunk position alternates with row >> 2
+            const int lgw = PWP_DIRECT ? ((tid & 3) ^ (((tid >> 5) & 1) << 1)) * 8 : lg;               // weight rows (PWP_DIRECT): with row >> 3
             int x2off[XROWS];
 #pragma unroll
             for (int i = 0; i < XROWS; ++i) {
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
 #define ISSUE_S(C2, ST)                                                                                        \
     {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < G::WROWS; ++i)                                                   \
-            GLDS16(a.wgt2 + (size_t)(ch0 + (tid >> 2) + 128 * i) * a.Cin2 + lg + (C2) * 32, sbase + (ST) * SST + (i * 512 + wave * 64) * 16); \
+            GLDS16(a.wgt2 + (size_t)(ch0 + (tid >> 2) + 128 * i) * a.Cin2 + lgw + (C2) * 32, sbase + (ST) * SST + (i * 512 + wave * 64) * 16); \
         _Pragma("unroll") for (int i = 0; i < XROWS; ++i)                                                      \
             GLDS16(x2off[i] >= 0 ? a.in2 + (size_t)(unsigned)x2off[i] + (C2) * 32 : (const _Float16*)g_zero_page_pw, \
                    sbase + (ST) * SST + G::WST + (i * 512 + wave * 64) * 16);                                  \
@@ -791,7 +801,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
                 const char* ss = sbase + (c2 & 1) * SST;
                 half8 sa[TI], sb[TP];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) sa[i] = *(const half8*)(ss + a_off + i * 16 * 64 + a_byte);
+                for (int i = 0; i < TI; ++i) sa[i] = *(const half8*)(ss + a_off + A_TILE(i) + a_byte);
 #pragma unroll
                 for (int j = 0; j < TP; ++j) sb[j] = *(const half8*)(ss + G::WST + (pbase + 16 * j + l16) * 64 + a_byte);
 #pragma unroll
@@ -804,8 +814,37 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
             RAW_BARRIER();
         }
 
-        // ---- epilogue (conv3x3_s2's): BN + ReLU on the accumulators, fp16 through LDS, 32 KB per channel half, two rounds of 128 pixels ----
-        {
+        if constexpr (PWP_DIRECT) {
+            // ---- epilogue straight from the registers: lane (kq, l16) holds, for pixel tile j, channels 8 kq .. + 7 (tiles 0, 1) and
+            //      32 + 8 kq .. + 7 (tiles 2, 3) of the wave's 64 channels of pixel pbase + 16 j + l16 ----
+            const int chw = ch0 + 128 * g + wc * 64 + 8 * kq;
+            f32x4_e sc[4], bi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c4 = chw + 32 * (i >> 1) + 4 * (i & 1);
+                sc[i] = *(const f32x4_e*)(bn_scale + c4);
+                bi[i] = *(const f32x4_e*)(bn_bias + c4);
+            }
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = pbase + 16 * j + l16;
+                const int n = n0 + G::p_img(p);
+                _Float16* const dst = a.out + ((size_t)n * (TH * TW) + G::p_oy(p) * TW + G::p_ox(p)) * a.Cout + chw;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    half8_e o;
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[2 * h + ii][j][e] * sc[2 * h + ii][e] + bi[2 * h + ii][e];
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            o[4 * ii + e] = a16_from_f32<BF>(v);
+                        }
+                    if (n < a.N) *(half8_e*)(dst + 32 * h) = o;
+                }
+            }
+        } else {
             char* const E = smem + L::E_OFF + g * 32768;
             int tl = tid & 255;
             asm volatile("" : "+v"(tl));
@@ -868,6 +907,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
 #undef TILE_RSRC_IN
 #undef TILE_RSRC_W
 #undef ISSUE_W
+#undef A_TILE
 #undef BLDS16
 }
 

@@ -44,6 +44,11 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef S2_DIRECT
+#define S2_DIRECT 1          // conv3x3_pwp's PWP_DIRECT: the MFMA rows of a wave's four channel tiles are a permutation of its 64 channels (row r of tile i =
+                             // channel 32 (i >> 1) + 8 (r >> 2) + 4 (i & 1) + (r & 3)), so a lane holds two runs of 8 consecutive channels per pixel and the
+                             // epilogue stores them straight from the registers — no trip through LDS, no barrier.  0: the two rounds through LDS
+#endif
 #ifndef S2_RELAX0
 #define S2_RELAX0 0          // 1: the previous tile's 16 output stores may stay in flight through step 0 of the next tile (see END_OF_STEP_WAIT).
                              // Built and measured in round 4 (same-box A/B on the five stride-2 classes, bit-identical): neutral (+-0.5 %): off
@@ -300,7 +305,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 
     // ---- per-lane fragment geometry (tile-independent) ----
     // weights: row (g*128 + wc*64 + l16 + 16 i), chunk kq at position kq ^ 2 ((row >> 2) & 1) = kq ^ 2 ((l16 >> 2) & 1)
-    const int a_off = ((HALF ? 0 : g * 128) + wc * 64 + l16) * 64 + ((kq ^ (((l16 >> 2) & 1) << 1)) << 4);
+    const int a_off = ((HALF ? 0 : g * 128) + wc * 64 + (S2_DIRECT ? 8 * (l16 >> 2) + (l16 & 3) : l16)) * 64 + ((kq ^ (((l16 >> 2) & 1) << 1)) << 4);
+    // byte offset of channel tile i's row of this lane relative to a_off
+#define A_TILE(I) (S2_DIRECT ? (32 * ((I) >> 1) + 4 * ((I) & 1)) * 64 : (I) * 16 * 64)
     // pixels: lane (by, bx) = (l16 >> 2, l16 & 3) of each 4 x 4 block; plane row parity of the cell = (by + dy) & 1
     const int by = l16 >> 2, bx = l16 & 3;
     const int pbase = HALF ? (g * 2 + wp) * 64 : wp * 128;        // first tile pixel of this wave
@@ -349,7 +356,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
     int tsel = 0;
     // weights: piece q = tid + 512 i -> row (tid >> 2) + 128 i, position tid & 3 holds chunk (tid & 3) ^ 2 ((row >> 2) & 1);
     // one descriptor per 128-row half of the channel tile (a pair's second conv has its own weight tensor)
-    const unsigned woff = 2u * ((unsigned)(tid >> 2) * Ktot + (((tid & 3) ^ (((tid >> 4) & 1) << 1)) << 3));
+    // (S2_DIRECT: a fragment's 16 lanes read rows 8 a + b + const: the chunk position alternates with row >> 3 instead of row >> 2)
+    const unsigned woff = 2u * ((unsigned)(tid >> 2) * Ktot + (((tid & 3) ^ (((tid >> (S2_DIRECT ? 5 : 4)) & 1) << 1)) << 3));
     const unsigned wbytes = 2u * 128u * Ktot;
     // element offset of channel chunk C0 (a multiple of 32) = C0 * cmul: 1 in NHWC, H * W in the planar layout (one 32-channel plane per chunk)
     const unsigned cmul = (MSK && a.lazy_planar) ? (unsigned)(a.H * a.W) : 1u;
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
             if constexpr (MSK && due0_ >= 0) { if (kk == S2_MASK_PHASE && due_on_) { MASK_LOAD(due0_ < 0 ? 0 : due0_, mw0_, mv0_); } } \
             if (kk == 0) {                                                                                     \
-                _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + i * 16 * 64);     \
+                _Pragma("unroll") for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(ws_ + A_TILE(i));       \
             }                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < JB; ++j)                                                     \
                 if (!S2_ABL_HALFREADS || !(j & 1)) bf[j] = *(const half8*)(pb_ + G::cell_delta(pl_, JB * kk + j) * 64); \
@@ -693,7 +701,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                 // through LDS; the three barriers keep step with a channel half that takes the ordinary path.
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int c4 = chl + wc * 64 + 16 * i + 4 * kq;
+                    const int cw = S2_DIRECT ? 32 * (i >> 1) + 8 * kq + 4 * (i & 1) : 16 * i + 4 * kq;      // this lane's 4 channels of tile i
+                    const int c4 = chl + wc * 64 + cw;
                     const f32x4_e sc = *(const f32x4_e*)(bn_scale + c4), bi = *(const f32x4_e*)(bn_bias + c4);
 #pragma unroll
                     for (int j = 0; j < TP; ++j) {
@@ -710,10 +719,41 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
                         int n = cur_n0 + wp * 8 + j;
                         if constexpr (IMAP) n = row_tabs[cur_tsel * 16 + wp * 8 + j];
                         else if (n >= a.N) n = -1;
-                        if (l16 == 0 && n >= 0) *(f32x4_e*)(poolp + (size_t)n * oc + chg + wc * 64 + 16 * i + 4 * kq) = v;
+                        if (l16 == 0 && n >= 0) *(f32x4_e*)(poolp + (size_t)n * oc + chg + wc * 64 + cw) = v;
                     }
                 }
-                lds_barrier(); lds_barrier(); lds_barrier();
+                if (!S2_DIRECT) { lds_barrier(); lds_barrier(); lds_barrier(); }
+            } else if constexpr (S2_DIRECT) {
+                // straight from the registers: lane (kq, l16) holds, for pixel tile j, channels 8 kq .. + 7 (tiles 0, 1) and 32 + 8 kq .. + 7
+                // (tiles 2, 3) of the wave's 64 channels of tile pixel pbase + 16 j + l16; the four lanes of a pixel write 64 contiguous bytes
+                const int cw = wc * 64 + 8 * kq;
+                f32x4_e sc[4], bi[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sc[i] = *(const f32x4_e*)(bn_scale + chl + cw + 32 * (i >> 1) + 4 * (i & 1));
+                    bi[i] = *(const f32x4_e*)(bn_bias + chl + cw + 32 * (i >> 1) + 4 * (i & 1));
+                }
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const int p = pbase + 16 * j + l16;
+                    int n = cur_n0 + G::p_img(p);
+                    if constexpr (IMAP) n = row_tabs[cur_tsel * 16 + G::p_img(p)];      // tensor row, -1 beyond N
+                    else if (n >= a.N) n = -1;
+                    _Float16* const dst = outp + ((size_t)(n < 0 ? 0 : n) * (TW * TW) + G::p_oy(p) * TW + G::p_ox(p)) * oc + chg + cw;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        half8_e o;
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[2 * h + ii][j][e] * sc[2 * h + ii][e] + bi[2 * h + ii][e];
+                                if (a.relu) v = fmaxf(v, 0.f);
+                                o[4 * ii + e] = a16_from_f32<BF>(v);
+                            }
+                        if (n >= 0 && !S2_ABL_NOSTORE) *(half8_e*)(dst + 32 * h) = o;
+                    }
+                }
             } else
 #pragma unroll
             for (int rr = 0; rr < (HALF ? 1 : 2); ++rr) {   // (128-channel tiles: a group's 128 ch x 128 px are one round)
@@ -785,6 +825,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #undef ISSUE_P
 #undef ISSUE_W
 #undef ISSUE_W_HALF
+#undef A_TILE
 }
 
 int& opt_conv_s2() { static int v = 1; return v; }
