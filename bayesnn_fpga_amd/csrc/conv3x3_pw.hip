@@ -555,8 +555,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // that would prefetch "the next chunk" — the weight stages of steps 0 / 1 (issued at taps 7 / 8) and the pieces of sub-patch 0 (taps
 // 1..ITER_P) — fetch the NEXT TILE's instead, with the unchanged counted-vmcnt schedule; Cin % 64 == 0 makes the last chunk odd, so what it
 // prefetches lands in stages 0 / 1 and sub-patch buffer 0.  The LDS map [W0 | W1 | P0 | W2 | P1 | pad] keeps those three outside the
-// 64 KB [W2 | P1 | pad] the epilogue (conv3x3_s2's: two rounds of 128 pixels per channel half, BN from an LDS table — a global load there
-// would wait for every DMA in flight) and the shortcut's K-steps work in.  A full tile leaves its 16 output stores per thread in flight
+// 64 KB [W2 | P1 | pad] the shortcut's K-steps work in (and the epilogue did before PWP_DIRECT: conv3x3_s2's two rounds of 128 pixels per channel
+// half; BN comes from an LDS table — a global load there would wait for every DMA in flight).  A full tile leaves its 16 output stores per thread in flight
 // across the tile boundary (vmcnt(16)).  Why: per-tile fixed cost of conv3x3_pw from its own K = 2304 / 4608 rates (1308 / 1422 TFLOP/s, corrected
 // for the last partial round of tiles): 14-21 K-steps' worth per tile, of which the prologue's HBM round trip and the workgroup hand-over are
 // what a persistent walk removes.  Same K order, same arithmetic, same bits as conv3x3_pw_kernel<TW, PLAIN>.

@@ -33,8 +33,8 @@
 //                wave groups one barrier apart, weights of the step AFTER NEXT in flight, counted vmcnt with compile-time
 //                immediates (the 9 steps of a chunk are unrolled).  Per step at most two patch pieces ride along.
 //   persistent = one workgroup per CU walks the tiles; the next tile's weight stages 0 / 1 and its plane A / B pieces are
-//                issued when the main loop ends and land while the epilogue (BN + ReLU, fp16, two rounds of 128 pixels per
-//                channel half in the 64 KB the C / D pieces and W2 occupy) runs.
+//                issued when the main loop ends and land while the epilogue runs (BN + ReLU on the accumulators, fp16 straight from the
+//                registers: S2_DIRECT; formerly two rounds of 128 pixels per channel half through the 64 KB the C / D pieces and W2 occupy).
 //   pair mode  = as conv_igemm_wide: channel tiles >= split use the second conv's weights / BN / output tensor.
 //   epilogue   = plain (BN + ReLU) only: every stride-2 conv of the path.  Anything else stays with conv_igemm_wide.
 #include <cstdlib>
@@ -672,8 +672,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
         const int nvb = vb + v_step;
         if (nvb < v_end) SETUP_TILE(nvb);
 
-        // ---- epilogue of the current tile: BN + ReLU on the accumulators, fp16 through LDS, 32 KB per channel half,
-        //      two rounds of 128 pixels (conv_igemm_wide_persist's, with this kernel's tile-pixel order) ----
+        // ---- epilogue of the current tile: BN + ReLU on the accumulators, fp16 straight from the registers (S2_DIRECT) or through LDS, 32 KB per
+        //      channel half, two rounds of 128 pixels (conv_igemm_wide_persist's, with this kernel's tile-pixel order) ----
         if (S2_ABL_NOEPI) {
             float sum_ = 0.f;
 #pragma unroll
