@@ -54,6 +54,7 @@ def test_repeat_launches_are_bit_identical_under_memory_traffic(mfma_shape):
 S2_SHAPES = [
     (64, 256, 32, 3, 2, 1, 230), (64, 256, 32, 3, 2, 1, 1500), (128, 256, 16, 3, 2, 1, 1000), (128, 512, 16, 3, 2, 1, 3001),
     (256, 512, 8, 3, 2, 1, 1800), (256, 1024, 8, 3, 2, 1, 5003), (256, 512, 8, 3, 2, 1, 12000),
+    (128, 128, 32, 3, 2, 1, 300), (256, 128, 32, 3, 2, 1, 1300),      # the 128-channel tiles (round 4): a tile or five per CU
 ]
 
 

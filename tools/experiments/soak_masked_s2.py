@@ -12,7 +12,9 @@ from tests import gpu_helpers as gh
 from tests.test_gpu_kernels import _conv_inputs
 
 lib = _lib.lib()
-B, tc, cin, cout, H, t0, seed, p = 25, 40, 64, 256, 32, 3, (7 << 32) + 5, 0.25
+# argv[2] = "half": the 128-channel tiles (256 -> 128, ResNet-50's lazy reader) instead of the 64 -> 128 + 128 pair shape
+HALF = len(sys.argv) > 2 and sys.argv[2] == "half"
+B, tc, cin, cout, H, t0, seed, p = (25, 40, 256, 128, 32, 3, (7 << 32) + 5, 0.25) if HALF else (25, 40, 64, 256, 32, 3, (7 << 32) + 5, 0.25)
 N = B * tc
 x, w, scale, bias, g = _conv_inputs(cin, cout, H, 3, B, 321, False)
 x = torch.relu(x)
