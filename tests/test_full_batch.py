@@ -217,7 +217,8 @@ def test_lazy_first_site_resnet50():
     assert ms_lazy < 0.7 * ms_plain
 
 
-@pytest.mark.parametrize("arch,batch,T", [("resnet18", 60, 7), ("resnet18", 250, 3), ("resnet50", 250, 3), ("resnet50", 36, 9)])
+@pytest.mark.parametrize("arch,batch,T", [("resnet18", 60, 7), ("resnet18", 250, 3), ("resnet50", 250, 3), ("resnet50", 36, 9),
+                                          ("resnet50", 5, 3), ("resnet50", 3, 5), ("resnet18", 5, 3)])      # small grids: conv_igemm's masked form, 30 tiles on 32 blocks
 def test_lazy_tile_order_is_placement_only(arch, batch, T):
     """`lazy_order` (conv_epilogue.h lazy_tile_map; conv3x3_s2's contiguous walk): the readers of a lazy site take their tiles sample-minor so
     that one activation tile's samples run back to back on one XCD.  Placement only: every bit equals the plain order — with ragged
