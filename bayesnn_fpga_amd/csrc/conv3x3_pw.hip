@@ -580,8 +580,14 @@ struct PwpGeom {
                           // channels: the epilogue stores them straight from the registers (two 16-byte stores per pixel tile; the four lanes of a
                           // pixel write 64 contiguous bytes per store) with no trip through LDS and no barrier.  0: conv3x3_s2's epilogue through LDS
 #endif
-template <int TW, bool BF, bool SHORTCUT>
+// EPIK: BMI_EPI_PLAIN, or (PWP_DIRECT only) BMI_EPI_LITE_RES / BMI_EPI_LITE_RES_MC — the BasicBlock tails (residual whose rows are the output's rows,
+// ReLU, optionally the 2-bit elementwise site) finished straight from the registers too: a lane fetches the two 16-byte residual runs of each of its
+// pixel tiles itself (the four lanes of a pixel read 64 contiguous bytes per instruction), so the lite epilogue's residual DMA, its 2 x 64 KB of LDS and
+// its three barriers are gone and these launches can take the persistent walk.  Same arithmetic in the same order as epilogue_lite: the same bits.
+template <int TW, bool BF, bool SHORTCUT, int EPIK = BMI_EPI_PLAIN>
 __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_tiles) {
+    static_assert(EPIK == BMI_EPI_PLAIN || (PWP_DIRECT && !SHORTCUT && (EPIK == BMI_EPI_LITE_RES || EPIK == BMI_EPI_LITE_RES_MC || EPIK == BMI_EPI_LITE_RES_MSK)),
+                  "epilogue kind");
     using G = PwGeom<TW>;
     using L = PwpGeom<TW>;
     constexpr int CT = G::CT, TH = G::TH, IMGS = G::IMGS, PH = G::PH, PW = G::PW, PWP = G::PWP;
@@ -814,7 +820,73 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
             RAW_BARRIER();
         }
 
-        if constexpr (PWP_DIRECT) {
+        if constexpr (EPIK != BMI_EPI_PLAIN) {
+            // ---- BasicBlock tail straight from the registers (see EPIK above) ----
+            constexpr bool MC = EPIK == BMI_EPI_LITE_RES_MC, MSKS = EPIK == BMI_EPI_LITE_RES_MSK;
+            const int chw = ch0 + 128 * g + wc * 64 + 8 * kq;
+            // the residual runs of this lane: run h of pixel tile j = 8 channels at chw + 32 h (rows beyond the tensor read row 0, never stored)
+            half8_e rres[2][TP];
+            unsigned poff[TP];                                    // element offset of the pixel's row / 8 (< 2^32: launcher)
+            int mrow[MSKS ? TP : 1];                              // Masksembles: element offset of this lane's multipliers in the mask table
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = pbase + 16 * j + l16;
+                const int n = n0 + G::p_img(p);
+                poff[j] = (unsigned)((((size_t)(n < a.N ? n : 0) * (TH * TW) + G::p_oy(p) * TW + G::p_ox(p)) * a.Cout + chw) >> 3);
+                if constexpr (MSKS) mrow[j] = ((a.site.cnt0 + a.t0 + n / a.B) % a.site.num_masks) * a.Cout + chw;     // Masksembles2D: mask (cnt0 + t) mod M
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) rres[h][j] = *(const half8_e*)(a.res + ((size_t)poff[j] << 3) + 32 * h);
+            // the site's Philox calls while the residual is in flight: one call = the 64 channels of (pixel, wave); this lane draws the calls of
+            // its own pixel column for the tiles j = kq and kq + 4, the four lanes of a column exchange words (epilogue_lite's distribution)
+            philox4 mine[TP / 4];
+            if constexpr (MC) {
+#pragma unroll
+                for (int r = 0; r < TP / 4; ++r) {
+                    const int p = pbase + 16 * (kq + 4 * r) + l16;
+                    const int n = n0 + G::p_img(p);
+                    const int tl = n / a.B;
+                    const uint64_t e0 = (uint64_t)((n - tl * a.B) * (TH * TW) + G::p_oy(p) * TW + G::p_ox(p)) * a.Cout + ch0 + 128 * g + wc * 64;
+                    mine[r] = philox_site_call(a.site, e0, (uint32_t)(a.t0 + tl));
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4_e sc[2], bi[2];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    sc[ii] = *(const f32x4_e*)(bn_scale + chw + 32 * h + 4 * ii);
+                    bi[ii] = *(const f32x4_e*)(bn_bias + chw + 32 * h + 4 * ii);
+                }
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    uint32_t fields = 0u;
+                    if constexpr (MC) {
+                        const int src = l16 + 16 * (j & 3);
+                        const uint32_t wa = (uint32_t)__shfl((int)mine[j >> 2].w[2 * h], src, 64), wb = (uint32_t)__shfl((int)mine[j >> 2].w[2 * h + 1], src, 64);
+                        fields = ((kq >> 1) ? wb : wa) >> (16 * (kq & 1));          // channels 32 h + 8 kq ..: word 2 h + (kq >> 1), half kq & 1
+                    }
+                    half8_e o;
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[2 * h + ii][j][e] * sc[ii][e] + bi[ii][e];
+                            asm("" : "+v"(v));                                  // (epilogue_lite rounds BN into the accumulator before the residual is added)
+                            v += a16_to_f32<BF>(rres[h][j][4 * ii + e]);
+                            v = fmaxf(v, 0.f);
+                            if constexpr (MC) v = ((fields >> (2 * (4 * ii + e))) & 3u) >= a.site.thresh ? v * a.site.scale : 0.f;
+                            if constexpr (MSKS) { const float mk = a.site.masks[mrow[j] + 32 * h + 4 * ii + e]; v = mk == 0.f ? 0.f : v * mk; }
+                            asm("" : "+v"(v));                                  // keep the fp32 product (epilogue_lite): rounded once
+                            o[4 * ii + e] = a16_from_f32<BF>(v);
+                        }
+                    const int p = pbase + 16 * j + l16;
+                    if (n0 + G::p_img(p) < a.N) *(half8_e*)(a.out + ((size_t)poff[j] << 3) + 32 * h) = o;
+                }
+            }
+        } else if constexpr (PWP_DIRECT) {
             // ---- epilogue straight from the registers: lane (kq, l16) holds, for pixel tile j, channels 8 kq .. + 7 (tiles 0, 1) and
             //      32 + 8 kq .. + 7 (tiles 2, 3) of the wave's 64 channels of pixel pbase + 16 j + l16 ----
             const int chw = ch0 + 128 * g + wc * 64 + 8 * kq;
@@ -964,6 +1036,28 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
         const dim3 block4(256);
         if (epi == BMI_EPI_PLAIN) hipLaunchKernelGGL((conv3x3_pw4_kernel<TW, BMI_EPI_PLAIN, false, false>), grid, block4, 0, s, a);
         else hipLaunchKernelGGL((conv3x3_pw4_kernel<TW, BMI_EPI_LITE, false, false>), grid, block4, 0, s, a);
+        BMI_CHECK_LAUNCH();
+        return BMI_OK;
+    }
+    if (PWP_DIRECT && opt_pw_persist() && opt_conv_pw() < 3 && (epi_fine == BMI_EPI_LITE_RES || epi_fine == BMI_EPI_LITE_RES_MC || epi_fine == BMI_EPI_LITE_RES_MSK) && !a.in2 && a.Cin % 64 == 0 &&
+        a.Cout <= 512 && a.in_mod >= a.N && (size_t)a.H * a.W * a.Cin * PwGeom<TW>::IMGS * 2 < 0xfffffff0ull && (size_t)a.N * a.Ho * a.Wo * a.Cout < (8ull << 32)) {
+        // the BasicBlock tails on the persistent walk, finished straight from the registers (conv3x3_pwp_kernel<.., EPIK>): the same bits
+        static const int n_cu = [] {
+            int dev = 0, cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+            return cu > 0 ? cu : 256;
+        }();
+        const dim3 pgrid((unsigned)(tiles < n_cu ? tiles : n_cu));
+        if (epi_fine == BMI_EPI_LITE_RES) {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, true, false, BMI_EPI_LITE_RES>), pgrid, block, 0, s, a, (int)tiles);
+            else hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, false, false, BMI_EPI_LITE_RES>), pgrid, block, 0, s, a, (int)tiles);
+        } else if (epi_fine == BMI_EPI_LITE_RES_MSK) {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, true, false, BMI_EPI_LITE_RES_MSK>), pgrid, block, 0, s, a, (int)tiles);
+            else hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, false, false, BMI_EPI_LITE_RES_MSK>), pgrid, block, 0, s, a, (int)tiles);
+        } else {
+            if (a.bf16) hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, true, false, BMI_EPI_LITE_RES_MC>), pgrid, block, 0, s, a, (int)tiles);
+            else hipLaunchKernelGGL((conv3x3_pwp_kernel<TW, false, false, BMI_EPI_LITE_RES_MC>), pgrid, block, 0, s, a, (int)tiles);
+        }
         BMI_CHECK_LAUNCH();
         return BMI_OK;
     }

@@ -473,6 +473,44 @@ def test_persistent_pw_equals_the_per_tile_kernel_bit_for_bit(name, n, shortcut,
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name,n,dt", [("S3", 1031, "f16"), ("S4", 4101, "f16"), ("S3", 2050, "bf16"), ("S4", 5000, "bf16"), ("S4", 37, "f16")])
+@pytest.mark.parametrize("use_site", [0, 1, 2])
+def test_persistent_pw_basicblock_tails_equal_the_lite_epilogue_bit_for_bit(name, n, dt, use_site):
+    """conv3x3_pwp with EPIK = LITE_RES / LITE_RES_MC (round 4): the BasicBlock tails (BN + residual + ReLU [+ the 2-bit elementwise site]) on the
+    persistent walk, finished straight from the registers in the channel-permuted accumulator layout (a lane fetches its own residual runs, the
+    Philox words are exchanged inside a pixel column) — against conv3x3_pw_kernel's lite epilogue ("pw_persist" = 0): identical bits, ragged last
+    tiles, several tiles per CU and fewer tiles than CUs, fp16 and bf16; and against the general epilogue ("epilogue_lite" = 0)."""
+    cin, cout, H, k, s, p = SHAPES[name]
+    g = _gen(23)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    x = torch.randn(n, H, H, cin, generator=g).to(tdt).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(tdt).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    res = torch.randn(n, H, H, cout, generator=g).to(tdt).to(DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=2, p=0.25) if use_site == 1 else None
+    if use_site == 2:      # Masksembles2D: per-channel multipliers of mask (cnt0 + t) mod M, t = image // batch
+        site = dict(kind=_lib.SITE_MASKSEMBLE, site_id=1, masks=(torch.rand(4, cout, generator=g) < 0.6).float().numpy() * 1.5)
+    if dt == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    _lib.set_option("conv_pw", 2)
+    outs = []
+    try:
+        for persist, lite in ((0, 1), (1, 1), (0, 0)):
+            _lib.set_option("pw_persist", persist)
+            _lib.set_option("epilogue_lite", lite)
+            outs.append(gh.run_conv(x, w, scale, bias, res, True, s, p, n, n, n, site=site, batch=7, t0=3, seed=9, cnt0=2, out_dtype=tdt))
+    finally:
+        _lib.set_option("pw_persist", 1)
+        _lib.set_option("epilogue_lite", 1)
+        _lib.set_option("conv_pw", 1)
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0
+    if use_site:
+        assert float((outs[0] == 0).float().mean()) > 0.25            # dropped elements (and ReLU zeros)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+
+
 def test_conv_pair_rejects_bad_splits():
     lib = _lib.lib()
     z = torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=DEV)
