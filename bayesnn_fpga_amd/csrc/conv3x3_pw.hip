@@ -584,8 +584,11 @@ struct PwpGeom {
 // ReLU, optionally the 2-bit elementwise site) finished straight from the registers too: a lane fetches the two 16-byte residual runs of each of its
 // pixel tiles itself (the four lanes of a pixel read 64 contiguous bytes per instruction), so the lite epilogue's residual DMA, its 2 x 64 KB of LDS and
 // its three barriers are gone and these launches can take the persistent walk.  Same arithmetic in the same order as epilogue_lite: the same bits.
-template <int TW, bool BF, bool SHORTCUT, int EPIK = BMI_EPI_PLAIN>
+// POOLP (4x4 maps, ConvArgs::pool): the tail feeds nothing but an exit head — instead of the map, fp32 means over it ([row][Cout]) of relu(.): a pixel
+// tile is one image, its 16 pixels the 16 lanes of a DPP row (epilogue_lite's POOL: the same four adds in the same order).
+template <int TW, bool BF, bool SHORTCUT, int EPIK = BMI_EPI_PLAIN, bool POOLP = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_tiles) {
+    static_assert(!POOLP || (TW == 4 && EPIK != BMI_EPI_PLAIN), "pooled output: the 4x4 maps' BasicBlock tails");
     static_assert(EPIK == BMI_EPI_PLAIN || (PWP_DIRECT && !SHORTCUT && (EPIK == BMI_EPI_LITE_RES || EPIK == BMI_EPI_LITE_RES_MC || EPIK == BMI_EPI_LITE_RES_MSK)),
                   "epilogue kind");
     using G = PwGeom<TW>;
@@ -869,6 +872,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
                         fields = ((kq >> 1) ? wb : wa) >> (16 * (kq & 1));          // channels 32 h + 8 kq ..: word 2 h + (kq >> 1), half kq & 1
                     }
                     half8_e o;
+                    f32x4_e pv[2];
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -880,10 +884,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
                             if constexpr (MC) v = ((fields >> (2 * (4 * ii + e))) & 3u) >= a.site.thresh ? v * a.site.scale : 0.f;
                             if constexpr (MSKS) { const float mk = a.site.masks[mrow[j] + 32 * h + 4 * ii + e]; v = mk == 0.f ? 0.f : v * mk; }
                             asm("" : "+v"(v));                                  // keep the fp32 product (epilogue_lite): rounded once
-                            o[4 * ii + e] = a16_from_f32<BF>(v);
+                            if constexpr (POOLP) {
+                                float x = fmaxf(v, 0.f);                       // (the head's ReLU)
+                                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+                                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+                                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // 7 - lane (half row)
+                                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // 15 - lane (row)
+                                pv[ii][e] = x * (1.f / 16.f);
+                            } else {
+                                o[4 * ii + e] = a16_from_f32<BF>(v);
+                            }
                         }
                     const int p = pbase + 16 * j + l16;
-                    if (n0 + G::p_img(p) < a.N) *(half8_e*)(a.out + ((size_t)poff[j] << 3) + 32 * h) = o;
+                    const int nimg = n0 + G::p_img(p);
+                    if constexpr (POOLP) {
+                        if (l16 == 0 && nimg < a.N) {
+                            *(f32x4_e*)(a.pool + (size_t)nimg * a.Cout + chw + 32 * h) = pv[0];
+                            *(f32x4_e*)(a.pool + (size_t)nimg * a.Cout + chw + 32 * h + 4) = pv[1];
+                        }
+                    } else if (nimg < a.N) {
+                        *(half8_e*)(a.out + ((size_t)poff[j] << 3) + 32 * h) = o;
+                    }
                 }
             }
         } else if constexpr (PWP_DIRECT) {
@@ -966,7 +987,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
             }
             lds_barrier();      // the staging area (W2 | P1) is free again for the next tile's K-steps
         }
-        stores16 = n0 + IMGS <= a.N;
+        stores16 = !POOLP && n0 + IMGS <= a.N;          // (a pooled tail: lane 0 of a row stores 32 quads, the others nothing: the next tile drains)
         if (!more) break;
         vb = nvb; ch0 = ch0n; n0 = n0n;
         TILE_RSRC_W(rs_w, ch0);
@@ -1002,6 +1023,21 @@ static int launch_pw(const ConvArgs& a_in, hipStream_t s) {
     if (a.pool) {   // fp32 means over the 4x4 map instead of the map (the conv feeds one exit head only): the lite epilogue on the registers
         if constexpr (TW == 4) {
             if (epi == BMI_EPI_GENERAL) return BMI_ERR_UNSUPPORTED;
+            if (PWP_DIRECT && opt_pw_persist() && opt_conv_pw() < 3 && opt_epilogue_lite() == 1 && epi == BMI_EPI_LITE && a.res && a.res_mod >= a.N && a.relu &&
+                a.site.kind == BMI_SITE_NONE && !a.imap && !a.in2 && a.Cin % 64 == 0 && a.Cout <= 512 && a.in_mod >= a.N &&
+                (size_t)a.H * a.W * a.Cin * PwGeom<4>::IMGS * 2 < 0xfffffff0ull && (size_t)a.N * a.Ho * a.Wo * a.Cout < (8ull << 32)) {
+                // the pooled BasicBlock tail on the persistent walk (conv3x3_pwp_kernel<4, .., LITE_RES, POOLP>): the same bits
+                static const int n_cu_p = [] {
+                    int dev = 0, cu = 0;
+                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+                    return cu > 0 ? cu : 256;
+                }();
+                const dim3 pgrid((unsigned)(tiles < n_cu_p ? tiles : n_cu_p));
+                if (a.bf16) hipLaunchKernelGGL((conv3x3_pwp_kernel<4, true, false, BMI_EPI_LITE_RES, true>), pgrid, block, 0, s, a, (int)tiles);
+                else hipLaunchKernelGGL((conv3x3_pwp_kernel<4, false, false, BMI_EPI_LITE_RES, true>), pgrid, block, 0, s, a, (int)tiles);
+                BMI_CHECK_LAUNCH();
+                return BMI_OK;
+            }
             if (a.imap) {
                 if (a.bf16) hipLaunchKernelGGL((conv3x3_pw_kernel<4, BMI_EPI_LITE, true, true, true>), grid, block, 0, s, a);
                 else hipLaunchKernelGGL((conv3x3_pw_kernel<4, BMI_EPI_LITE, false, true, true>), grid, block, 0, s, a);

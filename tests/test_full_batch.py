@@ -87,6 +87,15 @@ def test_fused_relu_avgpool_equals_the_separate_head_pooling():
     assert not torch.equal(fused["mean"][3], plain["mean"][3])              # ... and the final exit conv3x3_pw's (layer4[1].conv2, with its residual)
     again = eng.predict(x, T, seed=seed)
     assert torch.equal(again["mean"], fused["mean"])
+    # layer4[1].conv2's pooled tail runs on the persistent walk (conv3x3_pwp_kernel<4, .., LITE_RES, POOLP>, round 4): bit for bit the per-tile
+    # kernel's pooled lite epilogue ("epilogue_lite" = 2 keeps the unspecialised forms everywhere)
+    _lib.set_option("epilogue_lite", 2)
+    try:
+        old = eng.predict(x, T, seed=seed)
+    finally:
+        _lib.set_option("epilogue_lite", 1)
+    for k in ("mean", "var"):
+        assert torch.equal(old[k], fused[k]), k
 
 
 @pytest.mark.parametrize("dropout", ["block", "layer"])
