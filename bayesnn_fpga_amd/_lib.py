@@ -12,12 +12,14 @@ LIB_PATH = os.path.join(HERE, "libbayesnn_fpga_amd.so")
 BMI_OK = 0
 SITE_NONE, SITE_ELEMENTWISE, SITE_CHANNEL, SITE_MASKSEMBLE = 0, 1, 2, 3
 SITE_POS_OUTER, SITE_POS_INNER = 0, 1
-DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
+DTYPE_F16, DTYPE_BF16, DTYPE_F32, DTYPE_F16X2, DTYPE_BF16X3 = 0, 1, 2, 3, 4
+DTYPES = {"f16": DTYPE_F16, "bf16": DTYPE_BF16, "f32": DTYPE_F32, "f16x2": DTYPE_F16X2, "bf16x3": DTYPE_BF16X3}
+FP32_ACT_DTYPES = ("f32", "f16x2", "bf16x3")      # engines that keep fp32 activations in the workspace
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
 PROFILE_SLOTS = 8
 CONV_FAMILY_KERNELS = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel", "conv1x1_stream_kernel",
-                       "conv3x3_s2_kernel")
-ABI_VERSION = 400             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
+                       "conv3x3_s2_kernel", "conv_split_kernel")
+ABI_VERSION = 500             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
 CONV_FAMILIES = len(CONV_FAMILY_KERNELS)     # BMI_CONV_FAMILIES
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
                  OP_DENSE: "dense"}

@@ -184,6 +184,45 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
 }
 
 
+// The same for the engines that keep fp32 activations (the exact engine's conv_exact.hip, the split engines' conv_split.hip):
+// arithmetic and order of epilogue_quad, fp32 residual row (`resp`, or null), the finished quad left in v[] for the caller's store.
+__device__ __forceinline__ void epilogue_quad_f32(const ConvArgs& a, const PixelCtx& p, const float* resp, float v[4], int c4) {
+    if (a.scale) {
+        const float4 s4 = *(const float4*)(a.scale + c4);
+        v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
+    } else if (a.out_mul != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
+    }
+    if (a.bias) {
+        const float4 b4 = *(const float4*)(a.bias + c4);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    float m[4];
+    site_mult4(a, p, c4, m);
+    if (a.site_inner) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
+        if (a.bias_post) {
+            const float4 b4 = *(const float4*)(a.bias_post + c4);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+    }
+    if (resp) {
+        const float4 r4 = *(const float4*)(resp + c4);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (!a.site_inner) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Coalesced epilogue for 128-channel tiles: accumulators -> LDS (fp32, after BN scale/bias) ->
 // full 256-byte NHWC row segments.  The per-quad path above issues, per lane, dozens of

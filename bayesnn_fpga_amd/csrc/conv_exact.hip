@@ -97,43 +97,7 @@ __global__ __launch_bounds__(256) void conv_exact_kernel(ConvArgs a) {
     for (int q = 0; q < 4; ++q) {
         const int c4 = ch0 + wc * 32 + 8 * q + 4 * hh;
         float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        if (a.scale) {
-            const f32x4_x s4 = *(const f32x4_x*)(a.scale + c4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= s4[e] * a.out_mul;
-        } else if (a.out_mul != 1.f) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
-        }
-        if (a.bias) {
-            const f32x4_x b4 = *(const f32x4_x*)(a.bias + c4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += b4[e];
-        }
-        float mk[4];
-        site_mult4(a, p, c4, mk);
-        if (a.site_inner) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = mk[e] == 0.f ? 0.f : v[e] * mk[e];
-            if (a.bias_post) {
-                const f32x4_x b4 = *(const f32x4_x*)(a.bias_post + c4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += b4[e];
-            }
-        }
-        if (resp) {
-            const f32x4_x r4 = *(const f32x4_x*)(resp + c4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r4[e];
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (!a.site_inner) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = mk[e] == 0.f ? 0.f : v[e] * mk[e];
-        }
+        epilogue_quad_f32(a, p, resp, v, c4);
         *(f32x4_x*)(out + p.out_off + c4) = f32x4_x{v[0], v[1], v[2], v[3]};
     }
 }

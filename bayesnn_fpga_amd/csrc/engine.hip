@@ -77,7 +77,8 @@ struct bmi_engine_s {
     std::vector<OpInfo> prefix, suffix;
     int n_exits = 0, out_dim = 0;
     int bf16 = 0;               // BMI_DTYPE_BF16
-    int f32 = 0;                // BMI_DTYPE_F32: the exact engine (fp32 activations and conv weights, conv_exact.hip)
+    int f32 = 0;                // fp32 activations in the workspace: BMI_DTYPE_F32 (the exact engine: fp32 conv weights, conv_exact.hip) and the split engines
+    int split = 0;              // BMI_DTYPE_F16X2 (1) / BMI_DTYPE_BF16X3 (2): 16-bit head + tail weight planes, conv_split.hip
     int dtype = 0;              // BMI_DTYPE_*
     bool no_reuse = false;      // bmi_plan: every suffix tensor keeps its own workspace range ("ws_no_reuse": per-layer traces)
     int64_t prefix_macs = 0, suffix_macs = 0;
@@ -182,6 +183,7 @@ int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_mask_lazy() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
+static bool unit_f32act() { const int d = opt_unit_dtype(); return d == BMI_DTYPE_F32 || d == BMI_DTYPE_F16X2 || d == BMI_DTYPE_BF16X3; }
 int& opt_ws_no_reuse() { static int v = 0; return v; }
 int& opt_lazy_planar() { static int v = 1; return v; }
 int& opt_xcd_split() {
@@ -204,7 +206,7 @@ int bmi_version(void) { return BMI_VERSION; }
 int bmi_set_option(const char* name, int32_t value) {
     if (!name) return BMI_ERR_INVALID;
     if (std::strcmp(name, "unit_entry_dtype") == 0) {
-        if (value != BMI_DTYPE_F16 && value != BMI_DTYPE_BF16 && value != BMI_DTYPE_F32) return BMI_ERR_INVALID;
+        if (value < BMI_DTYPE_F16 || value > BMI_DTYPE_BF16X3) return BMI_ERR_INVALID;
         opt_unit_dtype() = value;
         return BMI_OK;
     }
@@ -305,13 +307,14 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     if (!desc || !out || desc->n_tensors < 2 || desc->n_ops < 1 || !desc->tensors || !desc->ops) return BMI_ERR_INVALID;
     if (desc->n_exits < 1 || desc->out_dim < 1) return BMI_ERR_INVALID;
     if (desc->out_dim > 128) return BMI_ERR_UNSUPPORTED;
-    if (desc->dtype != BMI_DTYPE_F16 && desc->dtype != BMI_DTYPE_BF16 && desc->dtype != BMI_DTYPE_F32) return BMI_ERR_INVALID;
+    if (desc->dtype < BMI_DTYPE_F16 || desc->dtype > BMI_DTYPE_BF16X3) return BMI_ERR_INVALID;
     bmi_engine_s* e = new (std::nothrow) bmi_engine_s();
     if (!e) return BMI_ERR_NOMEM;
     e->n_exits = desc->n_exits;
     e->out_dim = desc->out_dim;
     e->bf16 = desc->dtype == BMI_DTYPE_BF16;
-    e->f32 = desc->dtype == BMI_DTYPE_F32;
+    e->split = desc->dtype == BMI_DTYPE_F16X2 ? 1 : (desc->dtype == BMI_DTYPE_BF16X3 ? 2 : 0);
+    e->f32 = desc->dtype == BMI_DTYPE_F32 || e->split;
     e->dtype = desc->dtype;
     e->tensors.resize(desc->n_tensors);
     for (int i = 0; i < desc->n_tensors; ++i) {
@@ -348,7 +351,9 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 op.wo = (tin.w + 2 * d.pad - d.ksize) / d.stride + 1;
                 op.cout = to.c;
                 if (op.ho != to.h || op.wo != to.w) { rc = BMI_ERR_INVALID; break; }
-                if (d.kind == BMI_OP_CONV && (tin.c % 64 != 0 || to.c % 64 != 0)) { rc = BMI_ERR_UNSUPPORTED; break; }
+                if (d.kind == BMI_OP_CONV && !e->f32 && (tin.c % 64 != 0 || to.c % 64 != 0)) { rc = BMI_ERR_UNSUPPORTED; break; }
+                // the engines with fp32 activations: one generic kernel each (conv_exact / conv_split), 32-deep K-steps, 64-channel tiles
+                if (d.kind == BMI_OP_CONV && e->f32 && (tin.c % 32 != 0 || to.c % 64 != 0)) { rc = BMI_ERR_UNSUPPORTED; break; }
                 if (d.kind == BMI_OP_STEM && (to.c % 8 != 0 || to.c * d.ksize * d.ksize * tin.c > 4096 || d.residual >= 0)) {
                     rc = BMI_ERR_UNSUPPORTED; break;
                 }
@@ -816,7 +821,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     switch (d.kind) {
         case BMI_OP_STEM:
             return launch_stem_conv(x, (const float*)d.weight, d.scale, d.bias, (_Float16*)(ws + e->tensors[d.out].offset), N,
-                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, e->dtype, s);
+                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, e->f32 ? BMI_DTYPE_F32 : e->dtype, s);
         case BMI_OP_CONV: {
             ConvArgs a;
             std::memset(&a, 0, sizeof(a));
@@ -858,9 +863,13 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 m.in_bits = (const uint8_t*)(ws + e->tensors[tin.lazy_bits].offset);
                 m.lazy_planar = tin.lazy_planar_now;
             };
-            if (e->f32) {   // the exact engine: one generic kernel (a.in / a.wgt / a.res / a.out hold fp32)
-                prof.tag(-1, 0, 0);
-                return launch_conv_exact(a, s);
+            if (e->f32) {   // the exact / split engines: one generic kernel each (a.in / a.res / a.out hold fp32)
+                if (!e->split) { prof.tag(-1, 0, 0); return launch_conv_exact(a, s); }
+                const double fl = 2.0 * N * op.ho * op.wo * (double)op.cout * d.ksize * d.ksize * tin.c;
+                auto tb = [&](int id) { const TensorInfo& t = e->tensors[id]; return 4.0 * (t.stoch ? N : B) * t.h * t.w * t.c; };
+                prof.tag(BMI_CONV_FAMILY_SPLIT, fl, tb(d.in) + 4.0 * N * op.ho * op.wo * (double)op.cout + 4.0 * (double)op.cout * d.ksize * d.ksize * tin.c +
+                                                    (d.residual >= 0 ? tb(d.residual) : 0.0));
+                return launch_conv_split(a, e->split == 2, s);
             }
             double flops = 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
             if (d.in2 >= 0) flops += 2.0 * N * op.ho * op.wo * (double)op.cout * e->tensors[d.in2].c;
@@ -1213,7 +1222,7 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
                       int32_t pad, int32_t relu, bmi_stream stream) {
     if (!x_nchw || !weight || !out_nhwc) return BMI_ERR_INVALID;
     return launch_stem_conv(x_nchw, weight, scale, bias, (_Float16*)out_nhwc, n, cin, h, w, cout, ksize, stride, pad, relu,
-                            opt_unit_dtype(), (hipStream_t)stream);
+                            unit_f32act() ? BMI_DTYPE_F32 : opt_unit_dtype(), (hipStream_t)stream);
 }
 
 int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* site, int32_t batch, int32_t t0,
@@ -1245,6 +1254,7 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
     a.in_bits = (const uint8_t*)in_keep_bits;
     a.out_mul = out_mul;
     if (opt_unit_dtype() == BMI_DTYPE_F32) return launch_conv_exact(a, (hipStream_t)stream);
+    if (unit_f32act()) return launch_conv_split(a, opt_unit_dtype() == BMI_DTYPE_BF16X3, (hipStream_t)stream);
     return launch_conv(a, (hipStream_t)stream);
 }
 
@@ -1301,13 +1311,13 @@ int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t
                    int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
     EltArgs a;
     const int rc = elt_args(a, in, out, n, in_mod, hw, c, site, batch, t0, seed, mask_cnt0);
-    if (rc == BMI_OK && opt_unit_dtype() == BMI_DTYPE_F32) return launch_mask_apply_f32(a, (hipStream_t)stream);
+    if (rc == BMI_OK && unit_f32act()) return launch_mask_apply_f32(a, (hipStream_t)stream);
     return rc != BMI_OK ? rc : launch_mask_apply(a, (hipStream_t)stream);
 }
 
 int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c, bmi_stream stream) {
     if (!in || !out) return BMI_ERR_INVALID;
-    if (opt_unit_dtype() == BMI_DTYPE_F32) return launch_maxpool2_f32((const float*)in, (float*)out, n, h, w, c, (hipStream_t)stream);
+    if (unit_f32act()) return launch_maxpool2_f32((const float*)in, (float*)out, n, h, w, c, (hipStream_t)stream);
     return launch_maxpool2((const _Float16*)in, (_Float16*)out, n, h, w, c, opt_unit_dtype() == BMI_DTYPE_BF16, (hipStream_t)stream);
 }
 

@@ -128,6 +128,9 @@ int launch_stem_conv(const float* x, const float* w, const float* scale, const f
                      int cin, int h, int wdt, int cout, int ksize, int stride, int pad, int relu, int dt /* BMI_DTYPE_* of out */, hipStream_t s);
 // the exact engine (BMI_DTYPE_F32, conv_exact.hip): the 16-bit pointer fields of ConvArgs / EltArgs hold fp32 tensors and fp32 weights
 int launch_conv_exact(const ConvArgs& a, hipStream_t s);
+// the split engines (BMI_DTYPE_F16X2 / BF16X3, conv_split.hip): fp32 tensors as above, a.wgt = 16-bit [2][Cout][k*k*Cin] head / tail planes
+int launch_conv_split(const ConvArgs& a, int bf16, hipStream_t s);
+bool conv_takes_split_kernel(int cin, int cout);
 int launch_mask_apply_f32(const EltArgs& a, hipStream_t s);
 int launch_maxpool2_f32(const float* in, float* out, int n, int h, int w, int c, hipStream_t s);
 int launch_mask_apply(const EltArgs& a, hipStream_t s);

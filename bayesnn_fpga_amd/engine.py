@@ -44,11 +44,12 @@ class GraphBuilder:
     """Collects tensors / ops / device-resident weights for one model on one device."""
 
     def __init__(self, device, dtype="f16"):
-        if dtype not in ("f16", "bf16", "f32"):
-            raise ValueError(f"dtype must be 'f16', 'bf16' or 'f32' (the exact engine), got {dtype!r}")
+        if dtype not in _lib.DTYPES:
+            raise ValueError(f"dtype must be 'f16', 'bf16', 'f32' (the exact engine), 'f16x2' or 'bf16x3' (the split engines), got {dtype!r}")
         self.device = device
         self.dtype = dtype
-        self.act_dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype]     # conv weights / activations
+        # conv weights: the engine's 16-bit type, fp32 (exact engine), or 16-bit head + tail planes (split engines: conv_weight below)
+        self.act_dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32, "f16x2": torch.float16, "bf16x3": torch.bfloat16}[dtype]
         self.tensors = []          # (h, w, c)
         self.ops = []              # dicts
         self.keep = []             # device tensors that must outlive the engine
@@ -62,6 +63,16 @@ class GraphBuilder:
         d = t.detach().to(device=self.device, dtype=dtype).contiguous()
         self.keep.append(d)
         return d
+
+    def conv_weight(self, w):
+        """Device copy of a conv weight [Cout][ky][kx][Cin] in the engine's layout.  Split engines (BMI_DTYPE_F16X2 / BF16X3): the 16-bit
+        head and tail planes [2][Cout][ky][kx][Cin], hi = rn16(w), lo = rn16(w - hi) — split once here, csrc/conv_split.hip reads both."""
+        if self.dtype not in ("f16x2", "bf16x3"):
+            return self.dev(w, self.act_dtype)
+        w32 = w.detach().float()
+        hi = w32.to(self.act_dtype)
+        lo = (w32 - hi.float()).to(self.act_dtype)
+        return self.dev(torch.stack([hi, lo]), self.act_dtype)
 
     def site(self, module, channelwise=False):
         """Allocates the next site id (call order) for a stochastic layer, or none."""
@@ -107,7 +118,7 @@ class GraphBuilder:
             bias = bias + s_bias
             scale = None
             in2 = x2
-        wdev = self.dev(wk, torch.float32 if stem else self.act_dtype)
+        wdev = self.dev(wk, torch.float32) if stem else self.conv_weight(wk)
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
                              stride=s, pad=p, relu=int(relu), weight=wdev, in2=in2, weight2=w2dev,
                              scale=self.dev(scale, torch.float32) if scale is not None else None,
@@ -171,7 +182,7 @@ def _can_fuse_shortcut(t_in, blk, dtype="f16"):
     (16x16 / 8x8 / 4x4 maps, Cout % 128 == 0) and the block input has a multiple of 64 channels.
     BMI_FUSE_SHORTCUT=0 keeps the separate launch + residual (A/B, tests); the exact engine never fuses (the fusion folds
     the BN scales into the 16-bit weights: a speed feature)."""
-    if os.environ.get("BMI_FUSE_SHORTCUT", "1") == "0" or dtype == "f32":
+    if os.environ.get("BMI_FUSE_SHORTCUT", "1") == "0" or dtype in _lib.FP32_ACT_DTYPES:
         return False
     h, w, c = t_in
     ds = blk.downsample[0]
@@ -323,7 +334,7 @@ class CompiledGraph:
             else:
                 d.site = _lib.make_site()
         desc = _lib.ModelDesc(len(g.tensors), tarr, len(g.ops), oarr, self.n_exits, self.out_dim,
-                              {"f16": _lib.DTYPE_F16, "bf16": _lib.DTYPE_BF16, "f32": _lib.DTYPE_F32}[self.dtype])
+                              _lib.DTYPES[self.dtype])
         return (desc, tarr, oarr)
 
     def flops_per_batch(self, batch, T):

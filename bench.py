@@ -87,8 +87,9 @@ def parse():
     ap.add_argument("--T", type=int, default=0, help="MC samples per image (0 = the workload's)")
     ap.add_argument("--chunk", type=int, default=0, help="MC samples folded per suffix launch (0 = engine default)")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--dtype", choices=("f16", "bf16"), default="f16",
-                    help="16-bit type of activations / conv weights (f16 meets the 1e-3 bar and is the default; bf16 is reported next to it)")
+    ap.add_argument("--dtype", choices=("f16", "bf16", "f16x2", "bf16x3"), default="f16",
+                    help="f16 / bf16: 16-bit activations and conv weights (f16 meets the 1e-3 bar and is the default; bf16 is reported next to it); "
+                         "f16x2 / bf16x3: the split engines (fp32 activations, 16-bit head + tail operands, three MFMAs per K-step: csrc/conv_split.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the 1-GPU dry run)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -123,7 +124,7 @@ def hbm_traffic(workload, launches_per_step, family=None):
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     if not os.path.exists(path):
         return None, None
-    allk = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw", "conv3x3_s2", "conv1x1_stream"))}
+    allk = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw", "conv3x3_s2", "conv1x1_stream", "conv_split"))}
     n_all = sum(v["launches"] for v in allk.values())
     if n_all == 0 or n_all % launches_per_step:
         return None, None                   # collected for another batch / T / chunking: do not quote it
@@ -147,6 +148,28 @@ def pmc_sq(workload, family):
         return {}
     return {"mfma_busy_share_pmc": round(sum(v["sq"]["mfma_busy_share"] * v["launches"] for v in ks) / n, 4),
             "effective_clock_ghz_pmc": round(sum(v["sq"]["effective_clock_ghz"] * v["launches"] for v in ks) / n, 3)}
+
+
+def rocprof_family(workload, family, launches_per_step):
+    """The committed `rocprofv3 --kernel-trace --stats` summary of this same command (the newest profiles/rNN_<workload>_kernel_stats.csv):
+    the launches of one conv family — (name of its kernel with the most device time as rocprof prints it, without template arguments;
+    average launch duration in ms over ALL the family's kernels; calls; file).  None when absent or collected for another launch count."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_kernel_stats.csv")))
+    if not files:
+        return None
+    tot, calls, by_name = 0.0, 0, {}
+    for row in csv.DictReader(open(files[-1])):
+        name = re.sub(r"^void ", "", row["Name"]).split("<")[0].split("(")[0]
+        if _family_match(name, family):
+            tot += float(row["TotalDurationNs"])
+            calls += int(row["Calls"])
+            by_name[name] = by_name.get(name, 0.0) + float(row["TotalDurationNs"])
+    if not calls or calls % max(launches_per_step, 1):
+        return None
+    return max(by_name, key=by_name.get), tot / calls * 1e-6, calls, os.path.relpath(files[-1], ROOT)
 
 
 def physical_cores():
@@ -427,8 +450,15 @@ def main():
             d = by_kernel[dom]
             dom_traffic, _ = (hbm_traffic(a.workload, max(alg_launches, 1), dom) if traffic is not None else (None, None))
             hbm_bound = d["bound"] == "hbm"
+            # the same family in the committed rocprofv3 summary of this command: its kernel's name as rocprof prints it, and the
+            # roofline fraction its average duration gives (the live HIP-event `frac` of THIS box beside it: boxes differ by 2-3 %)
+            rp = rocprof_family(a.workload, dom, d["launches"]) if (world == 1 and not a.batch and not a.T and not a.chunk and a.dtype == "f16") else None
+            per_launch = d["algorithmic_bytes_per_launch"] / 1e9 if hbm_bound else d["algorithmic_flops_per_launch"] / 1e12
             line["roofline"] = {
-                "bound": d["bound"], "kernel": dom, "dominant_by": "hip_event_ms (the conv family with the most device time in the profiled step; "
+                "bound": d["bound"], "kernel": rp[0] if rp else dom, "kernel_family": dom,
+                "frac_rocprof": None if rp is None else round(per_launch / (rp[1] * 1e-3) / (HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS), 4),
+                "avg_launch_ms_rocprof": None if rp is None else round(rp[1], 4), "rocprof_source": None if rp is None else rp[3],
+                "dominant_by": "hip_event_ms (the conv family with the most device time in the profiled step; "
                                                                    "quote whole_step.frac when comparing rounds)",
                 "achieved": d["hbm_gbs_algorithmic"] if hbm_bound else d["achieved"],
                 "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
@@ -451,7 +481,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:        # the CPU baseline is reported at N=1 only
             cpu_val, threads, cpu_mean, sweep = cpu_baseline(wl, B, a.cpu_T, a.seed)
             gpu_same = eng.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()
-            other = "bf16" if a.dtype == "f16" else "f16"          # the other 16-bit instantiation on the same inputs / masks
+            other = "bf16" if a.dtype == "f16" else "f16"          # the other 16-bit instantiation (split engines: plain fp16) on the same inputs / masks
             eng_o = model.engine(dev, max_batch=B, chunk_samples=a.chunk or None, dtype=other)
             gpu_other = eng_o.predict(x, a.cpu_T, seed=a.seed)["mean"].cpu().numpy()
             one = cpu_baseline_1thread(wl, a.cpu_1t_images, 2, a.seed) if a.cpu_1t_images > 0 else None

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BMI_VERSION 400
+#define BMI_VERSION 500
 
 #define BMI_OK 0
 #define BMI_ERR_INVALID (-22)      /* EINVAL: bad descriptor / argument            */
@@ -129,6 +129,17 @@ typedef struct bmi_op_desc {
                             rate.  Graph features that exist for speed only are not built (in2 is BMI_ERR_UNSUPPORTED; no
                             pair / pooling / lazy-site fusion); bmi_forward_mcd_exit is BMI_ERR_UNSUPPORTED.              */
 
+#define BMI_DTYPE_F16X2 3  /* the SPLIT engines, parity at speed (csrc/conv_split.hip): fp32 activations in the workspace as in the exact
+                             engine, every conv operand a 16-bit head + tail pair — `weight` is 16-bit [2][Cout][k][k][Cin], plane 0 =
+                             rn16(w), plane 1 = rn16(w - plane 0), split ONCE by the host; the activations are split on the fly — and
+                             w.x = w_lo.x_hi + w_hi.x_lo + w_hi.x_hi on v_mfma_f32_32x32x16_f16 (fp32 accumulate; 22 significant bits
+                             per operand, lo.lo dropped): three MFMAs per K-step instead of the exact engine's sixteen.  The reference's
+                             fp32 arithmetic to ~1e-6 where plain fp16 is at 1e-4..2e-3 (peaky logits of trained / converted nets,
+                             Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45 on SA/models/vgg19/vgg19.py:256-324).  |values| < 65504.
+                             Graph restrictions of BMI_DTYPE_F32 apply (no in2, no dynamic exit).                                      */
+#define BMI_DTYPE_BF16X3 4 /* the same on v_mfma_f32_32x32x16_bf16: bf16 head + tail (16 significant bits, fp32's exponent range), three
+                             bf16 MFMAs per K-step — BASELINE configs[1] ("bf16") inside north_star's 1e-3 on the bf16 matrix pipe      */
+
 typedef struct bmi_model_desc {
     int32_t n_tensors;
     const bmi_tensor_desc* tensors;
@@ -136,7 +147,8 @@ typedef struct bmi_model_desc {
     const bmi_op_desc* ops;
     int32_t n_exits;
     int32_t out_dim;
-    int32_t dtype; /* BMI_DTYPE_*: conv weights (`weight`, `weight2`) must be in this type (F32: fp32) */
+    int32_t dtype; /* BMI_DTYPE_*: conv weights (`weight`, `weight2`) must be in this type (F32: fp32; F16X2 / BF16X3: 16-bit head
+                      and tail planes [2][Cout][k][k][Cin]) */
 } bmi_model_desc;
 
 /* per-op-kind device time, filled by bmi_profile_read */
@@ -199,7 +211,8 @@ const char* bmi_error_string(int code);
  *   "unit_entry_dtype"                      BMI_DTYPE_*: how the single-kernel entry points below (unit tests) interpret
  *                                           their 16-bit buffers; engines carry their own dtype in bmi_model_desc.  BMI_DTYPE_F32:
  *                                           bmi_conv_igemm_fwd / bmi_stem_conv_fwd (output) / bmi_mask_apply / bmi_maxpool2 take fp32
- *                                           buffers (and fp32 conv weights) and run the exact engine's kernels
+ *                                           buffers (and fp32 conv weights) and run the exact engine's kernels; BMI_DTYPE_F16X2 / BF16X3: fp32
+ *                                           buffers too, bmi_conv_igemm_fwd takes the 16-bit head / tail weight planes and runs conv_split
  *   "ws_no_reuse"                           0 | 1, read by bmi_plan: every suffix tensor keeps its own workspace range (per-layer
  *                                           traces through bmi_tensor_info; the workspace grows to the sum of the activations)
  * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT). */
@@ -280,7 +293,8 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
 #define BMI_CONV_FAMILY_PW 3    /* conv3x3_pw_kernel */
 #define BMI_CONV_FAMILY_STREAM 4 /* conv1x1_stream_kernel */
 #define BMI_CONV_FAMILY_S2 5    /* conv3x3_s2_kernel */
-#define BMI_CONV_FAMILIES 6
+#define BMI_CONV_FAMILY_SPLIT 6 /* conv_split_kernel (the split engines; FLOPs = algorithmic, i.e. one third of the MFMA work) */
+#define BMI_CONV_FAMILIES 7
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
                               double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]);
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--top", type=int, default=0, help="also list the N launches with the most time")
     ap.add_argument("--set", default="", help="bmi_set_option pairs, name=value+name=value")
+    ap.add_argument("--dtype", default="f16", choices=sorted(_lib.DTYPES))
     a = ap.parse_args()
     for kv in (a.set.split("+") if a.set else []):
         nm, _, val = kv.partition("=")
@@ -35,7 +36,7 @@ def main():
     np.random.seed(0)
     model = synthetic_weights_(bench._load(wl[0])(**wl[2]), 0).to(dev).eval()
     B, T = a.batch or wl[3], a.T or wl[4]
-    eng = model.engine(dev, max_batch=B)
+    eng = model.engine(dev, max_batch=B, dtype=a.dtype)
     x = synthetic_images(B, seed=1234).to(dev)
     S = eng.new_moments(B)
     for _ in range(2):
