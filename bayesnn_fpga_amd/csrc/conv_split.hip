@@ -25,7 +25,7 @@
 //              staging writes; the DMA writes lane-linearly, so the permutation is applied to the per-lane SOURCE address
 //   epilogue = conv_exact.hip's, on the accumulator quads (a lane holds pixel lane & 31 and, per quad q, channels 8q + 4(lane >> 5)..):
 //              folded BN, inner / outer site of every kind, fp32 residual, ReLU, fp32 store
-// One barrier per K-step.  The fp16-engine launch forms that exist for speed only (fused shortcut, pair, pooling, lazy sites,
+// Two wave groups in ping-pong (below).  The fp16-engine launch forms that exist for speed only (fused shortcut, pair, pooling, lazy sites,
 // split-K, dynamic-exit row tables) are not built for this dtype (bmi_create keeps them out, as for the exact engine).
 #include <type_traits>
 
@@ -36,23 +36,37 @@ typedef float f32x16_s __attribute__((ext_vector_type(16)));
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
 
 #define SP_PT 256
-// LDS-DMA, 16 B per lane to LDSPTR + 16 lane.  Inline asm, not __builtin_amdgcn_global_load_lds: to hipcc's waitcnt pass the builtin is a
-// load AND a store ("mixed events": no in-order counting), and while one is in flight every register dependency on a plain global load
-// becomes s_waitcnt vmcnt(0) — which would also wait for the input fetches issued for the K-step after next.  The DMA writes no register,
-// so hiding it is safe; the K loop's own counted waits cover it (it is older than what they leave in flight).
-#define SP_GLDS16(SRC, LDSPTR)                                                                                               \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                            \
-                 :: "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(LDSPTR)), "v"(SRC) : "m0", "memory")
+// LDS-DMA, 16 B per lane from SBASE (wave-uniform, 64-bit) + VOFF (per lane, 32-bit) to LDSPTR + 16 lane.  Inline asm, not
+// __builtin_amdgcn_global_load_lds: to hipcc's waitcnt pass the builtin is a load AND a store ("mixed events": no in-order counting),
+// and while one is in flight every register dependency on a plain global load becomes s_waitcnt vmcnt(0).  The DMA writes no register,
+// so hiding it is safe; the K loop's counted waits cover it (it is older than what they leave in flight).
+#define SP_GLDS16S(VOFF, SBASE, LDSPTR)                                                                                      \
+    {                                                                                                                        \
+        const uint64_t b_ = (uint64_t)(uintptr_t)(SBASE);       /* (readfirstlane: the base must sit in SGPRs whatever hipcc thinks of its uniformity) */ \
+        const uint64_t sb_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b_ >> 32)) << 32) |                   \
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b_);                                    \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                                         \
+                     :: "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(LDSPTR)), "v"(VOFF), "s"(sb_) : "m0", "memory"); \
+    }
 
-// v[0..7] -> heads and tails (zeros when !ok: an out-of-image tap / a tile row beyond M)
+static __device__ float g_split_zero[64];   // zeros: what an out-of-image tap / a tile row beyond M fetches (256 B)
+
+// v[0..7] -> heads and tails.  fp16: hi = rn16(v); bf16: hi = v truncated to bf16 (one AND instead of a rounding convert: |lo| < 2^-7 |v|
+// instead of <= 2^-8 |v|, the pair still carries 16 significant bits); lo = rn16(v - hi) either way (v - hi is exact in fp32).
 template <bool BF>
-__device__ __forceinline__ void split8(const f32x4_s& x0, const f32x4_s& x1, bool ok, half8_t& hi, half8_t& lo) {
+__device__ __forceinline__ void split8(const f32x4_s& x0, const f32x4_s& x1, half8_t& hi, half8_t& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float v = ok ? (e < 4 ? x0[e] : x1[e - 4]) : 0.f;
-        const _Float16 h = a16_from_f32<BF>(v);
-        hi[e] = h;
-        lo[e] = a16_from_f32<BF>(v - a16_to_f32<BF>(h));
+        const float v = e < 4 ? x0[e] : x1[e - 4];
+        if constexpr (BF) {
+            const uint32_t hb = __builtin_bit_cast(uint32_t, v) & 0xffff0000u;
+            hi[e] = __builtin_bit_cast(_Float16, (uint16_t)(hb >> 16));
+            lo[e] = a16_from_f32<true>(v - __builtin_bit_cast(float, hb));
+        } else {
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)__builtin_fmaf((float)h, -1.0f, v);
+        }
     }
 }
 
@@ -60,10 +74,15 @@ template <bool BF, int TI>
 __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     constexpr int CT = 64 * TI;
     constexpr int WPL = CT * 64;                       // bytes of one weight plane of a stage
-    constexpr int XOFF = 2 * WPL;                      // X hi plane
     constexpr int XPL = SP_PT * 64;
-    constexpr int STAGE = 2 * WPL + 2 * XPL;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    // LDS: a ring of NW weight slots [hi | lo] and two input stages [hi | lo].  NW = 3 (TI <= 2): the weights of K-step ks + 2 are
+    // fetched during K-step ks and have a whole K-step to land — with two slots they have half of one (two barrier intervals: 2 x 6 TI
+    // MFMAs), which TI = 4 covers (measured) and TI = 2 does not: its K-step took 3900 cycles for 1536 of MFMA, the rest waiting for
+    // the DMA.  (TI = 4 with three slots would need all 160 KB of the CU's LDS.)
+    constexpr int NW = TI == 4 ? 2 : 3;
+    constexpr int WSLOT = 2 * WPL, XST = 2 * XPL;
+    constexpr int XBASE = NW * WSLOT;
+    __shared__ __attribute__((aligned(16))) char smem[NW * WSLOT + 2 * XST];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,18 +99,29 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     const int Ktot = a.ksize * a.ksize * a.Cin;
     const float* const in = (const float*)a.in;
 
-    // ---- weight DMA: piece q = tid + 512 i of the stage's [hi | lo] image: plane q / (4 CT), row (q >> 2) % CT, slot q & 3 ----
-    const _Float16* wsrc[TI];
+    // ---- weight DMA: piece q = tid + 512 i of the stage's [hi | lo] image: plane q / (4 CT), row (q >> 2) % CT, slot q & 3.  A block of
+    // 512 pieces is 128 rows (TI = 1: a plane is 256 pieces = 64 rows, waves 0-3 / 4-7 take plane 0 / 1) — a multiple of the swizzle's
+    // period, so every piece of a lane has the same row-in-block and source slot: ONE 32-bit lane offset serves them all, and the
+    // piece's plane / row block / K-step go into a scalar base (the vaddr + saddr form of global_load_lds: 1 VGPR instead of 2 TI)
+    const uint32_t woff_l = (uint32_t)(((tid >> 2) & (TI == 1 ? 63 : 127)) * Ktot + (((tid & 3) ^ ((tid >> 4) & 3)) << 3)) * 2u;
+    const char* wbase[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int q = tid + 512 * i, plane = q / (4 * CT), qq = q - plane * 4 * CT, row = qq >> 2;
-        wsrc[i] = a.wgt + ((size_t)plane * a.Cout + ch0 + row) * Ktot + (((qq & 3) ^ ((row >> 2) & 3)) << 3);
+        const int q0 = 512 * i + (TI == 1 ? 256 * (wave >> 2) : 0), plane = q0 / (4 * CT), row0 = (q0 - plane * 4 * CT) >> 2;
+        wbase[i] = (const char*)(a.wgt + ((size_t)plane * a.Cout + ch0 + row0) * Ktot);
     }
+#if SP_ABL_NOW                  // timing probe (wrong results): every K-step fetches the weights of K-step 0
 #define SP_ISSUE_W(KOFF, ST)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < TI; ++i) SP_GLDS16(wsrc[i] + (KOFF), (ST) + (i * 512 + wave * 64) * 16);
+    _Pragma("unroll") for (int i = 0; i < TI; ++i) SP_GLDS16S(woff_l, wbase[i], (ST) + (i * 512 + wave * 64) * 16);
+#else
+#define SP_ISSUE_W(KOFF, ST)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TI; ++i) SP_GLDS16S(woff_l, wbase[i] + 2 * (KOFF), (ST) + (i * 512 + wave * 64) * 16);
+#endif
 
     // ---- input staging: item f = tid + 512 i: tile row (pixel) (tid >> 2) + 128 i, channels 8 (tid & 3) .. of the K-step ----
-    const float* xbase[2];
+    // xorg = address of the item's channels at tap (0, 0) — outside the image where the padding says so, never dereferenced there: a
+    // K-step adds its wave-uniform offset ((ky W + kx) Cin + c0) and fetches from a page of zeros instead when its tap is out of bounds
+    const float* xorg[2];
     int iy0[2], ix0[2], xdst[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -103,22 +133,24 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;      // a row beyond M never passes the bounds test
         ix0[i] = ox * a.stride - a.pad;
-        xbase[i] = in + (size_t)(n % a.in_mod) * a.H * a.W * a.Cin + 8 * (tid & 3);
-        xdst[i] = XOFF + row * 64 + (((tid & 3) ^ ((row >> 2) & 3)) << 4);
+        xorg[i] = in + ((long)(n % a.in_mod) * a.H * a.W + (long)(oy * a.stride - a.pad) * a.W + ix0[i]) * a.Cin + 8 * (tid & 3);
+        xdst[i] = XBASE + row * 64 + (((tid & 3) ^ ((row >> 2) & 3)) << 4);
     }
-    // X registers of one K-step: two items of 8 channels (two float4) + their bounds flags.  Two sets: while one is split and written
-    // (it was loaded a whole K-step ago: no exposed wait), the other receives the loads of the K-step after next.
-    struct XRegs { f32x4_s v[2][2]; bool ok[2]; };
-    XRegs xa, xb;
+    // X registers of one K-step: two items of 8 channels (two float4).  ONE set: the fetches of K-step ks + 2 are issued into it right
+    // after the split of K-step ks + 1 has read it, and stay in flight for a whole K-step.
+    struct XRegs { f32x4_s v[2][2]; };
+    XRegs xa;
     auto load_x = [&](XRegs& R, int ky, int kx, int c0) {
+        const long soff = (long)(ky * a.W + kx) * a.Cin + min(c0, a.Cin - 32);        // wave-uniform (c0 = Cin: past the last K-step)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int iy_ = iy0[i] + ky, ix_ = ix0[i] + kx;
-            R.ok[i] = (unsigned)iy_ < (unsigned)a.H && (unsigned)ix_ < (unsigned)a.W;
-            // an out-of-image tap loads from the clamped position and is zeroed when it is split: no branch, no select on the address
-            // (a branch in the K loop splits it into basic blocks, and hipcc then waits vmcnt(0) where a counted wait would do)
-            const int iyc = min(max(iy_, 0), a.H - 1), ixc = min(max(ix_, 0), a.W - 1);
-            const float* p_ = xbase[i] + ((iyc * a.W + ixc) * a.Cin + c0);
+            const bool ok = (unsigned)(iy0[i] + ky) < (unsigned)a.H && (unsigned)(ix0[i] + kx) < (unsigned)a.W;
+            // (a select between two addresses, not a branch: a branch splits the K loop into basic blocks and hipcc then waits
+            //  vmcnt(0) where a counted wait would do)
+            const float* p_ = ok ? xorg[i] + soff : g_split_zero;
+#if SP_ABL_NOX                  // timing probe (wrong results): every K-step fetches the page of zeros (an L1 hit)
+            p_ = g_split_zero;
+#endif
             R.v[i][0] = *(const f32x4_s*)p_;
             R.v[i][1] = *(const f32x4_s*)(p_ + 4);
         }
@@ -127,7 +159,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             half8_t hi_, lo_;
-            split8<BF>(R.v[i][0], R.v[i][1], R.ok[i], hi_, lo_);
+            split8<BF>(R.v[i][0], R.v[i][1], hi_, lo_);
             *(half8_t*)(st + xdst[i]) = hi_;
             *(half8_t*)(st + xdst[i] + XPL) = lo_;
         }
@@ -142,21 +174,24 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int a_off = (wc * 32 * TI + r) * 64;
-    const int b_off = XOFF + (wp * 64 + r) * 64;
-    // one 16-deep sub-step SS of the K-step in stage ST: (TI + 2) x 2 fragment reads, TI x 2 x 3 MFMAs; the small products first
-    // (lo . hi, hi . lo), then hi . hi
-#define SP_SUBSTEP(ST, SS)                                                                               \
+    const int b_off = XBASE + (wp * 64 + r) * 64;
+    // fragments of one 16-deep sub-step SS of the K-step in stage ST ((TI + 2) x 2 ds_read_b128), and its TI x 2 x 3 MFMAs: the small
+    // products first (lo . hi, hi . lo), then hi . hi
+    half8_t ah[TI], al[TI], bh[2], bl[2];
+#define SP_READ(WS, XS, SS)                                                                              \
     {                                                                                                    \
         const int coff = ((2 * (SS) + kq) ^ sw) << 4;                                                    \
-        half8_t ah[TI], al[TI], bh[2], bl[2];                                                            \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                 \
-            ah[i] = *(const half8_t*)((ST) + a_off + i * 32 * 64 + coff);                                \
-            al[i] = *(const half8_t*)((ST) + WPL + a_off + i * 32 * 64 + coff);                          \
+            ah[i] = *(const half8_t*)((WS) + a_off + i * 32 * 64 + coff);                                \
+            al[i] = *(const half8_t*)((WS) + WPL + a_off + i * 32 * 64 + coff);                          \
         }                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-            bh[j] = *(const half8_t*)((ST) + b_off + j * 32 * 64 + coff);                                \
-            bl[j] = *(const half8_t*)((ST) + XPL + b_off + j * 32 * 64 + coff);                          \
+            bh[j] = *(const half8_t*)((XS) + b_off + j * 32 * 64 + coff);                                \
+            bl[j] = *(const half8_t*)((XS) + XPL + b_off + j * 32 * 64 + coff);                          \
         }                                                                                                \
+    }
+#define SP_MFMA()                                                                                        \
+    {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16<BF>(al[i], bh[j], acc[i][j]);  \
         _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
@@ -164,49 +199,131 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16<BF>(ah[i], bh[j], acc[i][j]);  \
     }
+    // raw s_barrier with the scheduler fenced off on both sides (a __syncthreads() would drain the fetches in flight: vmcnt(0))
+// (no s_setprio around the MFMA parts: with the partner wave prioritised, the VALU-heavy LOAD parts — split, address arithmetic — issue at
+// a fraction of their rate, MI355X_MICROARCH.md 'Two waves per SIMD' item 2; -DSP_SETPRIO=1 restores it for an A/B)
+// timing probes (tools/ab_split.sh name:-DSP_ABL_...=1; wrong results by construction, never in the product build)
+#ifndef SP_ABL_NOX
+#define SP_ABL_NOX 0
+#endif
+#ifndef SP_ABL_NOW
+#define SP_ABL_NOW 0
+#endif
+#ifndef SP_TAP_MAJOR
+#define SP_TAP_MAJOR 0
+#endif
+#ifndef SP_SETPRIO
+#define SP_SETPRIO 0
+#endif
+#define SP_PRIO(P) { if (SP_SETPRIO) __builtin_amdgcn_s_setprio(P); }
+#define SP_BARRIER()                                   \
+    {                                                  \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_sched_barrier(0);             \
+    }
 
     const int nK = a.ksize * a.ksize * (a.Cin / 32);
     // (ky, kx, c0) of the K-step whose input is fetched next.  Every step fetches (at the end: clamped, unused), so the number of
     // loads in flight — what the counted vmcnt waits below rely on — never changes
     int ky = 0, kx = 0, c0 = 0;
-    auto advance = [&]() {            // scalar selects, no branch; runs past the last K-step (ky = ksize) at the end: the fetches of
-        const int c1 = c0 + 32;       // those steps are clamped to valid addresses and never used
+    auto advance = [&]() {            // scalar selects, no branch; runs past the last K-step (c0 = Cin) at the end: the fetches of
+#if SP_TAP_MAJOR                      // those steps are clamped to valid addresses and never used
+        const int c1 = c0 + 32;
         const bool wrapc = c1 == a.Cin;
         c0 = wrapc ? 0 : c1;
         const int kx1 = kx + (wrapc ? 1 : 0);
         const bool wrapx = kx1 == a.ksize;
         kx = wrapx ? 0 : kx1;
         ky += wrapx ? 1 : 0;
+#else
+        // K order: 32-channel chunk outer, tap inner.  The k*k K-steps of a chunk read the SAME 128-byte lines of the tile's pixels
+        // and their halo (a tap is a shift by whole pixels), so all but the first find them in L1 / L2; tap-major, a line came back
+        // Cin / 32 K-steps later, behind 32 KB x Cin / 32 of other input per workgroup — beyond an XCD's L2 share: every K-step then
+        // streamed its 32 KB at the far-memory rate (~10 B/clk/CU: 3300 cycles, whatever the MFMA work of the step)
+        const int kx1 = kx + 1;
+        const bool wrapx = kx1 == a.ksize;
+        kx = wrapx ? 0 : kx1;
+        const int ky1 = ky + (wrapx ? 1 : 0);
+        const bool wrapy = ky1 == a.ksize;
+        ky = wrapy ? 0 : ky1;
+        c0 += wrapy ? 32 : 0;
+#endif
     };
-    // K-step 0 -> stage 0; the loads of K-step 1 -> xa
+    // (the weight offset of (ky, kx, c0), clamped for the K-steps past the end)
+#define SP_KOFF() min((ky * a.ksize + kx) * a.Cin + c0, Ktot - 32)
+    // K-step 0 -> weight slot 0 / input stage 0 (NW = 3: K-step 1's weights -> slot 1 too); the input fetches of K-step 1 -> xa
     SP_ISSUE_W(0, smem);
     load_x(xa, 0, 0, 0);
     write_x(xa, smem);
     advance();
+    if constexpr (NW == 3) { SP_ISSUE_W(SP_KOFF(), smem + WSLOT); }
     load_x(xa, ky, kx, c0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // all but the four loads just issued: this wave's weight DMA has landed
     lds_barrier();
-    // K-step ks: stage ST is complete; P holds the input of K-step ks + 1 (loaded during K-step ks - 1), Q takes that of ks + 2
-    auto step = [&](XRegs& P, XRegs& Q, int ks, char* st, char* nst) {
-        SP_ISSUE_W(min((ky * a.ksize + kx) * a.Cin + c0, Ktot - 32), nst);      // (ky, kx, c0) = K-step ks + 1 here
-        advance();
-        load_x(Q, ky, kx, c0);
-        __builtin_amdgcn_sched_barrier(0);      // the fetches stay at the top of the step (hipcc sinks them to its end otherwise)
-        SP_SUBSTEP(st, 0);
-        SP_SUBSTEP(st, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // P's loads are a whole K-step old; hipcc's wait for them (vmcnt(4): everything but Q's four loads) covers the weight DMA,
-        // which is older than Q.  The split runs on the VALU under the tail of this wave's MFMAs and beside its SIMD partner's.
-        write_x(P, nst);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // (explicit for the DMA: hipcc does not know it)
-        lds_barrier();                     // (raw s_barrier: __syncthreads() would drain Q too) stage `st` is free again, `nst` is complete
-    };
-    for (int ks = 0; ks < nK; ks += 2) {
-        step(xa, xb, ks, smem, smem + STAGE);
-        if (ks + 1 < nK) step(xb, xa, ks + 1, smem + STAGE, smem);
+    // ---- ping-pong main loop (the schedule of conv_igemm_wide.hip) ----------------------------------------------------------------
+    // A K-step is four intervals between barriers: LOAD(0) | MFMA(0) | LOAD(1) | MFMA(1), one 16-deep sub-step each.  A LOAD part
+    // reads the sub-step's fragments and does the step's staging work (sub-step 0: the weight DMA of the next K-step; sub-step 1:
+    // split + ds_write of the next K-step's input, fetched a whole step ago, then the fetches of the K-step after it into the same
+    // registers); an MFMA part is 6 TI MFMAs at raised priority.  The two wave groups (waves 0-3 / 4-7 = the two channel halves: one
+    // wave per SIMD each) run ONE BARRIER APART, so on every SIMD one wave is in an MFMA part while the other reads LDS, fetches and
+    // splits: the matrix pipe does not wait for the staging, and a barrier is the hand-over between the two waves of a SIMD.
+    // Intervals, K-step T: group 0 = 4T .. 4T+3, group 1 = 4T+1 .. 4T+4.  Hazards, by construction:
+    //   WAR  what K-step T+1 will read (input stage (T+1)&1; weight slot (T+1) % NW for NW = 2, (T+2) % 3 = (T-1) % 3 for NW = 3) was
+    //        last read for K-step T-1, in intervals 4T-2 (group 0) and 4T-1 (group 1); every LOAD part retires its reads (lgkmcnt(0))
+    //        before the barrier that ends it; the first write of K-step T is group 0's DMA in interval 4T (NW = 2) / 4T+2 (NW = 3).
+    //   RAW  the writers: DMA issued in 4T / 4T+1 (NW = 2) or a K-step earlier (NW = 3), ds_writes in 4T+2 / 4T+3; every wave retires
+    //        its own DMA (the vmcnt(0) of its LOAD(1)) and ds_writes before the barrier that ends its LOAD(1), i.e. by 4T+3; the
+    //        first reads of K-step T+1 are in 4T+4 (group 0) and 4T+5 (group 1).
+    // Both groups execute the same number of barriers: group 1 one extra before the loop, group 0 one extra after it.
+    const int g = wc;
+    if (g == 1) SP_BARRIER();
+    // K-step ks: weight slot ks % NW and input stage ks & 1 are complete; xa holds the input of K-step ks + 1, in flight since the
+    // LOAD(1) of K-step ks - 1; (ky, kx, c0) = K-step ks + 1
+    int wslot = 0;
+    for (int ks = 0; ks < nK; ++ks) {
+        const char* const ws = smem + wslot * WSLOT;
+        const char* const xs = smem + (ks & 1) * XST;
+        char* const nxs = smem + ((ks & 1) ^ 1) * XST;
+        wslot = wslot + 1 == NW ? 0 : wslot + 1;              // slot of K-step ks + 1
+        // LOAD(0)
+        SP_READ(ws, xs, 0);
+        if constexpr (NW == 2) { SP_ISSUE_W(SP_KOFF(), smem + wslot * WSLOT); }   // K-step ks + 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SP_BARRIER();
+        // MFMA(0)
+        SP_PRIO(1);
+        SP_MFMA();
+        SP_PRIO(0);
+        SP_BARRIER();
+        // LOAD(1)
+        SP_READ(ws, xs, 1);
+        // xa's fetches (hipcc waits for them too) and every weight DMA issued so far (which it does not know): NW = 2: K-step ks + 1's,
+        // issued two intervals ago; NW = 3: K-step ks + 1's, issued a whole K-step ago right behind xa's fetches
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        write_x(xa, nxs);
+        advance();                                           // -> K-step ks + 2
+        load_x(xa, ky, kx, c0);
+        if constexpr (NW == 3) {                             // K-step ks + 2's weights -> the slot K-step ks - 1 used (free since interval 4 ks - 1)
+            SP_ISSUE_W(SP_KOFF(), smem + (wslot + 1 == NW ? 0 : wslot + 1) * WSLOT);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SP_BARRIER();
+        // MFMA(1)
+        SP_PRIO(1);
+        SP_MFMA();
+        SP_PRIO(0);
+        SP_BARRIER();
     }
+    if (g == 0) SP_BARRIER();
 #undef SP_ISSUE_W
-#undef SP_SUBSTEP
+#undef SP_READ
+#undef SP_MFMA
+#undef SP_BARRIER
+#undef SP_KOFF
+#undef SP_PRIO
 
     // ---- epilogue: this lane's pixel of each pixel tile, the quads of each channel tile (fp32 in and out) ----
     float* const out = (float*)a.out;

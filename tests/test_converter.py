@@ -297,7 +297,8 @@ def test_gpu_converted_multi_exit_against_reference_golden(name):
     # fp16 engine: north_star's 1e-3 on the ResNet (logits up to 22); the converted VGG-19's logits reach 61 and one fp16 ulp of such a
     # logit is 3e-2, which a peaky softmax turns into up to 1.7e-3 on a T = 4 mean (measured) — that golden is asserted at 3e-3 on the
     # fp16 engine and at 2e-5 on its exact-engine twin right below (the per-layer trace shows rounding, not a layer:
-    # profiles/experiments/r4_layer_trace_converter_vgg19.txt)
+    # profiles/experiments/r4_layer_trace_converter_vgg19.txt).  Round 5: the SAME golden within 1e-3 (measured 2.5e-6 / 1.7e-5) at a quarter
+    # of fp16 speed instead of a sixteenth on the split engines: tests/test_split_engine.py::test_converted_vgg19_early_exit_within_1e3_at_speed
     p16 = 1e-3 if name == "resnet18ee" else 3e-3
     for dt, ltol, ptol in (("f16", 4e-3 * scale, p16), ("f32", 1e-5 * scale + 2e-4, 2e-5)):
         m.engine_dtype = dt

@@ -37,8 +37,14 @@ CONFIGS = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_real_batch_against_oracle(name):
+# (config, engine dtype): every config on the default fp16 engine; BASELINE configs[1] names bf16 — plain bf16 measures 3.3e-3 on it
+# (8 mantissa bits), so the config AS WRITTEN is asserted on the bf16 matrix pipe through the split engine "bf16x3" (bf16 head + tail
+# operands, three bf16 MFMAs per K-step: csrc/conv_split.hip), and the headline on "f16x2" beside its fp16 run
+CASES = [(n, "f16") for n in sorted(CONFIGS)] + [("vgg11_nb3", "bf16x3"), ("resnet18_block_exit", "f16x2")]
+
+
+@pytest.mark.parametrize("name,dtype", CASES, ids=[f"{n}-{d}" for n, d in CASES])
+def test_real_batch_against_oracle(name, dtype):
     cls, ocls, kw, T = CONFIGS[name]
     seed = 42
     m, o = build_seeded(cls, kw), build_seeded(ocls, kw)
@@ -51,13 +57,16 @@ def test_real_batch_against_oracle(name):
             if hasattr(mod, "cnt") and hasattr(mod, "masks"):
                 mod.cnt = cnt0
     ref = mcd.mcd_predict(o, x, T, seed)
-    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B, dtype=dtype)
+    assert eng.dtype == dtype
     r = eng.predict(x.to(DEV), T, seed=seed, cnt0=cnt0)
     mean, var = r["mean"].cpu().numpy(), r["var"].cpu().numpy()
     assert mean.shape == ref["mean"].shape == (eng.n_exits, B, kw["out_dim"])
     err_m, err_v = np.abs(mean - ref["mean"]).max(), np.abs(var - ref["var"]).max()
-    print(f"{name}: B={B} T={T} max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
+    print(f"{name} [{dtype}]: B={B} T={T} max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
     assert err_m <= TOL and err_v <= TOL
+    if dtype in ("f16x2", "bf16x3"):                      # the split engines' own bar: ten times inside north_star's
+        assert err_m <= 1e-4 and err_v <= 1e-4
     np.testing.assert_allclose(mean.sum(-1), 1.0, atol=1e-6)
 
 
