@@ -84,6 +84,14 @@ def build_graph_fx(model, g):
             bad(n, "its input is not a tensor the engine produced")
         return val[a]
 
+    def map_arg(n, what):
+        """(kind, tensor id, relu_last) of a node that takes a feature map or a flattened one; a classifier's logits, a pooled vector or
+        a .size() going in is a TypeError naming the node (not an unpacking error)."""
+        v = tensor_arg(n)
+        if v[0] not in ("t", "flat"):
+            bad(n, f"{what} takes a feature map, not {'the logits of a classifier' if v[0] == 'exit' else 'a pooled vector' if v[0] == 'pooled' else 'a size'}")
+        return v
+
     first = [True]
     for n in nodes:
         if n in consumed:
@@ -109,7 +117,7 @@ def build_graph_fx(model, g):
         layer, wrap = _unwrap(m) if m is not None else (None, None)
         # ---- conv [-> bn] [-> add] [-> relu] ----
         if isinstance(layer, nn.Conv2d):
-            kind, x, _ = tensor_arg(n)
+            kind, x, _ = map_arg(n, "a convolution")
             if kind != "t":
                 bad(n, "a convolution needs a feature map")
             cur, bn, res, relu = n, None, -1, False
@@ -119,6 +127,8 @@ def build_graph_fx(model, g):
                 consumed.add(u)
                 u = sole_user(cur)
             if u is not None and u.op == "call_function" and u.target in (operator.add, torch.add, operator.iadd) and len(u.args) == 2:
+                if u.kwargs:
+                    bad(u, "a residual add with keyword arguments (alpha != 1, out=) is not a plain add")
                 other = u.args[1] if u.args[0] is cur else u.args[0]
                 if isinstance(other, torch.fx.Node) and other in val and val[other][0] == "t":
                     res, cur = val[other][1], u
@@ -147,7 +157,7 @@ def build_graph_fx(model, g):
             pd = layer.padding if layer is not None else n.kwargs.get("padding", 0)
             if ks not in (2, (2, 2)) or st not in (None, 2, (2, 2)) or pd not in (0, (0, 0)):
                 bad(n, "only MaxPool2d(2, 2)")
-            kind, x, rl = tensor_arg(n)
+            kind, x, rl = map_arg(n, "a max-pool")
             if kind != "t":
                 bad(n, "a max-pool needs a feature map")
             x = g.maxpool(x)
@@ -157,7 +167,7 @@ def build_graph_fx(model, g):
             continue
         # ---- relu on its own (e.g. F.relu(out) in front of an exit head: idempotent on a post-ReLU map) ----
         if is_relu(n):
-            kind, x, rl = tensor_arg(n)
+            kind, x, rl = map_arg(n, "a ReLU")
             if not rl:
                 bad(n, "a ReLU must directly follow its convolution / Linear (or repeat one)")
             val[n] = (kind, x, True)
@@ -165,7 +175,7 @@ def build_graph_fx(model, g):
         # ---- global average pool -> flatten -> Linear ----
         is_favg = n.op == "call_function" and n.target in (F.avg_pool2d, F.adaptive_avg_pool2d)
         if isinstance(layer, (nn.AdaptiveAvgPool2d, nn.AvgPool2d)) or is_favg:
-            kind, x, rl = tensor_arg(n)
+            kind, x, rl = map_arg(n, "an average pool")
             h, w, _ = g.tensors[x]
             if isinstance(layer, nn.AdaptiveAvgPool2d) or (is_favg and n.target is F.adaptive_avg_pool2d):
                 size = layer.output_size if layer is not None else (n.args[1] if len(n.args) > 1 else n.kwargs.get("output_size"))
@@ -196,8 +206,13 @@ def build_graph_fx(model, g):
         if isinstance(layer, nn.Linear):
             src = tensor_arg(n)
             u = sole_user(n)
-            is_output = u is not None and u.op == "output"
-            if src[0] == "pooled" or (src[0] == "flat" and (is_output or not users[n] or all(x.op == "output" for x in users[n]))):
+            to_output = not users[n] or all(x.op == "output" for x in users[n])
+            if src[0] == "pooled" and not to_output:
+                # (the engine pools inside its fused classifier kernel only: avgpool -> flatten -> fc1 -> relu -> fc2 has no op for fc1)
+                bad(n, "a hidden Linear behind a global average pool: only a classifier (whose logits are returned) may read a pooled map")
+            if src[0] in ("exit", "size"):
+                bad(n, "a Linear takes a pooled or flattened feature vector")
+            if src[0] == "pooled" or (src[0] == "flat" and to_output):
                 if src[0] == "flat" and not src[2]:
                     bad(n, "the classifier input must come out of a ReLU")
                 g.head(src[1], layer, n_exits[0], site=g.site(wrap), site_on_logits=True)

@@ -565,7 +565,7 @@ class BatchesInFlight:
         with torch.cuda.stream(st):
             return fn(self.engines[i])
 
-    def predict_graphed(self, x, T, seed=0, cnt0=0, group=None, kind=None):
+    def predict_graphed(self, x, T, seed=0, cnt0=0, group=None, kind=None, shard=False):
         """``engine.predict(x, T, seed, cnt0=cnt0)`` of the next slot as ONE hipGraph launch (torch.cuda.CUDAGraph on ROCm).
         The library neither allocates nor synchronises inside bmi_forward_mcd / bmi_finalize, so the whole batch step — zero
         the moments, the once-per-batch prefix, every sample chunk of the suffix, finalize — is captured once per
@@ -574,7 +574,7 @@ class BatchesInFlight:
         batch 250 x T = 30 is 20 launches of 20-50 us on a ~20 us floor each — and a replay issues them back to back.
         Results are bit for bit the eager ones (tests/test_gpu_model.py).
 
-        With a process group of more than one rank (``group``, or the default group when ``torch.distributed`` is initialised) the
+        With a process group of more than one rank (``group``; ``shard=True`` takes the default group of an initialised ``torch.distributed``) the
         graph holds THIS RANK'S SHARE of the step (``sharding.accumulate_share``: its samples, or its images when T < ranks — one
         Masksembles mask of config 4 per GPU is exactly such a launch-bound step) and the all-reduce + finalize follow the replay
         eagerly on the slot's stream: a collective is never captured.
@@ -586,20 +586,24 @@ class BatchesInFlight:
         Returns the slot's STATIC output tensors: read them (after `last_stream`) before the slot comes round again, i.e. within
         the next len(engines) - 1 submissions."""
         from .sharding import _rank_world, accumulate_share
-        rank, world = _rank_world(group)
+        # a share of the step only when the caller names the group (or shard=True for the default one): a data-parallel caller with a
+        # different batch on each rank must not have its ranks' moments summed behind its back
+        rank, world = _rank_world(group) if (group is not None or shard) else (0, 1)
         i = self.slot()
-        self.k += 1
         eng = self.engines[i]
         if not hasattr(self, "_graphs"):
             from collections import OrderedDict
             self._graphs = [OrderedDict() for _ in self.engines]
             self._gstreams = [st if st is not None else torch.cuda.Stream(self.device) for st in self.streams]
-        st = self._gstreams[i]
-        self.last_stream = st
-        cur = torch.cuda.current_stream(self.device)
         key = (tuple(x.shape), int(T), int(seed), int(cnt0), rank, world, kind)
         cache = self._graphs[i]
         rec = cache.get(key)
+        if rec is None and eng.profiling:          # (before the slot rotation advances: a refused call leaves the pipe as it was)
+            raise RuntimeError("predict_graphed while engine profiling is on: the event records of bmi_profile_enable cannot be captured")
+        self.k += 1
+        st = self._gstreams[i]
+        self.last_stream = st
+        cur = torch.cuda.current_stream(self.device)
 
         def eager():
             st.wait_stream(cur)
@@ -613,8 +617,6 @@ class BatchesInFlight:
                 return eng.finalize(S, T)
 
         if rec is None:
-            if eng.profiling:
-                raise RuntimeError("predict_graphed while engine profiling is on: the event records of bmi_profile_enable cannot be captured")
             xs = torch.empty_like(x)
             S = eng.new_moments(x.shape[0])
             st.wait_stream(cur)

@@ -76,4 +76,9 @@ class EngineModelMixin:
         eng = self.engine(x.device, max_batch=x.shape[0])
         out = eng.forward_once(x, seed=self.mc_seed, t=self.mc_pass, cnt0=self.mask_cnt0())
         self.advance(1)
+        # what the reference's forwards leave behind for the training loss (SA/models/resnet18/resnet18.py:179, :257, :345,
+        # vgg19.py:118, :251, :323; read by SA/train/loss/loss_functions.py:17-19 only): (final logits, [early-exit logits], final
+        # features, [early-exit features]).  The engine pools inside its fused head kernel, so the feature slots are None — the
+        # single-exit forms keep the reference's own placeholders (0, []).
+        self.intermediary_output_list = (out[-1], list(out[:-1]), None, []) if len(out) > 1 else (out[0], [], 0, [])
         return out

@@ -63,26 +63,50 @@ def _rank_world(group=None):
     return 0, 1
 
 
+def share_kind(engine, T, B, world, kind=None):
+    """``partition``'s choice for this engine: with ``kind=None`` an image split that some rank's kernels cannot take (a share that
+    does not start on a whole Philox call of every site, ``bmi_image_offset_ok``: e.g. B = 250 over 8 ranks with a 32-channel
+    channel-wise site) falls back to the sample split — host-only and the same answer on every rank, so the choice stays
+    collective-safe.  An explicit ``kind="images"`` that cannot be taken raises on every rank together."""
+    chosen = partition(T, B, 0, world, kind)[0]
+    if chosen != "images":
+        return chosen
+    # every rank checks EVERY rank's image offset: a partition is accepted or refused by the whole group before anyone launches,
+    # instead of one rank raising while the others wait in the all-reduce
+    bad = [r for r in range(world) if not engine.image_offset_ok(shard_range(B, r, world)[0])]
+    if not bad:
+        return "images"
+    if kind is None:
+        return "samples"
+    raise ValueError(f"image partition of a batch of {B} over {world} ranks: the shares of ranks {bad} do not start on a "
+                     "whole Philox call of every site (bmi_image_offset_ok)")
+
+
 def accumulate_share(engine, x, S, T, seed=0, cnt0=0, rank=0, world=1, kind=None):
     """Rank ``rank``'s share of batch ``x`` x T samples ADDED into the moment buffer ``S`` [3, E, B, C]; NO collective (what a
-    hipGraph of a rank's step captures: ``BatchesInFlight.predict_graphed``).  Shares by samples when T >= world size, by images
-    otherwise: the rank runs ``engine.accumulate(x[lo:hi], ..., image_offset=lo)`` — masks drawn at the images' indices in the
-    whole batch (bmi_forward_mcd_images) — into its rows of S; the other ranks' rows stay zero until the all-reduce."""
-    kind, lo, hi = partition(T, x.shape[0], rank, world, kind)
+    hipGraph of a rank's step captures: ``BatchesInFlight.predict_graphed``).  ``partition`` decides (``share_kind``): by samples
+    while T > world size; by images when T <= world — the rank runs ``engine.accumulate(x[lo:hi], ..., image_offset=lo)``, masks
+    drawn at the images' indices in the whole batch (bmi_forward_mcd_images), into its rows of S (the other ranks' rows stay zero
+    until the all-reduce) — unless some rank's share cannot start where the split puts it: then by samples after all
+    (``kind=None``), or a ValueError on every rank (explicit ``kind="images"``).  Nothing is allocated here: the share's
+    [3, E, hi - lo, C] staging buffer belongs to the engine."""
+    B = x.shape[0]
+    kind = share_kind(engine, T, B, world, kind)
+    _, lo, hi = partition(T, B, rank, world, kind)
     if kind == "samples":
         if hi > lo:
             engine.accumulate(x, S, lo, hi - lo, seed, cnt0)
         return S
-    # every rank checks EVERY rank's image offset (host-only, the same answer everywhere): a partition some rank's kernels cannot
-    # take is refused by the whole group before anyone launches, instead of one rank raising while the others wait in the all-reduce
-    bad = [r for r in range(world) if not engine.image_offset_ok(shard_range(x.shape[0], r, world)[0])]
-    if bad:
-        raise ValueError(f"image partition of a batch of {x.shape[0]} over {world} ranks: the shares of ranks {bad} do not start on a "
-                         "whole Philox call of every site (bmi_image_offset_ok)")
     if hi > lo:
-        part = S.new_zeros(3, S.shape[1], hi - lo, S.shape[3])
-        engine.accumulate(x[lo:hi].contiguous(), part, 0, T, seed, cnt0, image_offset=lo)
-        S[:, :, lo:hi] += part
+        cache = engine.__dict__.setdefault("_share_parts", {})
+        key = (S.shape[1], hi - lo, S.shape[3])
+        part = cache.get(key)
+        if part is None:
+            part = cache[key] = S.new_zeros(3, S.shape[1], hi - lo, S.shape[3])      # first call of this share shape only
+        else:
+            part.zero_()
+        engine.accumulate(x[lo:hi], part, 0, T, seed, cnt0, image_offset=lo)
+        S[:, :, lo:hi].add_(part)
     return S
 
 

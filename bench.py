@@ -315,7 +315,7 @@ def main():
         dist.all_reduce(_probe)
         torch.cuda.synchronize()
 
-    from bayesnn_fpga_amd.sharding import accumulate_partitioned, partition
+    from bayesnn_fpga_amd.sharding import accumulate_partitioned, partition, share_kind
     from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
     from bayesnn_fpga_amd.train.metrics import ece_hist_binary
 
@@ -332,7 +332,9 @@ def main():
     eng = pipe.engines[0]
     x = synthetic_images(B, seed=1234).to(dev)
     pkind = None if a.partition == "auto" else a.partition
-    share = partition(T, B, rank, world, pkind)       # ("samples", lo, hi) while T > world, else ("images", lo, hi): nobody idles
+    # ("samples", lo, hi) while T > world, else ("images", lo, hi): nobody idles (share_kind: by samples after all when an image share
+    # could not start on a whole Philox call of every site)
+    share = partition(T, B, rank, world, share_kind(eng, T, B, world, pkind))
     t_lo, t_hi = (share[1], share[2]) if share[0] == "samples" else (0, T)
     Ss = [e.new_moments(B) for e in pipe.engines]
 
@@ -346,7 +348,7 @@ def main():
     def step():
         # one step = one batch through the whole path; consecutive steps alternate between the engines / streams of `pipe`
         if a.graph:
-            return pipe.predict_graphed(x, T, a.seed, kind=pkind)
+            return pipe.predict_graphed(x, T, a.seed, kind=pkind, shard=True)
         i = pipe.slot()
         return pipe.submit(lambda e: one_batch(e, Ss[i]))
 

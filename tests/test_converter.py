@@ -395,3 +395,46 @@ def test_gpu_fx_compiled_net_against_reference_golden():
     mean_logits = m(x)                                                       # eval mode: sum(pred) / len(pred), per output
     assert isinstance(mean_logits, list) and len(mean_logits) == 2
     np.testing.assert_allclose(mean_logits[1].cpu().numpy(), ref.mean(0)[1], rtol=0, atol=2e-4)
+
+
+def test_fx_front_end_names_the_node_it_cannot_lower():
+    """Round-4 advisor: a hidden Linear behind a pooled map, a ReLU / pool on logits and a residual add with alpha are TypeErrors that
+    name the node — not an unpacking ValueError, not a silently folded plain add.  (Host only: the graph builder runs on a CPU box.)"""
+    from torch import nn
+    import torch.nn.functional as F
+    from bayesnn_fpga_amd.converter.pytorch import fx_frontend
+    from bayesnn_fpga_amd.engine import GraphBuilder
+
+    class HiddenAfterPool(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv, self.bn = nn.Conv2d(3, 64, 3, padding=1), nn.BatchNorm2d(64)
+            self.fc1, self.fc2 = nn.Linear(64, 64), nn.Linear(64, 10)
+
+        def forward(self, x):
+            y = F.relu(self.bn(self.conv(x)))
+            y = F.adaptive_avg_pool2d(y, 1).flatten(1)
+            return self.fc2(F.relu(self.fc1(y)))
+
+    class ReluOnLogits(HiddenAfterPool):
+        def forward(self, x):
+            y = F.relu(self.bn(self.conv(x)))
+            y = F.adaptive_avg_pool2d(y, 1).flatten(1)
+            return F.relu(self.fc2(y))
+
+    class AlphaAdd(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.b1 = nn.Conv2d(3, 64, 3, padding=1), nn.BatchNorm2d(64)
+            self.c2, self.b2 = nn.Conv2d(64, 64, 3, padding=1), nn.BatchNorm2d(64)
+            self.fc = nn.Linear(64, 10)
+
+        def forward(self, x):
+            y = F.relu(self.b1(self.c1(x)))
+            z = F.relu(torch.add(self.b2(self.c2(y)), y, alpha=2))
+            return self.fc(F.adaptive_avg_pool2d(z, 1).flatten(1))
+
+    for net, what in ((HiddenAfterPool(), "hidden Linear behind a global average pool"), (ReluOnLogits(), "hidden Linear behind a global average pool"),
+                      (AlphaAdd(), "keyword arguments")):
+        with pytest.raises(TypeError, match=what):
+            fx_frontend.build_graph_fx(net.eval(), GraphBuilder("cpu"))

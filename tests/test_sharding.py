@@ -188,3 +188,35 @@ def test_image_partition_is_refused_by_every_rank_together():
     eng.bad_offset = 0                     # world = 1: the only share starts at image 0
     with pytest.raises(ValueError, match="whole Philox call"):
         ap(eng, x, torch.zeros(3, 4, 3, 10, dtype=torch.float64), 2, seed=42, kind="images")
+
+
+def test_default_partition_falls_back_to_samples_when_an_image_share_is_refused():
+    """Round-4 advisor (medium): with kind=None a T <= world batch goes by images — unless some rank's share cannot start where the
+    split puts it (bmi_image_offset_ok: e.g. B = 250 over 8 ranks with a 32-channel channel-wise site).  Then every rank takes the
+    SAMPLE split instead (host-only decision, the same on all ranks), and the shares still add up to the one-rank result; an explicit
+    kind="images" keeps raising."""
+    from bayesnn_fpga_amd.sharding import accumulate_share, share_kind
+    from bayesnn_fpga_amd.synthetic import synthetic_images
+    model = _build(KW_MC)
+    x = synthetic_images(3, seed=1234)
+    T, world = 2, 2
+    eng = _OracleEngine(model, x, 42)
+    assert share_kind(eng, T, 3, world) == "images"
+    eng.bad_offset = 2                                    # rank 1's share would start at image 2
+    assert share_kind(eng, T, 3, world) == "samples"
+    with pytest.raises(ValueError, match="whole Philox call"):
+        share_kind(eng, T, 3, world, "images")
+    S = torch.zeros(3, 4, 3, 10, dtype=torch.float64)
+    for r in range(world):
+        accumulate_share(eng, x, S, T, seed=42, rank=r, world=world)
+    S1 = torch.zeros(3, 4, 3, 10, dtype=torch.float64)
+    accumulate_share(eng, x, S1, T, seed=42)
+    np.testing.assert_allclose(S.numpy(), S1.numpy(), rtol=1e-12, atol=1e-12)
+    # the image split itself (no refusal) through the engine-owned staging buffer: twice, the second call reuses it
+    eng.bad_offset = None
+    for _ in range(2):
+        S2 = torch.zeros(3, 4, 3, 10, dtype=torch.float64)
+        for r in range(world):
+            accumulate_share(eng, x, S2, T, seed=42, rank=r, world=world)
+        np.testing.assert_allclose(S2.numpy(), S1.numpy(), rtol=1e-12, atol=1e-12)
+    assert len(eng._share_parts) == 2                     # one staging buffer per share shape (2 images, 1 image)
