@@ -31,6 +31,7 @@ struct TensorInfo {
     // Lazy site (the output of an elementwise MASK op on a deterministic tensor, see bmi_create): tensors that hold the keep bits of
     // the folded batch and the deterministic input times 1/(1-p) (fp16), or -1
     int lazy_bits = -1, lazy_scaled = -1;
+    bool lazy_planar_plan = false;   // (bmi_plan) ... and every one of those readers' launches passes its kernel's minimum-grid rule at the planned chunk
     bool lazy_planar = false;   // every reader is a stride-2 consumer (conv3x3_s2 on 32x32 maps / conv3x3_patch's fused shortcut) and the site draws 2 bits
                                 // per element: bits + scaled copy are stored in the planar layout (kernels.h lazy_planar_off)
     bool lazy_pending = false;  // (run time) bits + scaled copy are written, the masked tensor itself is not (yet)
@@ -88,6 +89,12 @@ struct bmi_engine_s {
     size_t splitk_off = 0;               // fp32 partial sums of the split-K prefix convs
     int image_offset = 0;                // batch index of the current call's image 0 (bmi_forward_mcd_images), else 0
     size_t head_off = 0;                 // float64 partial sums of a head launch's 32-sample groups (joined in group order)
+    // bmi_forward_mcd_samples: per-sample logits out, Masksembles masks walked with a stride
+    float* logits_out = nullptr;         // (run time) [t_count][E][batch][C] of the current call, or null
+    bool no_moments = false;             // (run time) the heads write per-sample logits only
+    int logits_t_begin = 0, logits_batch = 0;
+    int mask_stride = 1, mask_t_begin = 0;    // (run time) stride != 1: a site's mask of sample t is row (t - mask_t_begin) % M of its PERMUTED table
+    std::vector<std::pair<const float*, size_t>> perm;   // (bmi_plan) Masksembles tables (device pointer of the site) -> workspace offset of the permuted copy
     // profiling
     bool profiling = false;
     double fam_ms[BMI_CONV_FAMILIES] = {0}, fam_flops[BMI_CONV_FAMILIES] = {0}, fam_bytes[BMI_CONV_FAMILIES] = {0};
@@ -732,9 +739,38 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     off += sk_bytes;
     h->head_off = off;
     off += align_up((size_t)((chunk_samples + 31) / 32) * 3 * max_batch * h->out_dim * sizeof(double), 256);
+    h->perm.clear();
+    for (const std::vector<OpInfo>* ops : {&h->prefix, &h->suffix})
+        for (const OpInfo& op : *ops) {
+            const bmi_site& st = op.d.site;
+            if (st.kind != BMI_SITE_MASKSEMBLE) continue;
+            bool seen = false;
+            for (const auto& pr : h->perm) seen = seen || pr.first == st.masks;
+            if (seen) continue;
+            const int width = op.d.kind == BMI_OP_HEAD ? h->tensors[op.d.in].c : op.cout;       // a site's table is [M][channels of its tensor]
+            h->perm.push_back({st.masks, off});
+            off += align_up((size_t)st.num_masks * width * sizeof(float), 256);
+        }
     h->ws_bytes = off;
     h->max_batch = max_batch;
     h->chunk = chunk_samples;
+    // A lazy site keeps its PLANAR layout only while every stride-2 reader's launch passes conv3x3_s2's minimum-grid rule at the planned
+    // full chunk (n_ref = max_batch x chunk: what the launcher looks at; 256 CUs): a reader that declines makes run_op materialise the
+    // tensor — correct either way, but the planar bits + copy would then have been written for nothing (and conv_igemm / conv1x1_stream
+    // refuse a planar operand).  Small engines (tests, T = 1 mirrors) therefore plan NHWC lazy sites.
+    for (TensorInfo& t : h->tensors) {
+        t.lazy_planar_plan = t.lazy_planar;
+        if (!t.lazy_planar) continue;
+        const int id = (int)(&t - h->tensors.data());
+        for (const OpInfo& c : h->suffix) {
+            if (c.d.kind != BMI_OP_CONV || c.d.in != id || c.d.in2 >= 0) continue;       // (the fused-shortcut reader is conv3x3_patch: no grid rule on the operand)
+            const int cout = c.cout + (c.has_pair ? c.pair_cout : 0);
+            const long imgs = std::max(1, 256 / (c.ho * c.wo));
+            const long tiles = ((long)NS + imgs - 1) / imgs * (cout / (cout % 256 ? 128 : 256));
+            if (opt_conv_s2() != 2 && tiles < 3 * 256 / 4) t.lazy_planar_plan = false;
+            if (opt_conv_s2() == 0) t.lazy_planar_plan = false;
+        }
+    }
     *workspace_bytes = off;
     return BMI_OK;
 }
@@ -802,6 +838,20 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         return (uint64_t)b0 * (st.kind == BMI_SITE_CHANNEL ? channels : per_image);
     };
     const int n_rows = imap ? (N / Bc) * B : N;     // rows of a stochastic tensor (original folded layout)
+    // Masksembles masks walked with a stride (bmi_forward_mcd_samples): the kernels index row (cnt0 + t) % M of a site's table; the
+    // call has gathered table'[r] = table[(mask_cnt0 + r stride) % M] into the workspace, and cnt0' = -t_begin mod M makes that row
+    // (t - t_begin) % M — no kernel knows about the stride
+    auto resolve_site = [&](const bmi_site* site, uint64_t sd, int c0, uint64_t elem_off = 0) {
+        SiteArgs sa = ::resolve_site(site, sd, c0, elem_off);
+        if (sa.kind == BMI_SITE_MASKSEMBLE && e->mask_stride != 1)
+            for (const auto& pr : e->perm)
+                if (pr.first == sa.masks) {
+                    sa.masks = (const float*)(ws + pr.second);
+                    sa.cnt0 = (sa.num_masks - e->mask_t_begin % sa.num_masks) % sa.num_masks;
+                    break;
+                }
+        return sa;
+    };
     if (imap && d.kind != BMI_OP_CONV && d.kind != BMI_OP_HEAD) return BMI_ERR_UNSUPPORTED;
     if (imap && e->f32) return BMI_ERR_UNSUPPORTED;
     // a lazy site's tensor (see bmi_create) is written now if this op cannot apply the mask itself
@@ -998,7 +1048,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             TensorInfo& to = e->tensors[d.out];
             to.lazy_pending = false;
             if (to.lazy_bits >= 0 && opt_mask_lazy() && !tin.stoch && N % B == 0) {
-                const bool planar = to.lazy_planar && opt_lazy_planar();
+                const bool planar = to.lazy_planar_plan && opt_lazy_planar();
                 to.lazy_planar_now = planar;
                 const int rcb = launch_mask_bits((uint8_t*)(ws + e->tensors[to.lazy_bits].offset), N, tin.h * tin.w, tin.c, a.site, B, t0, s, planar ? tin.w : 0);
                 if (rcb == BMI_OK) {
@@ -1037,7 +1087,13 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.b0 = b0;
             const size_t eo = (size_t)d.out * B * e->out_dim;
             a.S1 = S1 + eo; a.S2 = S2 + eo; a.SL = SL + eo;
+            if (e->no_moments) a.S1 = a.S2 = a.SL = nullptr;
             a.part = (double*)(ws + e->head_off);
+            if (e->logits_out) {            // per-sample logits of this exit: [t - t_begin][E][batch][C]
+                const size_t plane = (size_t)e->logits_batch * e->out_dim;
+                a.logits = e->logits_out + ((size_t)(t0 - e->logits_t_begin) * e->n_exits + d.out) * plane;
+                a.logits_tstride = (size_t)e->n_exits * plane;
+            }
             return launch_head_fused(a, s);
         }
     }
@@ -1100,6 +1156,43 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
         }
     }
     return BMI_OK;
+}
+
+int bmi_forward_mcd_samples(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_begin, int32_t t_count, uint64_t seed,
+                            int32_t mask_cnt0, int32_t mask_stride, float* logits, double* S1, double* S2, double* SL, void* workspace,
+                            size_t workspace_bytes, bmi_stream stream) {
+    if (!h || !logits || !workspace || mask_stride < 1 || t_begin < 0 || mask_cnt0 < 0) return BMI_ERR_INVALID;
+    if ((S1 || S2 || SL) && !(S1 && S2 && SL)) return BMI_ERR_INVALID;
+    if (h->max_batch == 0 || batch < 1 || batch > h->max_batch) return BMI_ERR_INVALID;
+    if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
+    int cnt0 = mask_cnt0;
+    if (mask_stride != 1 && !h->perm.empty()) {
+        // gather every Masksembles table in the order this call walks it: table'[r] = table[(mask_cnt0 + r * stride) % M]
+        for (const std::vector<OpInfo>* ops : {&h->prefix, &h->suffix})
+            for (const OpInfo& op : *ops) {
+                const bmi_site& st = op.d.site;
+                if (st.kind != BMI_SITE_MASKSEMBLE) continue;
+                for (auto& pr : h->perm)
+                    if (pr.first == st.masks) {
+                        const int width = op.d.kind == BMI_OP_HEAD ? h->tensors[op.d.in].c : op.cout;
+                        const int rc = launch_mask_permute(st.masks, (float*)((char*)workspace + pr.second), st.num_masks, width, mask_cnt0, mask_stride,
+                                                           (hipStream_t)stream);
+                        if (rc != BMI_OK) return rc;
+                        break;
+                    }
+            }
+        h->mask_stride = mask_stride;
+        h->mask_t_begin = t_begin;
+        cnt0 = 0;
+    }
+    h->logits_out = logits; h->logits_t_begin = t_begin; h->logits_batch = batch;
+    static double dummy;          // (bmi_forward_mcd's argument check; the head never dereferences S* when S1 is the dummy: see run_op)
+    const bool moments = S1 != nullptr;
+    h->no_moments = !moments;
+    const int rc = bmi_forward_mcd(h, x_nchw, batch, t_begin, t_count, seed, cnt0, moments ? S1 : &dummy, moments ? S2 : &dummy, moments ? SL : &dummy,
+                                   workspace, workspace_bytes, stream);
+    h->logits_out = nullptr; h->mask_stride = 1; h->mask_t_begin = 0; h->no_moments = false;
+    return rc;
 }
 
 int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_count, uint64_t seed, int32_t mask_cnt0,

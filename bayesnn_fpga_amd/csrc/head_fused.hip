@@ -316,6 +316,9 @@ __global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArg
                 const bool ok = live && c < C;
                 const double p = ok ? (double)pb_p[c * 33 + ts] : 0.0;
                 double s1 = p, s2 = p * p, sl = ok ? (double)pb_l[c * 33 + ts] : 0.0;
+                // per-sample logits out (bmi_forward_mcd_samples: what the reference's evaluate() consumes pass by pass)
+                if (a.logits && ok) a.logits[(size_t)(g * 32 + ts) * a.logits_tstride + (size_t)b * C + c] = pb_l[c * 33 + ts];
+                if (!a.S1) continue;
 #pragma unroll
                 for (int m = 16; m >= 1; m >>= 1) {
                     s1 += __shfl_xor(s1, m);
@@ -382,7 +385,8 @@ int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
     HeadArgs a = a_in;
     const int groups = (a.tc + 31) / 32;
     if (groups <= 1) a.part = nullptr;             // one group per image: the workgroup adds into S1 / S2 / SL itself
-    if (!a.in || !a.w || !a.bias || !a.S1 || !a.S2 || !a.SL) return BMI_ERR_INVALID;
+    if (!a.in || !a.w || !a.bias) return BMI_ERR_INVALID;
+    if (!a.S1 || !a.S2 || !a.SL) { if (!a.logits) return BMI_ERR_INVALID; a.S1 = a.S2 = a.SL = nullptr; a.part = nullptr; }     // logits only
     if (a.B <= 0 || a.tc <= 0 || a.in_mod <= 0 || a.HW <= 0 || a.C <= 0 || a.in_kind < 0 || a.in_kind > 2) return BMI_ERR_INVALID;
     if (a.in_mod != a.B && a.in_mod != a.B * a.tc) return BMI_ERR_INVALID;
     if (a.imap && (a.Bc <= 0 || a.Bc > a.B)) return BMI_ERR_INVALID;

@@ -111,6 +111,8 @@ struct HeadArgs {   // fused exit head (head_fused.hip)
     int b0;               // batch index of this launch's image 0 (bmi_forward_mcd_images), for the logits site: b0 * C is not a
                           // multiple of a Philox call, so it cannot ride in site_logits.elem_off
     double *S1, *S2, *SL; // this exit's [B][C] moment accumulators
+    float* logits;        // per-sample logits out: sample tl of this launch, class c of image b -> logits[tl * logits_tstride + b * C + c]; or null
+    size_t logits_tstride;
     double* part;         // scratch [ceil(tc / 32)][3][B][C] for the per-group partial sums of a launch with more than 32 samples, or
                           // null (hardware atomics then: the single-kernel entry point)
 };
@@ -141,6 +143,8 @@ int launch_dense_f32(const void* in, int in_kind, const float* w, const float* b
 int launch_exit_decide(const double* S1e, int C, int t_total, double thr, const int* in, int bc, int* out, int* count,
                        int* exit_of, int e, hipStream_t s);
 int launch_fill_int(int* p, int n, int v, hipStream_t s);
+// dst[r][c] = src[(cnt0 + r * stride) % m][c], r < m (a Masksembles table in the order a strided walk visits it)
+int launch_mask_permute(const float* src, float* dst, int m, int c, int cnt0, int stride, hipStream_t s);
 int launch_expand_rows(const int* active, int bc, int batch, int tc, int* rows, hipStream_t s);   // rows[tl*bc + i] = tl*batch + active[i]
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
                     double* var, double* lm, hipStream_t s);

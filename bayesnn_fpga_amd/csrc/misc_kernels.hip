@@ -607,6 +607,20 @@ __global__ void fill_int_kernel(int* p, int n, int v) {
     if (i < n) p[i] = v;
 }
 
+__global__ void mask_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int m, int c, int cnt0, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * c) return;
+    const int r = i / c, k = i - r * c;
+    dst[i] = src[(size_t)((cnt0 + (long)r * stride) % m) * c + k];
+}
+
+int launch_mask_permute(const float* src, float* dst, int m, int c, int cnt0, int stride, hipStream_t s) {
+    if (!src || !dst || m <= 0 || c <= 0 || stride < 1 || cnt0 < 0) return BMI_ERR_INVALID;
+    hipLaunchKernelGGL(mask_permute_kernel, dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, s, src, dst, m, c, cnt0, stride);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
 int launch_fill_int(int* p, int n, int v, hipStream_t s) {
     if (!p || n <= 0) return BMI_ERR_INVALID;
     hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);

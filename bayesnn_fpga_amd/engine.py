@@ -473,6 +473,24 @@ class MCDEngine(CompiledGraph):
         self.accumulate(x, S, t, 1, seed, cnt0)
         return [S[2, e].float() for e in range(self.n_exits)]
 
+    def forward_samples(self, x, T, seed=0, t_begin=0, cnt0=0, mask_stride=1, out=None):
+        """Per-sample logits of the folded path (bmi_forward_mcd_samples): fp32 [T, E, B, C] — what T calls of the reference's
+        ``model(x)`` return, from ONE pass of the engine over the batch (prefix once, the samples folded into the launches).
+        ``mask_stride``: the Masksembles mask of sample i is (cnt0 + i * mask_stride) mod M (the reference's layers count forward
+        calls: ``train/evaluate.py`` folds the T passes of batch k of an n-batch loader with cnt0 = cnt + k, mask_stride = n)."""
+        x = self._check_x(x)
+        B = x.shape[0]
+        if out is None:
+            out = torch.empty(T, self.n_exits, B, self.out_dim, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (T, self.n_exits, B, self.out_dim) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be contiguous float32 [T, E, B, C]")
+        with torch.cuda.device(self.device):
+            rc = self.lib.bmi_forward_mcd_samples(self.handle, x.data_ptr(), B, int(t_begin), int(T), int(seed) & 0xFFFFFFFFFFFFFFFF, int(cnt0),
+                                                  int(mask_stride), out.data_ptr(), None, None, None, self.workspace.data_ptr(), self.workspace_bytes,
+                                                  self._stream())
+        _lib.check(rc, "bmi_forward_mcd_samples")
+        return out
+
     def read_tensor(self, tensor_id, batch, samples=1):
         """A copy of graph tensor ``tensor_id`` as it sits in the workspace after a forward (bmi_tensor_info): fp32
         [samples * batch or batch, h, w, c].  For per-layer traces (tools/layer_trace.py): plan the engine under
@@ -538,6 +556,7 @@ class BatchesInFlight:
     def __init__(self, model, device, n=2, **engine_kwargs):
         if n < 1:
             raise ValueError("n >= 1 batches in flight")
+        self._model = model
         self.engines = [MCDEngine(model, device, **engine_kwargs) for _ in range(n)]
         self.device = self.engines[0].device
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else [None]
@@ -546,6 +565,69 @@ class BatchesInFlight:
 
     def slot(self):
         return self.k % len(self.engines)
+
+    use_graph = False      # step(): one hipGraph replay per batch step (tuned() sets it for launch-bound models)
+
+    @classmethod
+    def tuned(cls, model, device, x, T, seed=0, cnt0=0, threshold_ms=1.0, **engine_kwargs):
+        """The pipe a model should run with, decided by MEASUREMENT on its first batch: one engine is built, a batch step (x, T) is
+        warmed up and timed with HIP events; a step under ``threshold_ms`` is launch-bound (VGG-11 at batch 250 x T = 30: ~20 launches of
+        20-50 us on a ~20 us launch floor, 0.26 ms per step) and gets THREE batches in flight, each step ONE hipGraph replay
+        (``predict_graphed``: 28 -> 38 M MCD-samples/s on VGG-11, round-3 measurement); anything longer (the ResNets at T = 100:
+        21 ms) gets two eager engines, where a replay buys nothing and a third workspace costs memory.  ``pipe.step(x, T, seed)`` runs a
+        batch either way; results are bit for bit the same in both modes (tests/test_gpu_model.py)."""
+        pipe = cls(model, device, n=1, **engine_kwargs)
+        pipe.step_ms_measured = pipe.measure_ms(lambda e: e.predict(x, T, seed, cnt0=cnt0))
+        launch_bound = pipe.step_ms_measured < threshold_ms
+        pipe.grow(3 if launch_bound else 2)
+        pipe.use_graph = launch_bound
+        return pipe
+
+    def measure_ms(self, fn, warm=2, reps=3):
+        """Milliseconds per call of ``fn(engine 0)`` on the current stream (HIP events; ``warm`` untimed calls first)."""
+        eng = self.engines[0]
+        for _ in range(warm):
+            fn(eng)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record(torch.cuda.current_stream(self.device))
+        for _ in range(reps):
+            fn(eng)
+        ev[1].record(torch.cuda.current_stream(self.device))
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1]) / reps
+
+    def grow(self, n):
+        """``n`` batches in flight from now on: more engines of the same model (own workspace, own weights), one stream each."""
+        if n < len(self.engines):
+            raise ValueError("a pipe only grows")
+        e0 = self.engines[0]
+        kw = dict(max_batch=e0.max_batch, chunk_samples=e0.chunk_samples if e0.chunk_explicit else None, dtype=e0.dtype)
+        self.engines += [MCDEngine(self._model, self.device, **kw) for _ in range(n - len(self.engines))]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else [None]
+        for attr in ("_graphs", "_gstreams"):
+            if hasattr(self, attr):
+                delattr(self, attr)
+        return self
+
+    def step(self, x, T, seed=0, cnt0=0, group=None, kind=None, shard=False):
+        """One batch step on the next slot — a hipGraph replay (``use_graph``) or eager — with the work partitioned over ``group`` when
+        one is given (``shard=True``: the default group).  Returns what ``MCDEngine.finalize`` returns (device tensors on ``last_stream``)."""
+        if self.use_graph:
+            return self.predict_graphed(x, T, seed, cnt0, group=group, kind=kind, shard=shard)
+        from .sharding import accumulate_partitioned
+
+        def run(e):
+            S = e.__dict__.get("_step_S")
+            if S is None or S.shape[2] != x.shape[0]:
+                S = e.__dict__["_step_S"] = e.new_moments(x.shape[0])
+            else:
+                S.zero_()
+            if group is not None or shard:
+                accumulate_partitioned(e, x, S, T, seed, cnt0, group=group, kind=kind)
+            else:
+                e.accumulate(x, S, 0, T, seed, cnt0)
+            return e.finalize(S, T)
+        return self.submit(run, inputs=(x,))
 
     def submit(self, fn, inputs=()):
         """Runs fn(engine) on the next slot's stream (after everything already queued on the caller's current stream, which is
@@ -565,7 +647,7 @@ class BatchesInFlight:
         with torch.cuda.stream(st):
             return fn(self.engines[i])
 
-    def predict_graphed(self, x, T, seed=0, cnt0=0, group=None, kind=None, shard=False):
+    def predict_graphed(self, x, T, seed=0, cnt0=0, group=None, kind=None, shard=False, always_reduce=False):
         """``engine.predict(x, T, seed, cnt0=cnt0)`` of the next slot as ONE hipGraph launch (torch.cuda.CUDAGraph on ROCm).
         The library neither allocates nor synchronises inside bmi_forward_mcd / bmi_finalize, so the whole batch step — zero
         the moments, the once-per-batch prefix, every sample chunk of the suffix, finalize — is captured once per
@@ -595,7 +677,7 @@ class BatchesInFlight:
             from collections import OrderedDict
             self._graphs = [OrderedDict() for _ in self.engines]
             self._gstreams = [st if st is not None else torch.cuda.Stream(self.device) for st in self.streams]
-        key = (tuple(x.shape), int(T), int(seed), int(cnt0), rank, world, kind)
+        key = (tuple(x.shape), int(T), int(seed), int(cnt0), rank, world, kind, bool(always_reduce))
         cache = self._graphs[i]
         rec = cache.get(key)
         if rec is None and eng.profiling:          # (before the slot rotation advances: a refused call leaves the pipe as it was)
@@ -605,13 +687,15 @@ class BatchesInFlight:
         self.last_stream = st
         cur = torch.cuda.current_stream(self.device)
 
+        reduce = world > 1 or bool(always_reduce)        # (always_reduce: the collective in a group of ONE rank too — the 1-GPU RCCL probe)
+
         def eager():
             st.wait_stream(cur)
             x.record_stream(st)
             with torch.cuda.stream(st):
                 S = eng.new_moments(x.shape[0])
                 accumulate_share(eng, x, S, T, seed, cnt0, rank, world, kind)
-                if world > 1:
+                if reduce:
                     import torch.distributed as dist
                     dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
                 return eng.finalize(S, T)
@@ -629,7 +713,7 @@ class BatchesInFlight:
                 with torch.cuda.graph(graph, stream=st):
                     S.zero_()
                     accumulate_share(eng, xs, S, T, seed, cnt0, rank, world, kind)
-                    if world == 1:
+                    if not reduce:
                         out.update(eng.finalize(S, T))
             except Exception as exc:                              # (a launcher returned non-OK under capture, ...)
                 import warnings
@@ -649,7 +733,7 @@ class BatchesInFlight:
         with torch.cuda.stream(st):
             xs.copy_(x, non_blocking=True)
             graph.replay()
-            if world > 1:
+            if reduce:
                 import torch.distributed as dist
                 dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
                 return eng.finalize(S, T)

@@ -10,24 +10,25 @@ class EngineModelMixin:
     def _init_engine_state(self):
         self.mc_seed = 0      # Philox key of the Monte-Carlo stream (csrc/philox.h)
         self.mc_pass = 0      # global sample index t of the next forward
-        self._engines = {}
+        self._engines, self._eval_pipes = {}, {}
 
     def _apply(self, fn, *a, **k):
-        self._engines = {}          # parameters moved / cast: compiled weights are stale
+        self._engines, self._eval_pipes = {}, {}          # parameters moved / cast: compiled weights are stale
         return nn.Module._apply(self, fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._engines = {}
+        self._engines, self._eval_pipes = {}, {}
         return nn.Module.load_state_dict(self, *a, **k)
 
     def invalidate_engine(self):
-        self._engines = {}
+        self._engines, self._eval_pipes = {}, {}
 
     def __getstate__(self):
         """Compiled engines hold ctypes handles and device workspaces: never part of a pickle / deepcopy
         (torch.save(model) of SA/main.py:79 works without a manual invalidate_engine())."""
         state = self.__dict__.copy()
         state["_engines"] = {}
+        state["_eval_pipes"] = {}          # (train/evaluate.py: the folded evaluation's two engines in flight)
         return state
 
     def engine(self, device, max_batch=None, chunk_samples=None, dtype=None):
@@ -54,6 +55,8 @@ class EngineModelMixin:
 
     def mask_layers(self):
         return [m for m in self.modules() if isinstance(m, (Masksembles1D, Masksembles2D))]
+
+    forward_samples_ok = True      # (train/evaluate.py: this model's T stochastic forwards of a batch fold into MCDEngine.forward_samples)
 
     def advance(self, passes):
         """Bookkeeping after ``passes`` stochastic forwards: MC pass index and every Masksembles

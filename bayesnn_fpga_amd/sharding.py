@@ -110,13 +110,14 @@ def accumulate_share(engine, x, S, T, seed=0, cnt0=0, rank=0, world=1, kind=None
     return S
 
 
-def accumulate_partitioned(engine, x, S, T, seed=0, cnt0=0, group=None, kind=None):
+def accumulate_partitioned(engine, x, S, T, seed=0, cnt0=0, group=None, kind=None, always_reduce=False):
     """This rank's share of batch ``x`` x T samples ADDED into the moment buffer ``S`` [3, E, B, C] (``accumulate_share``), then ONE
-    all-reduce (sum) over the group."""
+    all-reduce (sum) over the group.  ``always_reduce``: issue the collective in a group of ONE rank too (a sum over one rank: the same
+    bits) — how a 1-GPU box exercises RCCL on exactly the streams and buffers the N-GPU path uses (bench.py's ``allreduce_us_1rank``)."""
     import torch.distributed as dist
     rank, world = _rank_world(group)
     accumulate_share(engine, x, S, T, seed, cnt0, rank, world, kind)
-    if world > 1:
+    if world > 1 or (always_reduce and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(S, op=dist.ReduceOp.SUM, group=group)
     return S
 

@@ -51,6 +51,34 @@ class MultiExitAccuracy:
     def _metrics(self, logits_list, y):
         return [float(v) for v in self._metrics_tensor(logits_list, y).cpu()]
 
+    def _metrics_passes(self, logits, y):
+        """``_metrics_tensor`` for T passes at once: ``logits`` fp32 [T, E, B, C] (MCDEngine.forward_samples) -> float64 [T, n_metrics],
+        row i = the vector ``_metrics`` gives for pass i's logits list (same arithmetic per pass, batched over T on the device).
+        With a leading group axis — ``logits`` [G, T, E, B, C], ``y`` [G, B]: G batches of one size — [G, T, n_metrics]: the metric
+        arithmetic of a whole group of loader batches in a dozen launches."""
+        grouped = logits.dim() == 5
+        if not grouped:
+            logits, y = logits[None], y[None]
+        G, T, E, Bn, C = logits.shape
+        k = len(self._acc_tops)
+        probs = F.softmax(logits if self.n_exits > 1 else logits[:, :, -1:], dim=-1)    # n_exits == 1: only the last logits count
+        ensemble = probs[:, :, 0].clone()
+        for i in range(1, probs.shape[2]):
+            ensemble += probs[:, :, i]                       # (the reference's order: exit 0 first)
+        both = torch.stack([logits[:, :, -1], ensemble])    # [2, G, T, B, C]: the two rows of the reference's quirk that survive
+        _, pred = both.topk(k=max(self._acc_tops), dim=-1)
+        hit = (pred == y[None, :, None, :, None]).float().cumsum(dim=-1).mean(dim=3)[..., [i - 1 for i in self._acc_tops]]   # [2, G, T, k]
+        acc_clf = torch.zeros(G, T, self.n_exits, k, device=y.device)
+        acc_ens = torch.zeros(G, T, self.n_exits, k, device=y.device)
+        acc_clf[:, :, 0] = hit[0]                            # (the reference's row-0 overwrite: the last exit and the full ensemble survive)
+        acc_ens[:, :, 0] = hit[1]
+        maxprob = probs[:, :, -1].max(dim=-1)[0].mean(dim=-1)
+        parts = [acc_clf.double().mean(dim=2)]
+        for i in range(k):
+            parts += [acc_clf[..., i].double(), acc_ens[:, :, 1:, i].double()]
+        out = torch.cat(parts + [maxprob.double()[..., None]], dim=-1)
+        return out if grouped else out[0]
+
     def metrics(self, net, X, y):
         return self._metrics(net.train(False)(X), y)
 
@@ -69,9 +97,69 @@ def validate_model_acc(loss_f, net, val_iter, gpu):
     return [sum(col) / len(col) for col in zip(*rows)]
 
 
-def evaluate(loss_fn, test_iter, model, gpu, experiment_id, mc_dropout_passes, create_log=True):
+def _evaluate_folded(loss_fn, test_iter, model, dev, T):
+    """The T outer passes of evaluate() FOLDED per batch: one walk over the loader, every batch's T stochastic forwards as ONE pass of
+    the engine (``MCDEngine.forward_samples``: prefix once, samples folded into the launches) and the metric vectors of its T passes in
+    one batched device op (``_metrics_passes``); averaged over the batches per pass, then over the passes, as the reference does
+    (train_utils.py:38, evaluate.py:17).  What the reference's loop order fixes is reproduced: pass i of batch k of an n-batch loader
+    is forward call i n + k, so its Masksembles mask is (cnt + k + i n) mod M (``mask_stride`` = n) and the layers' counters — and the
+    mirror's MC pass index — end T n calls further.  MC-dropout masks are i.i.d. draws addressed by the sample index: pass i of batch k
+    takes index mc_pass + k T + i here (the unfolded walk numbers them in call order, mc_pass + i n + k: another labelling of the same
+    draws — the averaged metrics agree in distribution, not sample for sample)."""
+    nb = len(test_iter)
+    cnt = model.mask_layers()[0].cnt if model.mask_layers() else 0
+    # Two batches in flight (engine.BatchesInFlight: own engine, workspace and stream each): the host-to-device copy of one batch runs
+    # beside the engine pass of the other.  The engine passes write their logits into ONE group buffer [G, T, E, B, C] (<= 256 MB), and
+    # the metric arithmetic runs once per group: per batch, its dozen tiny launches queued between the other stream's convolutions cost
+    # 0.7 ms of a 3.2 ms batch (tools/experiments/evaluate_fold_profile.py).
+    from ..engine import BatchesInFlight
+    rows, pipe, group = [], None, None            # group = [logits buffer, labels, batches filled, capacity, batch size]
+
+    def flush():
+        nonlocal group
+        if group is not None and group[2]:
+            pipe.synchronize()
+            rows.append(loss_fn._metrics_passes(group[0][:group[2]], torch.stack(group[1])))
+        group = None
+
+    for k, (X, y) in enumerate(test_iter):
+        Bk = int(X.shape[0])
+        if pipe is None or pipe.engines[0].max_batch < Bk:
+            flush()
+            key = (str(dev), getattr(model, "engine_dtype", "f16"), Bk)
+            pipes = model.__dict__.setdefault("_eval_pipes", {})
+            pipe = pipes.get(key) or pipes.setdefault(key, BatchesInFlight(model, dev, n=2, max_batch=Bk, dtype=key[1]))
+        if group is not None and (group[4] != Bk or group[2] == group[3]):
+            flush()
+        if group is None:
+            e0 = pipe.engines[0]
+            cap = max(1, min(nb - k, (1 << 28) // (T * e0.n_exits * Bk * e0.out_dim * 4)))
+            group = [torch.empty(cap, T, e0.n_exits, Bk, e0.out_dim, dtype=torch.float32, device=dev), [], 0, cap, Bk]
+        Xd, yd = X.to(dev, non_blocking=True), y.to(dev, non_blocking=True)      # (on the caller's stream: the slot's stream waits for it)
+        slot = group[0][group[2]]
+        group[1].append(yd)
+        group[2] += 1
+        pipe.submit(lambda eng, Xd=Xd, k=k, slot=slot: eng.forward_samples(Xd, T, seed=model.mc_seed, t_begin=model.mc_pass + k * T, cnt0=cnt + k,
+                                                                          mask_stride=nb, out=slot), inputs=(Xd,))
+    flush()
+    model.advance(T * nb)
+    per_batch = torch.cat(rows).cpu().numpy()               # [n_batches, T, n_metrics]: one host synchronisation per group of batches
+    # per pass: sum over the batches in loader order / n (train_utils.py:38), in Python floats like the reference
+    return np.array([[sum(float(per_batch[k, i, j]) for k in range(nb)) / nb for j in range(per_batch.shape[2])] for i in range(T)])
+
+
+def evaluate(loss_fn, test_iter, model, gpu, experiment_id, mc_dropout_passes, create_log=True, fold=True):
+    """SA/train/evaluate.py:8-22.  ``fold`` (default): the T outer passes are folded per batch (``_evaluate_folded``) when the model is one
+    of the package's mirrors, the loss a MultiExitAccuracy and the loader has a length; ``fold=False`` keeps the reference's loop order
+    (T walks over the loader, one ``model(X)`` per batch: 25 launches per call, host-bound — 11x slower, tools/loop_bench.py)."""
     model.eval()
-    per_pass = np.array([validate_model_acc(loss_fn, model, test_iter, gpu) for _ in range(mc_dropout_passes)])
+    dev = get_device(gpu)
+    foldable = (fold and hasattr(model, "forward_samples_ok") and hasattr(loss_fn, "_metrics_passes") and hasattr(test_iter, "__len__")
+                and len(test_iter) > 0 and dev.type == "cuda")
+    if foldable:
+        per_pass = _evaluate_folded(loss_fn, test_iter, model, dev, mc_dropout_passes)
+    else:
+        per_pass = np.array([validate_model_acc(loss_fn, model, test_iter, gpu) for _ in range(mc_dropout_passes)])
     averaged = list(np.average(per_pass, axis=0))
     if create_log:
         with open(f"log_{experiment_id}.txt", "w") as f:

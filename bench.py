@@ -96,15 +96,23 @@ def parse():
                     help="dry run of the N>1 code path on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-T", type=int, default=10, help="MC passes of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-1t-images", type=int, default=16, help="images of the 1-thread CPU-baseline sample (0 = skip)")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: consecutive steps alternate between this many engines / streams (engine.BatchesInFlight), so "
-                         "the once-per-batch prefix of step k+1 runs beside the suffix of step k; 1 = one stream")
+                         "the once-per-batch prefix of step k+1 runs beside the suffix of step k; 1 = one stream; 0 (default) = decided by "
+                         "measurement: a rank's step is timed once before the warm-up — under 1 ms it is launch-bound and gets 3 in flight + "
+                         "one hipGraph replay per step (VGG-11, one Masksembles mask per GPU), else 2 eager (the ResNets at T = 100)")
+    ap.add_argument("--no-graph", action="store_true", help="never replay a step as a hipGraph (overrides the measured choice)")
+    ap.add_argument("--macro", type=int, default=1,
+                    help="loader batches carried by one step: the engine batch is macro x the workload's 250 images (SURVEY 8.5: config 4's share "
+                         "of eight ranks is 31 images x 8 masks per 250-image batch, 0.6 ms of 25 launches — a macro-batch gives a rank enough work)")
     ap.add_argument("--graph", action="store_true",
                     help="each batch step (zero, prefix, suffix chunks, finalize) is ONE hipGraph replay (engine.BatchesInFlight.predict_graphed): "
                          "takes the launch floor out of the launch-bound small-model configs (VGG-11, one Masksembles mask per GPU); with more "
                          "than one rank the graph holds the rank's share and the all-reduce + finalize follow the replay eagerly")
     ap.add_argument("--partition", choices=("auto", "samples", "images"), default="auto",
                     help="how a batch x T samples is split over the ranks (sharding.partition): auto = by samples while T > ranks, by images otherwise")
+    ap.add_argument("--no-rccl-probe", action="store_true", help="N = 1: skip the one-rank RCCL probe (allreduce_us_1rank)")
+    ap.add_argument("--rccl-probe-only", action="store_true", help="N = 1: run only the one-rank RCCL probe and print its JSON (tests)")
     ap.add_argument("--dump-mean", default="", help="rank 0 writes the final predictive mean [E,B,C] float64 to this .npy (tests)")
     return ap.parse_args()
 
@@ -264,6 +272,87 @@ def cpu_baseline(wl, batch, T, seed):
     return batch * T / dt, best, r["mean"], sweep
 
 
+def rccl_probe_one_rank(pipe, x, T, seed, reps=50):
+    """RCCL on ONE GPU, on exactly the streams and buffers the N-GPU path uses (the only part of that path a 1-GPU box can execute):
+    a process group of one rank over backend "nccl" (= RCCL), then
+      * the float64 all-reduce of the [3, E, B, C] moment buffer issued from EACH of the in-flight side streams, timed with HIP events on
+        that stream (`allreduce_us`), and a whole eager step with the collective in it (sharding.accumulate_partitioned,
+        always_reduce) compared bit for bit with the same step without it (a sum over one rank);
+      * the same behind a hipGraph replay of the step (BatchesInFlight.predict_graphed: replay, all-reduce, finalize on the slot's stream).
+    Returns a dict (or {"error": ...}: the probe never fails the bench).  Leaves the process group destroyed."""
+    import socket
+    import torch.distributed as dist
+    from bayesnn_fpga_amd.sharding import accumulate_partitioned
+    if dist.is_initialized():
+        return {"error": "a process group is already initialised"}
+    dev = pipe.device
+    out = {}
+    try:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        t0 = time.perf_counter()
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        first = torch.zeros(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(first)                      # the communicator is created by its first collective (default stream)
+        torch.cuda.synchronize(dev)
+        out["init_plus_first_collective_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        B = x.shape[0]
+        per_stream, identical = [], True
+        for i, (e, st) in enumerate(zip(pipe.engines, pipe.streams)):
+            st = st if st is not None else torch.cuda.current_stream(dev)
+            S, S_ref = e.new_moments(B), e.new_moments(B)
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                e.accumulate(x, S_ref, 0, T, seed)
+                accumulate_partitioned(e, x, S, T, seed, always_reduce=True)        # the step with the collective behind it
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                for _ in range(5):
+                    dist.all_reduce(S_ref)
+                ev[0].record(st)
+                for _ in range(reps):
+                    dist.all_reduce(S_ref)
+                ev[1].record(st)
+            st.synchronize()
+            per_stream.append(round(ev[0].elapsed_time(ev[1]) / reps * 1e3, 2))
+            identical = identical and bool(torch.equal(S, S_ref))
+        out["allreduce_us"] = per_stream
+        out["buffer_bytes"] = int(S.numel() * 8)
+        out["eager_step_with_allreduce_equals_step_without"] = identical
+        # behind a graph replay (two submissions per slot: capture, then a replay)
+        plain = pipe.engines[0].predict(x, T, seed)
+        torch.cuda.synchronize(dev)
+        same, graph_us = True, []
+        for _ in range(2 * len(pipe.engines)):
+            r = pipe.predict_graphed(x, T, seed, group=dist.group.WORLD, always_reduce=True)
+            pipe.last_stream.synchronize()
+            same = same and all(bool(torch.equal(r[k], plain[k])) for k in ("mean", "var", "logit_mean"))
+        st = pipe.last_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        with torch.cuda.stream(st):
+            Sg = pipe.engines[0].new_moments(B)
+            ev[0].record(st)
+            for _ in range(reps):
+                dist.all_reduce(Sg)
+            ev[1].record(st)
+        st.synchronize()
+        graph_us = round(ev[0].elapsed_time(ev[1]) / reps * 1e3, 2)
+        out["graph_replay_plus_allreduce_equals_eager"] = same
+        out["allreduce_us_on_the_graph_stream"] = graph_us
+        out["backend"] = "nccl (RCCL), world_size 1"
+    except Exception as exc:           # noqa: BLE001 — measurement aid: report, never fail the bench line
+        out["error"] = f"{type(exc).__name__}: {exc}"[:300]
+    finally:
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:              # noqa: BLE001
+            pass
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` from a plain shell: start the N rank processes ourselves — fresh children through
     torch.distributed.run, one per GPU, rendezvous on 127.0.0.1 — relay their output (rank 0 prints the JSON line) and exit
@@ -324,19 +413,39 @@ def main():
     torch.manual_seed(0)
     np.random.seed(0)
     model = synthetic_weights_(_load(wl[0])(**kw), 0).to(dev).eval()
-    B, T = a.batch or wl[3], a.T or wl[4]
+    B, T = (a.batch or wl[3]) * max(a.macro, 1), a.T or wl[4]
     from bayesnn_fpga_amd.engine import BatchesInFlight
-    if a.in_flight < 1:
-        raise SystemExit("--in-flight >= 1")
-    pipe = BatchesInFlight(model, dev, n=a.in_flight, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
+    from bayesnn_fpga_amd.sharding import accumulate_share
+    if a.in_flight < 0:
+        raise SystemExit("--in-flight >= 0")
+    pipe = BatchesInFlight(model, dev, n=1, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
     eng = pipe.engines[0]
     x = synthetic_images(B, seed=1234).to(dev)
     pkind = None if a.partition == "auto" else a.partition
+    # batches in flight / hipGraph replay: by measurement of THIS rank's share of a step (before the warm-up, outside the timed region);
+    # every rank takes the slowest rank's figure, so the group decides together
+    S_probe = eng.new_moments(B)
+    probe_ms = pipe.measure_ms(lambda e: accumulate_share(e, x, S_probe, T, a.seed, 0, rank, world, pkind))
+    if dist is not None:
+        tprobe = torch.tensor([probe_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tprobe, op=dist.ReduceOp.MAX)
+        probe_ms = float(tprobe.item())
+    launch_bound = probe_ms < 1.0
+    a.in_flight = a.in_flight or (3 if launch_bound else 2)
+    a.graph = bool(a.graph or (launch_bound and not a.no_graph))
+    pipe.grow(a.in_flight)
+    del S_probe
     # ("samples", lo, hi) while T > world, else ("images", lo, hi): nobody idles (share_kind: by samples after all when an image share
     # could not start on a whole Philox call of every site)
     share = partition(T, B, rank, world, share_kind(eng, T, B, world, pkind))
     t_lo, t_hi = (share[1], share[2]) if share[0] == "samples" else (0, T)
     Ss = [e.new_moments(B) for e in pipe.engines]
+
+    if a.rccl_probe_only:
+        if world != 1:
+            raise SystemExit("--rccl-probe-only is the one-rank probe")
+        print(json.dumps(rccl_probe_one_rank(pipe, x, T, a.seed)), flush=True)
+        return
 
     def one_batch(e, S):
         S.zero_()
@@ -424,6 +533,9 @@ def main():
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
                        "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight, "hipgraph": bool(a.graph),
+                       "macro_batches": a.macro, "rank_step_probe_ms": round(probe_ms, 4),
+                       "pipe": "3 in flight + one hipGraph replay per step (launch-bound: the probed step is under 1 ms)" if launch_bound
+                               else "2 eager batches in flight (the probed step is over 1 ms)",
                        "sharding": (f"T over {world} rank(s)" if share[0] == "samples" else f"images over {world} ranks (T <= ranks)") +
                                    ", one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
@@ -501,6 +613,8 @@ def main():
                 "max_abs_mean_diff_gpu_vs_cpu": float(np.abs(gpu_same - cpu_mean).max()),
                 f"max_abs_mean_diff_gpu_{other}_vs_cpu": float(np.abs(gpu_other - cpu_mean).max()),
             }
+        if world == 1 and not a.no_rccl_probe:       # after everything timed: RCCL executed once on this GPU (SURVEY 8.5, round-4 review item 5)
+            line["allreduce_us_1rank"] = rccl_probe_one_rank(pipe, x, T, a.seed)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -261,6 +261,20 @@ int bmi_forward_mcd_images(bmi_handle h, const float* x_nchw, int32_t batch, int
                            int32_t t_count, uint64_t seed, int32_t mask_cnt0, double* S1, double* S2, double* SL,
                            void* workspace, size_t workspace_bytes, bmi_stream stream);
 
+/* Per-sample outputs of the folded path — what the reference's evaluate() consumes pass by pass (SA/train/evaluate.py:8-22 ->
+ * SA/train/train_utils.py:32-38 -> _MultiExitAccuracy._metrics, SA/train/loss/base_classes.py:39-66: the logits of every exit of every
+ * stochastic forward): samples t_begin .. t_begin+t_count-1 of the batch as in bmi_forward_mcd, and
+ *     logits[(t - t_begin)][e][b][c]   fp32 [t_count][E][batch][C]
+ * written by the fused head kernel beside the moment sums (S1 / S2 / SL as in bmi_forward_mcd), or instead of them (all three NULL).
+ * mask_stride: the Masksembles mask of sample t is (mask_cnt0 + (t - t_begin) * mask_stride) mod M — the reference's layers count
+ * their forward calls (SA/utils.py:165-169), so when its evaluate() walks a loader of n batches T times, pass i of batch k is call
+ * i * n + k: the T passes of batch k folded into ONE call here take mask_cnt0 = cnt + k, mask_stride = n.  (mask_stride = 1: the
+ * masks of bmi_forward_mcd.)  MC-dropout masks depend on the sample index t alone, as everywhere.  Captures into a hipGraph like
+ * bmi_forward_mcd. */
+int bmi_forward_mcd_samples(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_begin, int32_t t_count, uint64_t seed,
+                            int32_t mask_cnt0, int32_t mask_stride, float* logits, double* S1, double* S2, double* SL, void* workspace,
+                            size_t workspace_bytes, bmi_stream stream);
+
 /* Confidence-threshold early exiting ON the device — what the reference only models after the fact
  * (FullAnalysis.confidence_exiting / is_confident / flop_saver, SA/train/results_analyzer.py:606-630, :638-677, :725-733):
  * runs samples 0 .. t_count-1 of the batch stage by stage; after the head of exit e (first_exit <= e < n_exits-1; the

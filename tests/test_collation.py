@@ -322,3 +322,69 @@ def test_gpu_masksembles_counter_carries_across_batches():
     synthetic_weights_(o2, 0)
     restart = mcd.mcd_predict(o2, loader[1][0], T, seed=0)["mean"]
     assert np.abs(restart - want[:, B:2 * B]).max() > 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f16x2", "f16"])
+def test_gpu_folded_evaluate_against_the_reference_s_own_evaluate(dtype):
+    """tests/golden/evaluate_masksembles.npz = the reference's OWN evaluate() (SA/train/evaluate.py:8-22, nothing patched: a Masksembles
+    net is deterministic) on a 3-batch loader, T = 5, M = 4, counters starting at 2: pass i of batch k is forward call 3 i + k.  The
+    mirror's evaluate() folds the T passes of a batch into ONE engine pass (bmi_forward_mcd_samples, mask_cnt0 = cnt + k,
+    mask_stride = 3) and must give the reference's averaged metric vector — accuracies exactly (fp32-equivalent arithmetic on the split
+    engine; on fp16 a near-tie may flip one of 60 argmaxes), avg_maxprob to 1e-5 / 1e-3 — and leave the layers' counters where the
+    reference's are.  The unfolded walk (fold=False: the reference's loop order, one model(X) per call) gives the same numbers."""
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
+    from bayesnn_fpga_amd.train.evaluate import MultiExitAccuracy, evaluate
+    from tests.helpers import build_seeded, golden_kwargs, load_golden
+    g = load_golden("evaluate_masksembles.npz")
+    kw = golden_kwargs(g)
+    B, nb, T, cnt0 = int(g["B"]), int(g["nb"]), int(g["T"]), int(g["cnt0"])
+    x, y = synthetic_images(B * nb, seed=3), synthetic_labels(B * nb, 10, seed=4)
+    loader = [(x[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(nb)]
+    loss = MultiExitAccuracy(4, acc_tops=(1, 5))
+    assert loss.metric_names == [str(n) for n in g["metric_names"]]
+    want = g["averaged"]
+    for fold in (True, False):
+        m = synthetic_weights_(build_seeded(ResNet18MCEarlyExit, kw), 0).to("cuda:0").eval()
+        m.engine_dtype = dtype
+        for lay in m.mask_layers():
+            lay.cnt = cnt0
+        got = np.array(evaluate(loss, loader, m, 0, "t", T, create_log=False, fold=fold))
+        print(f"{dtype} fold={fold}: max|acc - ref| = {np.abs(got[:-1] - want[:-1]).max():.2e}, |maxprob - ref| = {abs(got[-1] - want[-1]):.2e}")
+        np.testing.assert_allclose(got[:-1], want[:-1], rtol=0, atol=1e-6 if dtype == "f16x2" else 1.0 / (B * nb * T) + 1e-6)
+        assert abs(got[-1] - want[-1]) <= (1e-5 if dtype == "f16x2" else 1e-3)
+        assert {lay.cnt for lay in m.mask_layers()} == {int(g["cnt_after"])} and m.mc_pass == T * nb
+
+
+@pytest.mark.gpu
+def test_gpu_forward_samples_equals_T_model_calls():
+    """MCDEngine.forward_samples (bmi_forward_mcd_samples): the per-sample logits [T, E, B, C] of ONE folded engine pass are bit for bit
+    what T calls of model(x) return (MC dropout: sample index t; Masksembles with stride 1: mask (cnt + t) mod M), with and without
+    the moment sums beside them, whatever the chunking; a strided mask walk equals the calls that use those masks."""
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
+    from tests.helpers import build_seeded
+    B, T = 5, 7
+    x = synthetic_images(B, seed=1234).to("cuda:0")
+    for kw in (dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10),
+               dict(dropout_exit=True, dropout="block", mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=10)):
+        m = synthetic_weights_(build_seeded(ResNet18MCEarlyExit, kw), 0).to("cuda:0").eval()
+        m.mc_seed = 11
+        calls = torch.stack([torch.stack(m(x)) for _ in range(T)])                   # [T, E, B, C], t = 0 .. T-1, masks cnt + t
+        for lay in m.mask_layers():
+            lay.cnt = 0
+        eng = m.engine(x.device, max_batch=B)                                          # the engine model(x) ran on
+        got = eng.forward_samples(x, T, seed=11)
+        assert torch.equal(got, calls), kw.get("mask_type")
+        e3 = m.engine(x.device, max_batch=B, chunk_samples=3)                          # three launches (3 + 3 + 1 samples): ANOTHER plan may pick
+        got3 = e3.forward_samples(x, T, seed=11)                                       # other kernels (K order), so: close to the first, and bit for
+        assert float((got3 - calls).abs().max()) <= 2e-3 * float(calls.abs().max())    # bit its own one-sample calls
+        for i in range(T):
+            assert torch.equal(got3[i], e3.forward_samples(x, 1, seed=11, t_begin=i)[0]), i
+        if m.mask_layers():                                                            # stride 3 from counter 1: masks 1, 0, 3, 2, 1, 0, 3
+            eng = m.engine(x.device, max_batch=B)
+            got = eng.forward_samples(x, T, seed=11, cnt0=1, mask_stride=3)
+            for i in range(T):
+                one = eng.forward_samples(x, 1, seed=11, t_begin=i, cnt0=(1 + 3 * i - i) % 4)   # (stride 1: mask (cnt0 + t) mod M at t = i)
+                assert torch.equal(got[i], one[0]), i

@@ -157,6 +157,31 @@ def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
         assert ms_lazy < 0.7 * ms_plain                  #  consumers: nothing takes keep bits there and the op runs as before)
 
 
+@pytest.mark.parametrize("name,batch,T", [("resnet18_block_exit", 250, 4), ("resnet50_block_exit", 64, 3), ("resnet18_block_exit", 8, 2)],
+                         ids=["resnet18-250", "resnet50-64", "resnet18-small-plan"])
+def test_lazy_planar_layout_is_bit_for_bit_the_nhwc_one(name, batch, T):
+    """Round-4 advisor: the lazy first site's PLANAR layout (32-channel planes, even columns in front of the odd ones: what a stride-2
+    reader DMAs is contiguous) against the same site in NHWC ("lazy_planar" 1 / 0) on the ResNet-18 and ResNet-50 block sites: equal
+    moment buffers, bit for bit.  The small plan (8 images x 2 samples: its stride-2 readers' grids are under conv3x3_s2's minimum,
+    so bmi_plan keeps the site NHWC and the readers' fallbacks read it) must agree with itself across the option too."""
+    from bayesnn_fpga_amd import _lib
+    cls, _, kw, _ = CONFIGS[name]
+    m = build_seeded(cls, kw)
+    synthetic_weights_(m, 0)
+    x = synthetic_images(batch, seed=1234).to(DEV)
+    out = {}
+    for planar in (1, 0):
+        _lib.set_option("lazy_planar", planar)
+        try:
+            eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=batch, chunk_samples=T)       # (planned under the option)
+            out[planar] = eng.accumulate(x, eng.new_moments(batch), 0, T, seed=7).clone()
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("lazy_planar", 1)
+        m._engines = {}                                    # a fresh engine (and plan) for the other arm
+    assert torch.equal(out[1], out[0]) and float(out[1][1].max()) > 0
+
+
 def test_p_one_drops_everything_like_the_reference():
     """dropout_p = 1.0 (F.dropout zeroes every element): the drop-all path of every site kernel.  Block sites zero the stage outputs, exit
     sites the pooled features: every logit is its classifier's bias, the predictive mean softmax(bias) for every image, the variance 0 —

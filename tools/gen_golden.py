@@ -245,6 +245,33 @@ def gen_masksembles():
     print("masksembles ok")
 
 
+def gen_evaluate_masksembles():
+    """The reference's OWN evaluate() (SA/train/evaluate.py:8-22: T outer passes over the loader, validate_model_acc per pass,
+    _MultiExitAccuracy._metrics per batch) on a Masksembles model — deterministic, nothing patched: its layers count their forward
+    calls, so pass i of batch k of an n-batch loader is call i * n + k and sees mask (i * n + k) mod M.  Pins the folded route's
+    mask_stride (bmi_forward_mcd_samples: the T passes of batch k in one call, masks (cnt + k + i n) mod M)."""
+    from train.evaluate import evaluate as ref_evaluate
+    kw = dict(dropout_exit=True, dropout="block", mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=10)
+    B, nb, T = 4, 3, 5                                   # 3 batches, M = 4: stride 3, the walk visits masks 0,3,2,1,0 / 1,0,3,2,1 / 2,1,0,3,2
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = synthetic_weights_(ResNet18MCEarlyExit(**kw), 0).eval()
+    x, y = synthetic_images(B * nb, seed=3), synthetic_labels(B * nb, 10, seed=4)
+    loader = [(x[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(nb)]
+    loss = _MultiExitAccuracy(4, acc_tops=(1, 5))
+    cnt0 = 2                                             # the counters do not start at 0 (a model that has been called before)
+    for m in model.modules():
+        if hasattr(m, "cnt") and hasattr(m, "masks"):
+            m.cnt = cnt0
+    with torch.no_grad():
+        avg = ref_evaluate(loss, loader, model, -1, "golden", T, create_log=False)
+    cnt_after = [int(m.cnt) for m in model.modules() if hasattr(m, "cnt") and hasattr(m, "masks")]
+    assert len(set(cnt_after)) == 1
+    np.savez_compressed(os.path.join(OUT, "evaluate_masksembles.npz"), kwargs=str(kw), B=B, nb=nb, T=T, cnt0=cnt0, cnt_after=cnt_after[0],
+                        metric_names=np.array(loss.metric_names), averaged=np.array([float(v) for v in avg]))
+    print("evaluate_masksembles", [round(float(v), 4) for v in avg], cnt_after[0])
+
+
 def gen_metrics():
     rng = np.random.RandomState(17)
     N, C = 2000, 10
@@ -450,6 +477,9 @@ if __name__ == "__main__":
         gen_converter_multi_exit()
         gen_converter_custom()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "evaluate_masksembles":
+        gen_evaluate_masksembles()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "converter_custom":
         gen_converter_custom()
         sys.exit(0)
@@ -469,6 +499,7 @@ if __name__ == "__main__":
     gen_converter_custom()
     gen_philox()
     gen_masksembles()
+    gen_evaluate_masksembles()
     gen_metrics()
     gen_confidence_exiting()
     gen_resnet()

@@ -36,15 +36,17 @@ def evaluate_route(a, wl, model, loader):
 
     n_exits = model_exits(model)
     out = {}
-    for name, defer in (("deferred_sync", True), ("per_batch_sync", False)):
+    # folded (the default since round 5): one walk over the loader, the T passes of a batch as ONE engine pass (MCDEngine.forward_samples)
+    # + one batched metric op; the two unfolded figures keep the reference's loop order (T walks, one model(X) per batch)
+    for name, defer, fold in (("folded", True, True), ("deferred_sync", True, False), ("per_batch_sync", False, False)):
         loss = MultiExitAccuracy(n_exits)
         loss.defer_host_sync = defer
-        evaluate(loss, loader, model, 0, "loop_bench", 1, create_log=False)          # warm-up
+        evaluate(loss, loader, model, 0, "loop_bench", 1 if not fold else a.evaluate, create_log=False, fold=fold)          # warm-up
         torch.cuda.synchronize()
         ts = []
         for _ in range(a.repeats):
             t0 = time.perf_counter()
-            vec = evaluate(loss, loader, model, 0, "loop_bench", a.evaluate, create_log=False)
+            vec = evaluate(loss, loader, model, 0, "loop_bench", a.evaluate, create_log=False, fold=fold)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         t = sorted(ts)[len(ts) // 2]

@@ -30,17 +30,20 @@ def main():
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--in-flight", type=int, default=2)
+    ap.add_argument("--macro", type=int, default=1, help="loader batches carried by one step (a macro-batch of macro x 250 images): config 4's "
+                                                        "share of eight is 31 images x 8 masks per 250-image batch — too little work per rank")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     wl = bench.WORKLOADS[a.workload]
     torch.manual_seed(0)
     np.random.seed(0)
     model = synthetic_weights_(bench._load(wl[0])(**wl[2]), 0).to(dev).eval()
-    B, T = wl[3], a.T or wl[4]
+    B, T = wl[3] * a.macro, a.T or wl[4]
     x = synthetic_images(B, seed=1234).to(dev)
     res = {}
-    for kind in ("samples", "images"):
-        k, lo, hi = partition(T, B, 0, a.world, kind)
+    cases = [(kind, a.world) for kind in ("samples", "images")] + [("samples", 1)]      # (.., 1): the whole step on one GPU, the ratio's numerator
+    for kind, world in cases:
+        k, lo, hi = partition(T, B, 0, world, kind)
         if hi <= lo:
             continue
         for mode in ("eager", "graph"):
@@ -52,7 +55,7 @@ def main():
 
                 def run(e):
                     Ss[i].zero_()
-                    accumulate_share(e, x, Ss[i], T, 42, 0, 0, a.world, kind)
+                    accumulate_share(e, x, Ss[i], T, 42, 0, 0, world, kind)
                     return e.finalize(Ss[i], T)
                 return pipe.submit(run)
 
@@ -65,12 +68,12 @@ def main():
                 st = pipe.streams[i] or torch.cuda.current_stream(dev)
                 if i not in graphs:
                     with torch.cuda.stream(st):
-                        accumulate_share(e, x, Ss[i], T, 42, 0, 0, a.world, kind)
+                        accumulate_share(e, x, Ss[i], T, 42, 0, 0, world, kind)
                     st.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=st):
                         Ss[i].zero_()
-                        accumulate_share(e, x, Ss[i], T, 42, 0, 0, a.world, kind)
+                        accumulate_share(e, x, Ss[i], T, 42, 0, 0, world, kind)
                     graphs[i] = g
                 with torch.cuda.stream(st):
                     graphs[i].replay()
@@ -85,11 +88,15 @@ def main():
                 step()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / a.steps * 1e3
-            res[f"{kind}_{mode}"] = round(ms, 4)
-            print(f"{a.workload} world={a.world} rank 0: {kind} [{lo},{hi}) of T={T} B={B}  {mode:5}  {ms:.4f} ms per step", flush=True)
+            res[f"{kind}_{mode}" if world > 1 else f"whole_{mode}"] = round(ms, 4)
+            print(f"{a.workload} world={world} rank 0: {kind} [{lo},{hi}) of T={T} B={B}  {mode:5}  {ms:.4f} ms per step", flush=True)
             del pipe, Ss, graphs
             torch.cuda.empty_cache()
-    print(json.dumps({"workload": a.workload, "world": a.world, "T": T, "batch": B, "in_flight": a.in_flight, "steps": a.steps, "ms_per_step": res}))
+    best = min(v for k, v in res.items() if not k.startswith("whole"))
+    whole = min(v for k, v in res.items() if k.startswith("whole"))
+    print(json.dumps({"workload": a.workload, "world": a.world, "T": T, "batch": B, "macro_batches": a.macro, "in_flight": a.in_flight, "steps": a.steps,
+                      "ms_per_step": res, "implied_ratio_before_allreduce": round(whole / best, 2),
+                      "note": "whole_* = the same macro-batch on ONE rank; ratio = whole / the fastest share of rank 0 (no collective in either)"}))
 
 
 if __name__ == "__main__":
