@@ -325,38 +325,59 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 #undef SP_KOFF
 #undef SP_PRIO
 
-    // ---- epilogue: this lane's pixel of each pixel tile, the quads of each channel tile (fp32 in and out) ----
+    // ---- epilogue, coalesced through LDS (the stages are dead: every wave is behind the loop's last barrier) ---------------------------
+    // Straight from the accumulators a lane owns 4 channels of 32 different pixels: 16-byte stores 4 Cout bytes apart, and as many
+    // scattered residual loads (rocprofv3 WRITE_SIZE: 2.0x the tensor on the Cout = 128 launches).  Instead, in two rounds (pixel tile
+    // j = 0, 1 of every wave: 128 of the tile's pixels x all CT channels = CT / 2 KB of fp32): the raw accumulators go to LDS as
+    // [pixel][channel] rows (16-byte chunk c of pixel row p at c ^ (p & 31 & (chunks - 1)): conflict-free both ways), then consecutive
+    // lanes take consecutive chunks of a row — folded BN, site, residual, ReLU on the quad (epilogue_quad_f32: arithmetic and order of
+    // every other conv kernel) and whole contiguous rows to and from HBM.  The second phase is a ROLLED loop (it does not touch the
+    // accumulators, so nothing lands in scratch) — the site arithmetic is compiled once instead of 8 TI times.
     float* const out = (float*)a.out;
     const float* const res = (const float*)a.res;
-    // (one instantiation per pixel tile j, not a loop: hipcc gives up unrolling 2 x TI x 4 copies of the site arithmetic, and a loop
-    //  that stays rolled indexes the accumulators dynamically — they then live in scratch for the whole kernel)
-    auto finish = [&](auto jc) {
+    constexpr int CHUNKS = CT / 4;                             // 16-byte chunks per pixel row
+    constexpr int ROWB = CT * 4;                               // bytes per row
+    static_assert(128 * ROWB <= (int)sizeof(smem), "one round's tile fits the dead stages");
+    auto round = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const int m_o = pix0 + wp * 64 + 32 * j + r;
-        const bool vo = m_o < a.M;
-        const int m_c = vo ? m_o : 0;
-        const int n = m_c / HoWo, rem = m_c - n * HoWo;
-        PixelCtx p;
-        p.out_off = ((size_t)n * HoWo + rem) * a.Cout;
-        p.resp = nullptr;
-        const int tl = n / a.B;
-        p.b = n - tl * a.B;
-        p.t = a.t0 + tl;
-        p.e_pix = p.b * HoWo + rem;
-        p.mrow = a.site.kind == BMI_SITE_MASKSEMBLE ? a.site.masks + (size_t)((a.site.cnt0 + p.t) % a.site.num_masks) * a.Cout : nullptr;
-        const float* resp = res ? res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout : nullptr;
+        __syncthreads();                                       // the previous round's rows have been read
+        {
+            const int pl = wp * 32 + r;                        // this lane's pixel among the round's 128
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c4 = ch0 + wc * 32 * TI + 32 * i + 8 * q + 4 * kq;
-                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                epilogue_quad_f32(a, p, resp, v, c4);
-                if (vo) *(f32x4_s*)(out + p.out_off + c4) = f32x4_s{v[0], v[1], v[2], v[3]};
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const int chunk = (wc * 32 * TI + 32 * i + 8 * q + 4 * kq) >> 2;
+                    *(f32x4_s*)(smem + pl * ROWB + ((chunk ^ (pl & 31 & (CHUNKS - 1))) << 4)) =
+                        f32x4_s{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int it = 0; it < 128 * CHUNKS / 512; ++it) {
+            const int qi = tid + 512 * it, pl = qi / CHUNKS, chunk = qi - pl * CHUNKS;
+            const int m_o = pix0 + (pl >> 5) * 64 + 32 * j + (pl & 31);
+            if (m_o >= a.M) continue;
+            const f32x4_s raw = *(const f32x4_s*)(smem + pl * ROWB + ((chunk ^ (pl & 31 & (CHUNKS - 1))) << 4));
+            const int n = m_o / HoWo, rem = m_o - n * HoWo;
+            PixelCtx p;
+            p.out_off = ((size_t)n * HoWo + rem) * a.Cout;
+            p.resp = nullptr;
+            const int tl = n / a.B;
+            p.b = n - tl * a.B;
+            p.t = a.t0 + tl;
+            p.e_pix = p.b * HoWo + rem;
+            p.mrow = a.site.kind == BMI_SITE_MASKSEMBLE ? a.site.masks + (size_t)((a.site.cnt0 + p.t) % a.site.num_masks) * a.Cout : nullptr;
+            const float* resp = res ? res + ((size_t)(n % a.res_mod) * HoWo + rem) * a.Cout : nullptr;
+            const int c4 = ch0 + 4 * chunk;
+            float v[4] = {raw[0], raw[1], raw[2], raw[3]};
+            epilogue_quad_f32(a, p, resp, v, c4);
+            *(f32x4_s*)(out + p.out_off + c4) = f32x4_s{v[0], v[1], v[2], v[3]};
+        }
     };
-    finish(std::integral_constant<int, 0>{});
-    finish(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last K-steps' (unused) weight DMA must land BEFORE the rows overwrite its slot
+    round(std::integral_constant<int, 0>{});
+    round(std::integral_constant<int, 1>{});
 }
 
 template <bool BF>
