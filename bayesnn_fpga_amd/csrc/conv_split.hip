@@ -110,6 +110,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const int q0 = 512 * i + (TI == 1 ? 256 * (wave >> 2) : 0), plane = q0 / (4 * CT), row0 = (q0 - plane * 4 * CT) >> 2;
         wbase[i] = (const char*)(a.wgt + ((size_t)plane * a.Cout + ch0 + row0) * Ktot);
     }
+#define SP_ISSUE_W1(I, KOFF, ST) SP_GLDS16S(woff_l, wbase[I] + 2 * (KOFF), (ST) + ((I) * 512 + wave * 64) * 16)
 #if SP_ABL_NOW                  // timing probe (wrong results): every K-step fetches the weights of K-step 0
 #define SP_ISSUE_W(KOFF, ST)                                                                             \
     _Pragma("unroll") for (int i = 0; i < TI; ++i) SP_GLDS16S(woff_l, wbase[i], (ST) + (i * 512 + wave * 64) * 16);
@@ -140,20 +141,21 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     // after the split of K-step ks + 1 has read it, and stay in flight for a whole K-step.
     struct XRegs { f32x4_s v[2][2]; };
     XRegs xa;
-    auto load_x = [&](XRegs& R, int ky, int kx, int c0) {
+    auto load_x_item = [&](XRegs& R, int i, int ky, int kx, int c0) {
         const long soff = (long)(ky * a.W + kx) * a.Cin + min(c0, a.Cin - 32);        // wave-uniform (c0 = Cin: past the last K-step)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool ok = (unsigned)(iy0[i] + ky) < (unsigned)a.H && (unsigned)(ix0[i] + kx) < (unsigned)a.W;
-            // (a select between two addresses, not a branch: a branch splits the K loop into basic blocks and hipcc then waits
-            //  vmcnt(0) where a counted wait would do)
-            const float* p_ = ok ? xorg[i] + soff : g_split_zero;
+        const bool ok = (unsigned)(iy0[i] + ky) < (unsigned)a.H && (unsigned)(ix0[i] + kx) < (unsigned)a.W;
+        // (a select between two addresses, not a branch: a branch splits the K loop into basic blocks and hipcc then waits
+        //  vmcnt(0) where a counted wait would do)
+        const float* p_ = ok ? xorg[i] + soff : g_split_zero;
 #if SP_ABL_NOX                  // timing probe (wrong results): every K-step fetches the page of zeros (an L1 hit)
-            p_ = g_split_zero;
+        p_ = g_split_zero;
 #endif
-            R.v[i][0] = *(const f32x4_s*)p_;
-            R.v[i][1] = *(const f32x4_s*)(p_ + 4);
-        }
+        R.v[i][0] = *(const f32x4_s*)p_;
+        R.v[i][1] = *(const f32x4_s*)(p_ + 4);
+    };
+    auto load_x = [&](XRegs& R, int ky, int kx, int c0) {
+        load_x_item(R, 0, ky, kx, c0);
+        load_x_item(R, 1, ky, kx, c0);
     };
     auto write_x = [&](const XRegs& R, char* st) {
 #pragma unroll
@@ -190,14 +192,21 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
             bl[j] = *(const half8_t*)((XS) + XPL + b_off + j * 32 * 64 + coff);                          \
         }                                                                                                \
     }
-#define SP_MFMA()                                                                                        \
-    {                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16<BF>(al[i], bh[j], acc[i][j]);  \
-        _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16<BF>(ah[i], bl[j], acc[i][j]);  \
-        _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16<BF>(ah[i], bh[j], acc[i][j]);  \
+    // the 6 TI MFMAs of a sub-step in NG groups, HOOK(g) behind group g: the staging work that needs no LDS result — the weight DMA's
+    // issue, the input fetches' address arithmetic and loads — rides in the MFMA parts, in the issue slots the matrix pipe leaves free
+    // (an MFMA holds the SIMD's issue port for 8 of its 32 cycles), instead of lengthening the LOAD parts: those ran ~900 cycles
+    // against 768 of MFMA at TI = 4 (12 fragment reads + four DMA pieces at 100-185 cycles each inside a phase that also reads LDS,
+    // MI355X_MICROARCH.md).  The scheduler is fenced around every hook, so the order below is the order issued.
+    constexpr int NG = TI == 4 ? 4 : 2, GS = 6 * TI / NG;
+#define SP_MFMA(HOOK)                                                                                    \
+    _Pragma("unroll") for (int m = 0; m < 6 * TI; ++m) {                                                 \
+        const int pr = m / (2 * TI), rm = m - pr * 2 * TI, i = rm >> 1, j = rm & 1;                      \
+        acc[i][j] = mfma_32x32x16<BF>(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j]);      \
+        if ((m + 1) % GS == 0) {                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            HOOK((m + 1) / GS - 1);                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
     }
     // raw s_barrier with the scheduler fenced off on both sides (a __syncthreads() would drain the fetches in flight: vmcnt(0))
 // (no s_setprio around the MFMA parts: with the partner wave prioritised, the VALU-heavy LOAD parts — split, address arithmetic — issue at
@@ -288,37 +297,46 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const char* const xs = smem + (ks & 1) * XST;
         char* const nxs = smem + ((ks & 1) ^ 1) * XST;
         wslot = wslot + 1 == NW ? 0 : wslot + 1;              // slot of K-step ks + 1
-        // LOAD(0)
+        char* const wnext = smem + (NW == 2 ? wslot : (wslot + 1 == NW ? 0 : wslot + 1)) * WSLOT;   // NW = 2: K-step ks + 1's slot; NW = 3: K-step ks + 2's
+        const int koff1 = SP_KOFF();                         // (ky, kx, c0) = K-step ks + 1 until MFMA(1)'s first hook
+        // LOAD(0): the sub-step's fragments
         SP_READ(ws, xs, 0);
-        if constexpr (NW == 2) { SP_ISSUE_W(SP_KOFF(), smem + wslot * WSLOT); }   // K-step ks + 1
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SP_BARRIER();
-        // MFMA(0)
+        // MFMA(0); NW = 2 (TI = 4): K-step ks + 1's weight DMA, one piece behind each group of six MFMAs
+#define SP_HOOK0(G) { if constexpr (NW == 2) { SP_ISSUE_W1(G, koff1, wnext); } }
         SP_PRIO(1);
-        SP_MFMA();
+        SP_MFMA(SP_HOOK0);
         SP_PRIO(0);
+#undef SP_HOOK0
         SP_BARRIER();
-        // LOAD(1)
+        // LOAD(1): fragments; then the input of K-step ks + 1 — fetched in MFMA(1) of K-step ks - 1, three intervals ago — is split and written.
+        // vmcnt(0): xa's fetches (hipcc waits for them too) and every weight DMA issued so far (which it does not know): NW = 2:
+        // K-step ks + 1's, issued in the interval before; NW = 3: K-step ks + 1's, issued a whole K-step ago
         SP_READ(ws, xs, 1);
-        // xa's fetches (hipcc waits for them too) and every weight DMA issued so far (which it does not know): NW = 2: K-step ks + 1's,
-        // issued two intervals ago; NW = 3: K-step ks + 1's, issued a whole K-step ago right behind xa's fetches
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         write_x(xa, nxs);
-        advance();                                           // -> K-step ks + 2
-        load_x(xa, ky, kx, c0);
-        if constexpr (NW == 3) {                             // K-step ks + 2's weights -> the slot K-step ks - 1 used (free since interval 4 ks - 1)
-            SP_ISSUE_W(SP_KOFF(), smem + (wslot + 1 == NW ? 0 : wslot + 1) * WSLOT);
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SP_BARRIER();
-        // MFMA(1)
+        // MFMA(1); the fetches of K-step ks + 2 into the registers the split has just read (and, NW = 3, its weight DMA into the slot
+        // K-step ks - 1 used, free since interval 4 ks - 1) behind the first groups
+#define SP_HOOK1(G)                                                                                      \
+    {                                                                                                    \
+        if ((G) == 0) { advance(); load_x_item(xa, 0, ky, kx, c0); }                                     \
+        if ((G) == 1) {                                                                                  \
+            load_x_item(xa, 1, ky, kx, c0);                                                              \
+            if constexpr (NW == 3) { SP_ISSUE_W(SP_KOFF(), wnext); }                                     \
+        }                                                                                                \
+    }
         SP_PRIO(1);
-        SP_MFMA();
+        SP_MFMA(SP_HOOK1);
         SP_PRIO(0);
+#undef SP_HOOK1
         SP_BARRIER();
     }
     if (g == 0) SP_BARRIER();
 #undef SP_ISSUE_W
+#undef SP_ISSUE_W1
 #undef SP_READ
 #undef SP_MFMA
 #undef SP_BARRIER
