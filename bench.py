@@ -548,15 +548,19 @@ def main():
         # that bounds it: algorithmic FLOPs (or bytes) per launch / its average launch duration, HIP events on the launch
         # stream.  `all_conv_launches` is the same for every conv launch together, `by_kernel` per family.
         fam = eng.conv_families
+        # the split engines' kernel issues THREE MFMA instructions per algorithmic product (w_lo.x_hi + w_hi.x_lo + w_hi.x_hi): its MFMA
+        # roofline in algorithmic FLOPs is a third of the dense peak (`achieved` stays algorithmic, `mfma_work_factor` says so)
+        wf = lambda k: 3.0 if k == "conv_split_kernel" else 1.0
         by_kernel = {k: {"launches": int(v["launches"]), "avg_launch_ms": round(v["ms"] / v["launches"], 4),
                          "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                         "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                         "mfma_work_factor": wf(k), "peak_algorithmic_tflops": round(MFMA_PEAK_TFLOPS / wf(k), 1),
+                         "frac": round(wf(k) * v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                          "hbm_gbs_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                          "hbm_frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "flop_per_byte": round(v["flops"] / max(v["bytes"], 1.0), 1),
                          "algorithmic_flops_per_launch": round(v["flops"] / v["launches"]),
                          "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]),
-                         "bound": "mfma" if v["flops"] / MFMA_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_GBS / 1e9 else "hbm",
+                         "bound": "mfma" if wf(k) * v["flops"] / MFMA_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_GBS / 1e9 else "hbm",
                          **(pmc_sq(a.workload, k) if traffic is not None else {})}
                      for k, v in fam.items()}
         dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
@@ -567,7 +571,7 @@ def main():
             # the same family in the committed rocprofv3 summary of this command: its kernel's name as rocprof prints it, and the
             # roofline fraction its average duration gives (the live HIP-event `frac` of THIS box beside it: boxes differ by 2-3 %)
             rp = rocprof_family(a.workload, dom, d["launches"]) if (world == 1 and not a.batch and not a.T and not a.chunk and a.dtype == "f16") else None
-            per_launch = d["algorithmic_bytes_per_launch"] / 1e9 if hbm_bound else d["algorithmic_flops_per_launch"] / 1e12
+            per_launch = d["algorithmic_bytes_per_launch"] / 1e9 if hbm_bound else d["mfma_work_factor"] * d["algorithmic_flops_per_launch"] / 1e12
             line["roofline"] = {
                 "bound": d["bound"], "kernel": rp[0] if rp else dom, "kernel_family": dom,
                 "frac_rocprof": None if rp is None else round(per_launch / (rp[1] * 1e-3) / (HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS), 4),
@@ -575,7 +579,7 @@ def main():
                 "dominant_by": "hip_event_ms (the conv family with the most device time in the profiled step; "
                                                                    "quote whole_step.frac when comparing rounds)",
                 "achieved": d["hbm_gbs_algorithmic"] if hbm_bound else d["achieved"],
-                "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "peak": HBM_PEAK_GBS if hbm_bound else d["peak_algorithmic_tflops"], "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": d["hbm_frac"] if hbm_bound else d["frac"],
                 "traffic": None if dom_traffic is None else round(dom_traffic),
                 "traffic_unit": "fabric bytes per launch = L2 misses, Infinity-Cache hits included (PMC FETCH_SIZE x2 + WRITE_SIZE): an upper bound of the HBM bytes", "traffic_source": traffic_src,
