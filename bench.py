@@ -353,6 +353,30 @@ def rccl_probe_one_rank(pipe, x, T, seed, reps=50):
     return out
 
 
+def rccl_probe_in_a_child(a, timeout=240):
+    """The one-rank RCCL probe in a CHILD process (`bench.py --rccl-probe-only`, an ordinary subprocess: this process keeps running and
+    never re-execs itself): a communicator that hangs or dies at start-up or tear-down costs the bench line `timeout` seconds and an
+    {"error": ...} entry, never the line itself."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--rccl-probe-only", "--workload", a.workload, "--in-flight", str(a.in_flight),
+           "--dtype", a.dtype, "--seed", str(a.seed), "--macro", str(a.macro)]
+    for flag, val in (("--batch", a.batch), ("--T", a.T), ("--chunk", a.chunk)):
+        if val:
+            cmd += [flag, str(val)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"probe child exited with {r.returncode}: {r.stderr[-200:]}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"probe child did not finish within {timeout} s"}
+    except Exception as exc:           # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` from a plain shell: start the N rank processes ourselves — fresh children through
     torch.distributed.run, one per GPU, rendezvous on 127.0.0.1 — relay their output (rank 0 prints the JSON line) and exit
@@ -425,6 +449,22 @@ def main():
     # batches in flight / hipGraph replay: by measurement of THIS rank's share of a step (before the warm-up, outside the timed region);
     # every rank takes the slowest rank's figure, so the group decides together
     S_probe = eng.new_moments(B)
+    partition_probe = None
+    if dist is not None and pkind is None:
+        # --partition auto with several ranks: both splits a rank can take are timed (this rank's share, no collective) and the group
+        # takes the one whose SLOWEST rank is faster — on one MI355X rank 0's share of eight at T = 100 measures 2.98 ms by samples and
+        # 2.78 ms by images (profiles/r05_share_config4.txt); which wins depends on T, B and the rank count, so it is measured, not assumed
+        from bayesnn_fpga_amd.sharding import shard_range
+        cands = [k for k in ("samples", "images")
+                 if (k == "samples" and T >= world) or (k == "images" and B >= world and all(eng.image_offset_ok(shard_range(B, r, world)[0]) for r in range(world)))]
+        if len(cands) == 2:
+            ms = [pipe.measure_ms(lambda e, k=k: accumulate_share(e, x, S_probe.zero_(), T, a.seed, 0, rank, world, k)) for k in cands]
+            tp = torch.tensor(ms, dtype=torch.float64, device=dev)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            partition_probe = {k: round(float(v), 4) for k, v in zip(cands, tp.tolist())}
+            pkind = min(partition_probe, key=partition_probe.get)
+        elif cands:
+            pkind = cands[0]
     probe_ms = pipe.measure_ms(lambda e: accumulate_share(e, x, S_probe, T, a.seed, 0, rank, world, pkind))
     if dist is not None:
         tprobe = torch.tensor([probe_ms], dtype=torch.float64, device=dev)
@@ -533,7 +573,7 @@ def main():
             "config": {"workload": wl[5],
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
                        "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight, "hipgraph": bool(a.graph),
-                       "macro_batches": a.macro, "rank_step_probe_ms": round(probe_ms, 4),
+                       "macro_batches": a.macro, "rank_step_probe_ms": round(probe_ms, 4), "partition_probe_ms": partition_probe,
                        "pipe": "3 in flight + one hipGraph replay per step (launch-bound: the probed step is under 1 ms)" if launch_bound
                                else "2 eager batches in flight (the probed step is over 1 ms)",
                        "sharding": (f"T over {world} rank(s)" if share[0] == "samples" else f"images over {world} ranks (T <= ranks)") +
@@ -618,7 +658,7 @@ def main():
                 f"max_abs_mean_diff_gpu_{other}_vs_cpu": float(np.abs(gpu_other - cpu_mean).max()),
             }
         if world == 1 and not a.no_rccl_probe:       # after everything timed: RCCL executed once on this GPU (SURVEY 8.5, round-4 review item 5)
-            line["allreduce_us_1rank"] = rccl_probe_one_rank(pipe, x, T, a.seed)
+            line["allreduce_us_1rank"] = rccl_probe_in_a_child(a)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

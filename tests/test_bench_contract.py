@@ -172,7 +172,10 @@ def test_graphed_share_on_the_sharded_path(tmp_path):
     common = ["--workload", "resnet18_masksembles", "--T", "2", "--batch", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     fs = []
-    for n, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu"]), (2, ["--backend", "gloo", "--share-gpu", "--graph"]),
+    # (--partition is explicit in every two-rank arm: left on auto, bench.py times both splits and takes the faster — a choice two runs
+    #  may make differently, and the pairs below are compared bit for bit)
+    for n, extra in ((1, []), (2, ["--backend", "gloo", "--share-gpu", "--partition", "images"]),
+                     (2, ["--backend", "gloo", "--share-gpu", "--partition", "images", "--graph"]),
                      (2, ["--backend", "gloo", "--share-gpu", "--partition", "samples"]),
                      (2, ["--backend", "gloo", "--share-gpu", "--partition", "samples", "--graph"])):
         f = str(tmp_path / f"m{len(fs)}.npy")

@@ -311,3 +311,22 @@ def test_split_engine_repeats_bit_for_bit(dt):
     for _ in range(4):
         again = eng.accumulate(x, eng.new_moments(250), 0, 3, seed=9)
         assert torch.equal(again, first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f16x2", "bf16x3"])
+def test_split_engine_resnet50_multi_exit(dt):
+    """BASELINE configs[4]'s model (Bottleneck blocks: 1x1 convs with 64-2048 channels, every channel-tile width of the split kernel)
+    against the build's fp32 oracle: the fp16 engine sits at 7.7e-4 of the 1e-3 bar there (tests/test_full_batch.py)."""
+    B, T, seed = 32, 2, 42
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    m, o = build_seeded(bx.ResNet50MCEarlyExit, kw), build_seeded(ox.ResNet50MCEarlyExit, kw)
+    synthetic_weights_(m, 0)
+    synthetic_weights_(o, 0)
+    x = synthetic_images(B, seed=1234)
+    ref = mcd.mcd_predict(o, x, T, seed)
+    r = _on(m, dt).engine(torch.device(DEV), max_batch=B, dtype=dt).predict(x.to(DEV), T, seed=seed)
+    err_m = float(np.abs(r["mean"].cpu().numpy() - ref["mean"]).max())
+    err_v = float(np.abs(r["var"].cpu().numpy() - ref["var"]).max())
+    print(f"ResNet-50 multi-exit {dt}: B={B} T={T} max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
+    assert err_m <= 5 * TOLS[dt]["prob"] and err_v <= 5 * TOLS[dt]["prob"]
