@@ -25,6 +25,35 @@ __device__ __forceinline__ _Float16 a16_from_f32(float v) {
 }
 typedef float f32x4_m __attribute__((ext_vector_type(4)));
 typedef float f32x16_m __attribute__((ext_vector_type(16)));
+
+// ---- "pair32": how the SPLIT engines (BMI_DTYPE_F16X2 / BF16X3) keep an activation tensor in the workspace -------------------------
+// Every element is a 16-bit head and tail, v = hi + lo (hi = rn16(v), lo = rn16(v - hi)) — the operand form conv_split.hip multiplies —
+// stored per pixel in 32-channel blocks [hi x 32 | lo x 32]: element (pixel, c) has its head at 16-bit index
+//     pixel * 2 C + (c >> 5) * 64 + (c & 31)          and its tail 32 further,
+// 4 bytes per element like fp32, and a K-step's operand (one pixel, 32 channels, both halves) is ONE contiguous 128-byte line: the conv
+// fetches it by LDS-DMA, nothing is split in the consumer (the producer encodes once what nine taps and every channel tile would
+// otherwise split again).  C % 32 == 0.
+__host__ __device__ inline size_t pair32_off(size_t pixel, int C, int c) { return pixel * 2 * (size_t)C + (size_t)(c >> 5) * 64 + (c & 31); }
+typedef _Float16 half4_p __attribute__((ext_vector_type(4)));
+template <bool BF, int N>     // N = 4 | 8 consecutive channels inside one 32-block; p = address of the first head
+__device__ __forceinline__ void pair_decode(const _Float16* p, float v[N]) {
+    typedef _Float16 hv __attribute__((ext_vector_type(N)));
+    const hv hi = *(const hv*)p, lo = *(const hv*)(p + 32);
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = a16_to_f32<BF>(hi[e]) + a16_to_f32<BF>(lo[e]);
+}
+template <bool BF, int N>
+__device__ __forceinline__ void pair_encode(_Float16* p, const float v[N]) {
+    typedef _Float16 hv __attribute__((ext_vector_type(N)));
+    hv hi, lo;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        hi[e] = a16_from_f32<BF>(v[e]);
+        lo[e] = a16_from_f32<BF>(v[e] - a16_to_f32<BF>(hi[e]));
+    }
+    *(hv*)p = hi;
+    *(hv*)(p + 32) = lo;
+}
 template <bool BF>
 __device__ __forceinline__ f32x4_m mfma_16x16x32(half8_t a, half8_t b, f32x4_m c) {
     if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);

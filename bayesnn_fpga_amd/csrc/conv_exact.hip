@@ -117,6 +117,8 @@ int launch_conv_exact(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // stand-alone site on an fp32 tensor (mask_apply_kernel's arithmetic: MCDropout / Masksembles2D on a stage output, or the
 // mask + BN shift + ReLU half of a deterministic conv with an inner site)
+// PAIR = 0: fp32 tensors; 1 | 2: pair32 tensors (conv_epilogue.h) of fp16 | bf16 halves — the split engines
+template <int PAIR>
 __global__ __launch_bounds__(256) void mask_apply_f32_kernel(EltArgs a) {
     const float* const in = (const float*)a.in;
     float* const out = (float*)a.out;
@@ -129,9 +131,15 @@ __global__ __launch_bounds__(256) void mask_apply_f32_kernel(EltArgs a) {
         const int p = (int)(pix - (long)n * a.HW);
         const int tl = n / a.B, b = n - tl * a.B;
         const int t = a.t0 + tl;
-        const float* src = in + ((size_t)(n % a.in_mod) * a.HW + p) * a.C + c8;
-        const f32x4_x x0 = *(const f32x4_x*)src, x1 = *(const f32x4_x*)(src + 4);
-        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        float v[8];
+        if constexpr (PAIR == 0) {
+            const float* src = in + ((size_t)(n % a.in_mod) * a.HW + p) * a.C + c8;
+            const f32x4_x x0 = *(const f32x4_x*)src, x1 = *(const f32x4_x*)(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+        } else {
+            pair_decode<PAIR == 2, 8>((const _Float16*)a.in + pair32_off((size_t)(n % a.in_mod) * a.HW + p, a.C, c8), v);
+        }
         const uint64_t elem0 = a.site.kind == BMI_SITE_CHANNEL ? (uint64_t)b * a.C + c8 : ((uint64_t)b * a.HW + p) * a.C + c8;
         if (a.site.kind == BMI_SITE_ELEMENTWISE || a.site.kind == BMI_SITE_CHANNEL) {
             const uint32_t keep = site_keep8(a.site, elem0, (uint32_t)t);
@@ -150,18 +158,24 @@ __global__ __launch_bounds__(256) void mask_apply_f32_kernel(EltArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        float* dst = out + ((size_t)n * a.HW + p) * a.C + c8;
-        *(f32x4_x*)dst = f32x4_x{v[0], v[1], v[2], v[3]};
-        *(f32x4_x*)(dst + 4) = f32x4_x{v[4], v[5], v[6], v[7]};
+        if constexpr (PAIR == 0) {
+            float* dst = out + ((size_t)n * a.HW + p) * a.C + c8;
+            *(f32x4_x*)dst = f32x4_x{v[0], v[1], v[2], v[3]};
+            *(f32x4_x*)(dst + 4) = f32x4_x{v[4], v[5], v[6], v[7]};
+        } else {
+            pair_encode<PAIR == 2, 8>((_Float16*)a.out + pair32_off((size_t)n * a.HW + p, a.C, c8), v);
+        }
     }
 }
 
 int launch_mask_apply_f32(const EltArgs& a, hipStream_t s) {
-    if (a.C % 8 != 0) return BMI_ERR_UNSUPPORTED;
+    if (a.C % 8 != 0 || (a.pair && a.C % 32 != 0)) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
     long blocks = ((long)a.N * a.HW * (a.C >> 3) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(mask_apply_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.pair == 1) hipLaunchKernelGGL(mask_apply_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (a.pair == 2) hipLaunchKernelGGL(mask_apply_f32_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mask_apply_f32_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }
@@ -185,13 +199,38 @@ __global__ __launch_bounds__(256) void maxpool2_f32_kernel(const float* in, floa
     }
 }
 
-int launch_maxpool2_f32(const float* in, float* out, int n, int h, int w, int c, hipStream_t s) {
-    if (c % 4 != 0 || (h & 1) || (w & 1)) return BMI_ERR_UNSUPPORTED;
-    const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+// pair32 tensors: the maximum of the four decoded values, re-encoded (it IS one of the four pairs' value, so the encoding is exact again)
+template <bool BF>
+__global__ __launch_bounds__(256) void maxpool2_pair_kernel(const _Float16* in, _Float16* out, int N, int H, int W, int C) {
+    const int cg = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg) * 8;
+        long q = i / cg;
+        const int ox = (int)(q % Wo); q /= Wo;
+        const int oy = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        const size_t p00 = ((size_t)n * H + 2 * oy) * W + 2 * ox;
+        float a0[8], a1[8], a2[8], a3[8], o[8];
+        pair_decode<BF, 8>(in + pair32_off(p00, C, c8), a0);
+        pair_decode<BF, 8>(in + pair32_off(p00 + 1, C, c8), a1);
+        pair_decode<BF, 8>(in + pair32_off(p00 + W, C, c8), a2);
+        pair_decode<BF, 8>(in + pair32_off(p00 + W + 1, C, c8), a3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaxf(fmaxf(a0[e], a1[e]), fmaxf(a2[e], a3[e]));
+        pair_encode<BF, 8>(out + pair32_off(((size_t)n * Ho + oy) * Wo + ox, C, c8), o);
+    }
+}
+
+int launch_maxpool2_f32(const float* in, float* out, int n, int h, int w, int c, hipStream_t s, int pair) {
+    if (c % 4 != 0 || (h & 1) || (w & 1) || (pair && c % 32 != 0)) return BMI_ERR_UNSUPPORTED;
+    const long total = (long)n * (h / 2) * (w / 2) * (c / (pair ? 8 : 4));
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks <= 0) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL(maxpool2_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n, h, w, c);
+    if (pair == 1) hipLaunchKernelGGL(maxpool2_pair_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16*)in, (_Float16*)out, n, h, w, c);
+    else if (pair == 2) hipLaunchKernelGGL(maxpool2_pair_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16*)in, (_Float16*)out, n, h, w, c);
+    else hipLaunchKernelGGL(maxpool2_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n, h, w, c);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     // products first (lo . hi, hi . lo), then hi . hi
     half8_t ah[TI], al[TI], bh[2], bl[2];
 #define SP_READ(WS, XS, SS)                                                                              \
-    {                                                                                                    \
+    if (!SP_ABL_NOREAD || ks == 0) {                                                                     \
         const int coff = ((2 * (SS) + kq) ^ sw) << 4;                                                    \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                 \
             ah[i] = *(const half8_t*)((WS) + a_off + i * 32 * 64 + coff);                                \
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 #define SP_MFMA(HOOK)                                                                                    \
     _Pragma("unroll") for (int m = 0; m < 6 * TI; ++m) {                                                 \
         const int pr = m / (2 * TI), rm = m - pr * 2 * TI, i = rm >> 1, j = rm & 1;                      \
-        acc[i][j] = mfma_32x32x16<BF>(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j]);      \
+        if (!SP_ABL_NOMFMA || m == 0) acc[i][j] = mfma_32x32x16<BF>(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j]);      \
         if ((m + 1) % GS == 0) {                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             HOOK((m + 1) / GS - 1);                                                                      \
@@ -212,6 +212,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 // (no s_setprio around the MFMA parts: with the partner wave prioritised, the VALU-heavy LOAD parts — split, address arithmetic — issue at
 // a fraction of their rate, MI355X_MICROARCH.md 'Two waves per SIMD' item 2; -DSP_SETPRIO=1 restores it for an A/B)
 // timing probes (tools/ab_split.sh name:-DSP_ABL_...=1; wrong results by construction, never in the product build)
+#ifndef SP_ABL_NOBAR
+#define SP_ABL_NOBAR 0
+#endif
+#ifndef SP_ABL_NOSPLIT
+#define SP_ABL_NOSPLIT 0
+#endif
+#ifndef SP_ABL_NOREAD
+#define SP_ABL_NOREAD 0
+#endif
+#ifndef SP_ABL_NOMFMA
+#define SP_ABL_NOMFMA 0
+#endif
 #ifndef SP_ABL_NOX
 #define SP_ABL_NOX 0
 #endif
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     {                                                  \
         __builtin_amdgcn_sched_barrier(0);             \
         asm volatile("" ::: "memory");                 \
-        __builtin_amdgcn_s_barrier();                  \
+        if (!SP_ABL_NOBAR) __builtin_amdgcn_s_barrier();   \
         asm volatile("" ::: "memory");                 \
         __builtin_amdgcn_sched_barrier(0);             \
     }
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         // K-step ks + 1's, issued in the interval before; NW = 3: K-step ks + 1's, issued a whole K-step ago
         SP_READ(ws, xs, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        write_x(xa, nxs);
+        if (!SP_ABL_NOSPLIT || ks == 0) write_x(xa, nxs);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SP_BARRIER();
         // MFMA(1); the fetches of K-step ks + 2 into the registers the split has just read (and, NW = 3, its weight DMA into the slot

@@ -156,10 +156,12 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(const TIN* __restrict__ 
 // above stays for bf16 inputs and behind bmi_set_option("dense_exact", 1).
 typedef _Float16 half4_d __attribute__((ext_vector_type(4)));
 
-template <bool XF32>
+// XKIND: 0 fp16 input (its own head), 1 fp32, 3 | 4 a pair32 tensor of the split engines (fp16 | bf16 halves: decoded while it is fetched)
+template <int XKIND>
 __global__ __launch_bounds__(256) void dense_split_kernel(const void* __restrict__ in_, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int N,
                                                           int in_mod, int K, int Cout, int relu, SiteArgs site, int B, int t0) {
+    constexpr bool XF32 = XKIND != 0;
     __shared__ __attribute__((aligned(16))) _Float16 Wh[DN_TF * 32], Wl[DN_TF * 32], Xh[DN_TS * 32], Xl[XF32 ? DN_TS * 32 : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
@@ -182,6 +184,11 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const void* __restrict
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
                 const int f = tid + 256 * i, row = f >> 3, q4 = f & 7;                                             \
                 const int nn = n0 + row < N ? n0 + row : 0;                                                        \
+                if constexpr (XKIND >= 3) {                                                                        \
+                    float d_[4];                                                                                   \
+                    pair_decode<XKIND == 4, 4>((const _Float16*)in_ + pair32_off((size_t)(nn % in_mod), K, (K0) + 4 * q4), d_); \
+                    xf[i] = f32x4_s{d_[0], d_[1], d_[2], d_[3]};                                                   \
+                } else                                                                                             \
                 xf[i] = *(const f32x4_s*)((const float*)in_ + (size_t)(nn % in_mod) * K + (K0) + 4 * q4);          \
             }                                                                                                      \
         } else {                                                                                                   \
@@ -286,9 +293,11 @@ int launch_dense_f32(const void* in, int in_kind, const float* w, const float* b
     if (n <= 0 || in_mod <= 0 || batch <= 0) return BMI_ERR_INVALID;
     if (k % DN_KC != 0 || cout % DN_TF != 0) return BMI_ERR_UNSUPPORTED;
     const dim3 grid((n + DN_TS - 1) / DN_TS, cout / DN_TF), block(256);
-    if (!opt_dense_exact() && in_kind != 2) {
-        if (in_kind == 1) hipLaunchKernelGGL((dense_split_kernel<true>), grid, block, 0, s, in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
-        else if (in_kind == 0) hipLaunchKernelGGL((dense_split_kernel<false>), grid, block, 0, s, in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+    if ((!opt_dense_exact() && in_kind != 2) || in_kind >= 3) {     // (pair32 inputs: the split form always)
+        if (in_kind == 1) hipLaunchKernelGGL((dense_split_kernel<1>), grid, block, 0, s, in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+        else if (in_kind == 0) hipLaunchKernelGGL((dense_split_kernel<0>), grid, block, 0, s, in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+        else if (in_kind == 3) hipLaunchKernelGGL((dense_split_kernel<3>), grid, block, 0, s, in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
+        else if (in_kind == 4) hipLaunchKernelGGL((dense_split_kernel<4>), grid, block, 0, s, in, w, bias, out, n, in_mod, k, cout, relu, site, batch, t0);
         else return BMI_ERR_INVALID;
         BMI_CHECK_LAUNCH();
         return BMI_OK;

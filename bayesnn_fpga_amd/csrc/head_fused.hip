@@ -32,7 +32,7 @@ typedef _Float16 half8_h __attribute__((ext_vector_type(8)));
 #define HEAD_KC 512                       // K chunk held in LDS (floats per sample)
 #define HEAD_FEAT_BYTES (32 * HEAD_KC * 4)
 
-// KIND: 0 fp16, 1 fp32, 2 bf16 input tensor
+// KIND: 0 fp16, 1 fp32, 2 bf16 input tensor; 3 | 4: a pair32 tensor of the split engines (conv_epilogue.h), fp16 | bf16 halves
 // CSPLIT (RT >= 3 class tiles, K % 32 == 0; round 2): the four waves split the CLASSES instead of K — wave w owns class tile w
 // for the whole K — and the classifier weights go through LDS.  Why: with the K split every wave holds partial sums of all RT
 // tiles (64 accumulators at RT = 4) and they meet in a [4][RT][16][64] fp32 LDS array (64 KB) next to the 64 KB feature chunk:
@@ -116,7 +116,12 @@ __global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArg
                         } else {
 #pragma unroll 8
                         for (int p = 0; p < a.HW; ++p) {
-                            if constexpr (KIND == 1) {
+                            if constexpr (KIND >= 3) {
+                                float x[8];
+                                pair_decode<KIND == 4, 8>((const _Float16*)a.in + pair32_off((size_t)(n % a.in_mod) * a.HW + p, K, k0 + c8 * 8), x);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += fmaxf(x[e], 0.f);
+                            } else if constexpr (KIND == 1) {
                                 const float* src = (const float*)a.in + row0 + (size_t)p * K;
                                 const f32x4_h x0 = *(const f32x4_h*)src, x1 = *(const f32x4_h*)(src + 4);
 #pragma unroll
@@ -367,18 +372,23 @@ __global__ __launch_bounds__(256) void head_join_kernel(const double* __restrict
 template <int RT>
 static void launch_rt(const HeadArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.imap ? a.Bc : a.B), (unsigned)((a.tc + 31) / 32)), block(256);
+#define HEAD_LAUNCH(CS)                                                                                                   \
+    switch (a.in_kind) {                                                                                                  \
+        case 1: hipLaunchKernelGGL((head_fused_kernel<RT, 1, CS>), grid, block, 0, s, a); break;                          \
+        case 2: hipLaunchKernelGGL((head_fused_kernel<RT, 2, CS>), grid, block, 0, s, a); break;                          \
+        case 3: hipLaunchKernelGGL((head_fused_kernel<RT, 3, CS>), grid, block, 0, s, a); break;                          \
+        case 4: hipLaunchKernelGGL((head_fused_kernel<RT, 4, CS>), grid, block, 0, s, a); break;                          \
+        default: hipLaunchKernelGGL((head_fused_kernel<RT, 0, CS>), grid, block, 0, s, a); break;                         \
+    }
     if constexpr (RT >= 3) {
         static const int csplit = [] { const char* v = std::getenv("BMI_HEAD_CSPLIT"); return v ? std::atoi(v) : 1; }();
         if (csplit) {
-            if (a.in_kind == 1) hipLaunchKernelGGL((head_fused_kernel<RT, 1, true>), grid, block, 0, s, a);
-            else if (a.in_kind == 2) hipLaunchKernelGGL((head_fused_kernel<RT, 2, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((head_fused_kernel<RT, 0, true>), grid, block, 0, s, a);
+            HEAD_LAUNCH(true)
             return;
         }
     }
-    if (a.in_kind == 1) hipLaunchKernelGGL((head_fused_kernel<RT, 1>), grid, block, 0, s, a);
-    else if (a.in_kind == 2) hipLaunchKernelGGL((head_fused_kernel<RT, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((head_fused_kernel<RT, 0>), grid, block, 0, s, a);
+    HEAD_LAUNCH(false)
+#undef HEAD_LAUNCH
 }
 
 int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
@@ -387,7 +397,7 @@ int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
     if (groups <= 1) a.part = nullptr;             // one group per image: the workgroup adds into S1 / S2 / SL itself
     if (!a.in || !a.w || !a.bias) return BMI_ERR_INVALID;
     if (!a.S1 || !a.S2 || !a.SL) { if (!a.logits) return BMI_ERR_INVALID; a.S1 = a.S2 = a.SL = nullptr; a.part = nullptr; }     // logits only
-    if (a.B <= 0 || a.tc <= 0 || a.in_mod <= 0 || a.HW <= 0 || a.C <= 0 || a.in_kind < 0 || a.in_kind > 2) return BMI_ERR_INVALID;
+    if (a.B <= 0 || a.tc <= 0 || a.in_mod <= 0 || a.HW <= 0 || a.C <= 0 || a.in_kind < 0 || a.in_kind > 4) return BMI_ERR_INVALID;
     if (a.in_mod != a.B && a.in_mod != a.B * a.tc) return BMI_ERR_INVALID;
     if (a.imap && (a.Bc <= 0 || a.Bc > a.B)) return BMI_ERR_INVALID;
     if (a.K % 32 != 0 || a.C > 128) return BMI_ERR_UNSUPPORTED;

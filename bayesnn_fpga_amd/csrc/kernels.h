@@ -84,6 +84,7 @@ __host__ __device__ inline long lazy_planar_off(int c, int y, int x, int hw, int
 }
 
 struct EltArgs {  // MASK op
+    int pair;     // 0, or 1 | 2: the tensors are in the split engines' pair32 layout (conv_epilogue.h), fp16 | bf16 halves
     int bf16;     // 16-bit tensors hold bfloat16 bits
     const _Float16* in;
     void* out;    // fp16 [N][HW][C]
@@ -134,7 +135,7 @@ int launch_conv_exact(const ConvArgs& a, hipStream_t s);
 int launch_conv_split(const ConvArgs& a, int bf16, hipStream_t s);
 bool conv_takes_split_kernel(int cin, int cout);
 int launch_mask_apply_f32(const EltArgs& a, hipStream_t s);
-int launch_maxpool2_f32(const float* in, float* out, int n, int h, int w, int c, hipStream_t s);
+int launch_maxpool2_f32(const float* in, float* out, int n, int h, int w, int c, hipStream_t s, int pair = 0);   // pair: 1 | 2 = pair32 tensors (fp16 | bf16)
 int launch_mask_apply(const EltArgs& a, hipStream_t s);
 int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int c, int bf16, hipStream_t s);
 // hidden dense layer, fp32 weights [cout][k] / accumulate / output; `in` 16-bit (in_kind 0: fp16, 2: bf16) or fp32 (1) [n or in_mod][k]

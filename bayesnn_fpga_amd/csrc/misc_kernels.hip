@@ -444,7 +444,8 @@ int launch_maxpool2(const _Float16* in, _Float16* out, int n, int h, int w, int 
 // FAST: three input channels and whole 32-channel blocks (every model of the path): no per-quad channel guards, the three
 // loads of a tap issued together.
 // F32OUT (the exact engine, BMI_DTYPE_F32): `out` holds fp32.
-template <bool BF, bool FAST, bool F32OUT = false>
+// PAIROUT (the split engines): `out` is a pair32 tensor (conv_epilogue.h) of fp16 (BF = false) or bf16 halves; a thread's 32 channels are one block.
+template <bool BF, bool FAST, bool F32OUT = false, bool PAIROUT = false>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         _Float16* __restrict__ out, int N, int Cin_, int H, int W, int Cout,
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     }
     const size_t o_off = (((size_t)n * Ho + oy) * Wo + ox) * Cout + c0;
     _Float16* op = out + o_off;
+    if constexpr (PAIROUT) op = out + pair32_off(((size_t)n * Ho + oy) * Wo + ox, Cout, c0);
 #pragma unroll
     for (int g8 = 0; g8 < 4; ++g8) {
         if (8 * g8 < nc) {
@@ -506,10 +508,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                 if (scale) v *= scale[c0 + 8 * g8 + e];
                 if (bias) v += bias[c0 + 8 * g8 + e];
                 if (relu) v = fmaxf(v, 0.f);
-                if constexpr (F32OUT) of[e] = v;
+                if constexpr (F32OUT || PAIROUT) of[e] = v;
                 else o[e] = a16_from_f32<BF>(v);
             }
-            if constexpr (F32OUT) {
+            if constexpr (PAIROUT) {
+                pair_encode<BF, 8>(op + 8 * g8, of);
+            } else if constexpr (F32OUT) {
                 float* fp = (float*)out + o_off + 8 * g8;
                 *(float4*)fp = make_float4(of[0], of[1], of[2], of[3]);
                 *(float4*)(fp + 4) = make_float4(of[4], of[5], of[6], of[7]);
@@ -530,7 +534,11 @@ int launch_stem_conv(const float* x, const float* w, const float* scale, const f
     const long total = (long)n * ho * wo;
     const dim3 grid((unsigned)((total + 255) / 256), (unsigned)((cout + 31) / 32)), block(256);
 #define STEM_LAUNCH(BF_, F_) hipLaunchKernelGGL((stem_conv_kernel<BF_, F_>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu)
-    if (dt == BMI_DTYPE_F32) {
+    if (dt == BMI_DTYPE_F16X2 || dt == BMI_DTYPE_BF16X3) {      // pair32 output: whole 32-channel blocks
+        if (cin != 3 || cout % 32 != 0) return BMI_ERR_UNSUPPORTED;
+        if (dt == BMI_DTYPE_BF16X3) hipLaunchKernelGGL((stem_conv_kernel<true, true, false, true>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+        else hipLaunchKernelGGL((stem_conv_kernel<false, true, false, true>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
+    } else if (dt == BMI_DTYPE_F32) {
         if (cin == 3 && cout % 32 == 0) hipLaunchKernelGGL((stem_conv_kernel<false, true, true>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
         else hipLaunchKernelGGL((stem_conv_kernel<false, false, true>), grid, block, 0, s, x, w, scale, bias, out, n, cin, h, wdt, cout, ksize, stride, pad, ho, wo, relu);
     } else if (cin == 3 && cout % 32 == 0) { if (bf16) STEM_LAUNCH(true, true); else STEM_LAUNCH(false, true); }
