@@ -215,7 +215,9 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
 
 // The same for the engines that keep fp32 activations (the exact engine's conv_exact.hip, the split engines' conv_split.hip):
 // arithmetic and order of epilogue_quad, fp32 residual row (`resp`, or null), the finished quad left in v[] for the caller's store.
-__device__ __forceinline__ void epilogue_quad_f32(const ConvArgs& a, const PixelCtx& p, const float* resp, float v[4], int c4) {
+// (rq: the four residual VALUES of the quad, added when has_res — a flag, not a null pointer: a select between a local array's address
+//  and null sends the array to scratch)
+__device__ __forceinline__ void epilogue_quad_f32v(const ConvArgs& a, const PixelCtx& p, const float* rq, bool has_res, float v[4], int c4) {
     if (a.scale) {
         const float4 s4 = *(const float4*)(a.scale + c4);
         v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
@@ -237,10 +239,7 @@ __device__ __forceinline__ void epilogue_quad_f32(const ConvArgs& a, const Pixel
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         }
     }
-    if (resp) {
-        const float4 r4 = *(const float4*)(resp + c4);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-    }
+    if (has_res) { v[0] += rq[0]; v[1] += rq[1]; v[2] += rq[2]; v[3] += rq[3]; }
     if (a.relu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -249,6 +248,11 @@ __device__ __forceinline__ void epilogue_quad_f32(const ConvArgs& a, const Pixel
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
     }
+}
+__device__ __forceinline__ void epilogue_quad_f32(const ConvArgs& a, const PixelCtx& p, const float* resp, float v[4], int c4) {
+    float rq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (resp) { const float4 r4 = *(const float4*)(resp + c4); rq[0] = r4.x; rq[1] = r4.y; rq[2] = r4.z; rq[3] = r4.w; }
+    epilogue_quad_f32v(a, p, rq, resp != nullptr, v, c4);
 }
 
 

@@ -26,7 +26,8 @@ struct TensorInfo {
     int h = 0, w = 0, c = 0;
     bool stoch = false;
     bool bits = false;          // holds keep bits (1 bit per element) instead of fp16 activations
-    bool f32 = false;           // fp32 activations (output of a DENSE op)
+    bool f32 = false;           // 4-byte elements: fp32 (output of a DENSE op; every tensor of the exact engine) or pair32 (the split engines' conv / stem / site / pool tensors)
+    bool dense_out = false;     // written by a DENSE op: plain fp32 in every engine
     bool pooled_now = false;    // (run time) the producing conv of this chunk wrote fp32 means over its 4x4 map instead of the tensor
     // Lazy site (the output of an elementwise MASK op on a deterministic tensor, see bmi_create): tensors that hold the keep bits of
     // the folded batch and the deterministic input times 1/(1-p) (fp16), or -1
@@ -190,6 +191,7 @@ int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_mask_lazy() { static int v = 1; return v; }
 int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
+static int unit_pair() { const int d = opt_unit_dtype(); return d == BMI_DTYPE_F16X2 ? 1 : (d == BMI_DTYPE_BF16X3 ? 2 : 0); }
 static bool unit_f32act() { const int d = opt_unit_dtype(); return d == BMI_DTYPE_F32 || d == BMI_DTYPE_F16X2 || d == BMI_DTYPE_BF16X3; }
 int& opt_ws_no_reuse() { static int v = 0; return v; }
 int& opt_lazy_planar() { static int v = 1; return v; }
@@ -465,6 +467,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 op.ho = 1; op.wo = 1; op.cout = to.c;
                 e->tensors[d.out].stoch = op.stoch;
                 e->tensors[d.out].f32 = true;
+                e->tensors[d.out].dense_out = true;
                 (op.stoch ? e->suffix : e->prefix).push_back(op);
                 (op.stoch ? e->suffix_macs : e->prefix_macs) += (int64_t)tin.c * to.c;
                 written[d.out] = 1;
@@ -781,7 +784,7 @@ int bmi_tensor_info(bmi_handle h, int32_t id, int64_t* offset, int32_t* elem_byt
     if (t.bits || (t.stoch && t.first < 0)) return BMI_ERR_UNSUPPORTED;   // keep bits / a tensor nothing reads have no activation layout
     if (offset) *offset = (int64_t)t.offset;
     if (elem_bytes) *elem_bytes = t.f32 ? 4 : 2;
-    if (per_sample) *per_sample = t.stoch ? 1 : 0;
+    if (per_sample) *per_sample = (t.stoch ? 1 : 0) | ((h->split && !t.dense_out) ? 2 : 0);
     if (th) *th = t.h;
     if (tw) *tw = t.w;
     if (tc) *tc = t.c;
@@ -871,7 +874,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     switch (d.kind) {
         case BMI_OP_STEM:
             return launch_stem_conv(x, (const float*)d.weight, d.scale, d.bias, (_Float16*)(ws + e->tensors[d.out].offset), N,
-                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, e->f32 ? BMI_DTYPE_F32 : e->dtype, s);
+                                    tin.c, tin.h, tin.w, op.cout, d.ksize, d.stride, d.pad, d.relu, e->dtype, s);     // (F32: fp32 out; F16X2 / BF16X3: pair32 out)
         case BMI_OP_CONV: {
             ConvArgs a;
             std::memset(&a, 0, sizeof(a));
@@ -1044,6 +1047,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             a.N = N; a.in_mod = tin.stoch ? N : B; a.HW = tin.h * tin.w; a.C = tin.c; a.B = B; a.t0 = t0;
             a.site = resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)tin.h * tin.w * tin.c, (size_t)tin.c));
             if (d.site_pos == BMI_SITE_POS_INNER) { a.bias_post = d.bias_post; a.relu = d.relu; }
+            a.pair = e->split;                                     // the split engines: pair32 tensors in and out
             if (e->f32) return launch_mask_apply_f32(a, s);
             TensorInfo& to = e->tensors[d.out];
             to.lazy_pending = false;
@@ -1064,11 +1068,12 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             return launch_mask_apply(a, s);
         }
         case BMI_OP_MAXPOOL:
-            if (e->f32) return launch_maxpool2_f32((const float*)(ws + tin.offset), (float*)(ws + e->tensors[d.out].offset), N, tin.h, tin.w, tin.c, s);
+            if (e->f32) return launch_maxpool2_f32((const float*)(ws + tin.offset), (float*)(ws + e->tensors[d.out].offset), N, tin.h, tin.w, tin.c, s, e->split);
             return launch_maxpool2((const _Float16*)(ws + tin.offset), (_Float16*)(ws + e->tensors[d.out].offset), N, tin.h,
                                    tin.w, tin.c, e->bf16, s);
         case BMI_OP_DENSE:
-            return launch_dense_f32(ws + tin.offset, tin.f32 ? 1 : (e->bf16 ? 2 : 0), (const float*)d.weight, d.bias,
+            // input: fp32 (a dense layer's output; any tensor of the exact engine), the engine's 16-bit type, or pair32 (kinds 3 | 4)
+            return launch_dense_f32(ws + tin.offset, (e->split && !tin.dense_out) ? 2 + e->split : (tin.f32 ? 1 : (e->bf16 ? 2 : 0)), (const float*)d.weight, d.bias,
                                     (float*)(ws + e->tensors[d.out].offset), N, tin.stoch ? N : B, tin.c, op.cout, d.relu,
                                     resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)op.cout, (size_t)op.cout)), B, t0, s);
         case BMI_OP_HEAD: {
@@ -1076,7 +1081,8 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             HeadArgs a;
             std::memset(&a, 0, sizeof(a));
             a.in = ws + tin.offset;
-            a.in_kind = (tin.f32 || tin.pooled_now) ? 1 : (e->bf16 ? 2 : 0);      // pooled_now: fp32 means [row][K] written by the conv
+            a.in_kind = (e->split && !tin.dense_out) ? 2 + e->split        // the split engines' pair32 tensors
+                        : (tin.f32 || tin.pooled_now) ? 1 : (e->bf16 ? 2 : 0);      // pooled_now: fp32 means [row][K] written by the conv
             a.in_mod = tin.stoch ? n_rows : B;
             a.imap = imap; a.Bc = Bc;
             a.HW = tin.pooled_now ? 1 : tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = imap ? N / Bc : N / B;
@@ -1315,7 +1321,7 @@ int bmi_stem_conv_fwd(const float* x_nchw, const float* weight, const float* sca
                       int32_t pad, int32_t relu, bmi_stream stream) {
     if (!x_nchw || !weight || !out_nhwc) return BMI_ERR_INVALID;
     return launch_stem_conv(x_nchw, weight, scale, bias, (_Float16*)out_nhwc, n, cin, h, w, cout, ksize, stride, pad, relu,
-                            unit_f32act() ? BMI_DTYPE_F32 : opt_unit_dtype(), (hipStream_t)stream);
+                            opt_unit_dtype(), (hipStream_t)stream);
 }
 
 int bmi_mask_bits(void* bits, int32_t n, int32_t hw, int32_t c, const bmi_site* site, int32_t batch, int32_t t0,
@@ -1404,13 +1410,13 @@ int bmi_mask_apply(const void* in, void* out, int32_t n, int32_t in_mod, int32_t
                    int32_t batch, int32_t t0, uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
     EltArgs a;
     const int rc = elt_args(a, in, out, n, in_mod, hw, c, site, batch, t0, seed, mask_cnt0);
-    if (rc == BMI_OK && unit_f32act()) return launch_mask_apply_f32(a, (hipStream_t)stream);
+    if (rc == BMI_OK && unit_f32act()) { a.pair = unit_pair(); return launch_mask_apply_f32(a, (hipStream_t)stream); }
     return rc != BMI_OK ? rc : launch_mask_apply(a, (hipStream_t)stream);
 }
 
 int bmi_maxpool2(const void* in, void* out, int32_t n, int32_t h, int32_t w, int32_t c, bmi_stream stream) {
     if (!in || !out) return BMI_ERR_INVALID;
-    if (unit_f32act()) return launch_maxpool2_f32((const float*)in, (float*)out, n, h, w, c, (hipStream_t)stream);
+    if (unit_f32act()) return launch_maxpool2_f32((const float*)in, (float*)out, n, h, w, c, (hipStream_t)stream, unit_pair());
     return launch_maxpool2((const _Float16*)in, (_Float16*)out, n, h, w, c, opt_unit_dtype() == BMI_DTYPE_BF16, (hipStream_t)stream);
 }
 
@@ -1419,7 +1425,7 @@ int bmi_dense_f32(const void* in, int32_t in_is_f32, const float* weight, const 
                   uint64_t seed, int32_t mask_cnt0, bmi_stream stream) {
     if (!in || !weight || !bias || !out) return BMI_ERR_INVALID;
     if (site && !site_ok(*site)) return BMI_ERR_INVALID;
-    return launch_dense_f32(in, in_is_f32 ? 1 : (opt_unit_dtype() == BMI_DTYPE_BF16 ? 2 : 0), weight, bias, out, n, in_mod, k, cout, relu, resolve_site(site, seed, mask_cnt0), batch,
+    return launch_dense_f32(in, in_is_f32 ? 1 : (unit_pair() ? 2 + unit_pair() : (opt_unit_dtype() == BMI_DTYPE_BF16 ? 2 : 0)), weight, bias, out, n, in_mod, k, cout, relu, resolve_site(site, seed, mask_cnt0), batch,
                             t0, (hipStream_t)stream);
 }
 
@@ -1430,7 +1436,7 @@ int bmi_head_fused(const void* in, int32_t in_is_f32, int32_t in_mod, int32_t hw
     HeadArgs a;
     std::memset(&a, 0, sizeof(a));
     a.in = in;
-    a.in_kind = in_is_f32 ? 1 : (opt_unit_dtype() == BMI_DTYPE_BF16 ? 2 : 0);
+    a.in_kind = in_is_f32 ? 1 : (unit_pair() ? 2 + unit_pair() : (opt_unit_dtype() == BMI_DTYPE_BF16 ? 2 : 0));
     a.in_mod = in_mod; a.HW = hw; a.K = k; a.B = batch; a.t0 = t0; a.tc = tc;
     a.w = weight_pad; a.bias = bias; a.C = out_dim;
     a.site = resolve_site(site, seed, mask_cnt0);

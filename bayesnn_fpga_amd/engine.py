@@ -499,9 +499,13 @@ class MCDEngine(CompiledGraph):
         th, tw, tc = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.bmi_tensor_info(self.handle, int(tensor_id), C.byref(off), C.byref(eb), C.byref(ps), C.byref(th),
                                             C.byref(tw), C.byref(tc)), "bmi_tensor_info")
-        n = batch * (samples if ps.value else 1)
+        n = batch * (samples if ps.value & 1 else 1)
         count = n * th.value * tw.value * tc.value
         raw = self.workspace[off.value:off.value + count * eb.value]
+        if ps.value & 2:                   # the split engines' pair32 layout: per pixel, 32-channel blocks [32 heads | 32 tails]
+            dt16 = torch.bfloat16 if self.dtype == "bf16x3" else torch.float16
+            blocks = raw.view(dt16).view(n, th.value, tw.value, tc.value // 32, 2, 32).float()
+            return (blocks[..., 0, :] + blocks[..., 1, :]).reshape(n, th.value, tw.value, tc.value).clone()
         dt = torch.float32 if eb.value == 4 else (torch.bfloat16 if self.dtype == "bf16" else torch.float16)
         return raw.view(dt).view(n, th.value, tw.value, tc.value).float().clone()
 

@@ -129,9 +129,11 @@ typedef struct bmi_op_desc {
                             rate.  Graph features that exist for speed only are not built (in2 is BMI_ERR_UNSUPPORTED; no
                             pair / pooling / lazy-site fusion); bmi_forward_mcd_exit is BMI_ERR_UNSUPPORTED.              */
 
-#define BMI_DTYPE_F16X2 3  /* the SPLIT engines, parity at speed (csrc/conv_split.hip): fp32 activations in the workspace as in the exact
-                             engine, every conv operand a 16-bit head + tail pair — `weight` is 16-bit [2][Cout][k][k][Cin], plane 0 =
-                             rn16(w), plane 1 = rn16(w - plane 0), split ONCE by the host; the activations are split on the fly — and
+#define BMI_DTYPE_F16X2 3  /* the SPLIT engines, parity at speed (csrc/conv_split.hip): every conv operand a 16-bit head + tail pair, v = hi + lo
+                             (hi = rn16(v), lo = rn16(v - hi)) — `weight` is 16-bit [2][Cout][k][k][Cin], plane 0 = the heads, plane 1 = the
+                             tails, split ONCE by the host; the activations live in the workspace in the same form ("pair32": per pixel,
+                             32-channel blocks [hi x 32 | lo x 32], 4 bytes per element: csrc/conv_epilogue.h), encoded once by the
+                             kernel that produces a tensor — and
                              w.x = w_lo.x_hi + w_hi.x_lo + w_hi.x_hi on v_mfma_f32_32x32x16_f16 (fp32 accumulate; 22 significant bits
                              per operand, lo.lo dropped): three MFMAs per K-step instead of the exact engine's sixteen.  The reference's
                              fp32 arithmetic to ~1e-6 where plain fp16 is at 1e-4..2e-3 (peaky logits of trained / converted nets,
@@ -211,8 +213,9 @@ const char* bmi_error_string(int code);
  *   "unit_entry_dtype"                      BMI_DTYPE_*: how the single-kernel entry points below (unit tests) interpret
  *                                           their 16-bit buffers; engines carry their own dtype in bmi_model_desc.  BMI_DTYPE_F32:
  *                                           bmi_conv_igemm_fwd / bmi_stem_conv_fwd (output) / bmi_mask_apply / bmi_maxpool2 take fp32
- *                                           buffers (and fp32 conv weights) and run the exact engine's kernels; BMI_DTYPE_F16X2 / BF16X3: fp32
- *                                           buffers too, bmi_conv_igemm_fwd takes the 16-bit head / tail weight planes and runs conv_split
+ *                                           buffers (and fp32 conv weights) and run the exact engine's kernels; BMI_DTYPE_F16X2 / BF16X3: the
+ *                                           activation buffers of those entry points (and of bmi_head_fused / bmi_dense_f32 with in_is_f32 = 0)
+ *                                           are pair32 tensors, bmi_conv_igemm_fwd takes the 16-bit head / tail weight planes and runs conv_split
  *   "ws_no_reuse"                           0 | 1, read by bmi_plan: every suffix tensor keeps its own workspace range (per-layer
  *                                           traces through bmi_tensor_info; the workspace grows to the sum of the activations)
  * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT). */
@@ -233,8 +236,9 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
 int bmi_query(bmi_handle h, int64_t* prefix_macs, int64_t* suffix_macs, int32_t* n_prefix_ops, int32_t* n_suffix_ops);
 
 /* Traces (tools/layer_trace.py): where tensor `id` (1 .. n_tensors-1 of the descriptor) of a PLANNED engine lives in the caller's
- * workspace: byte offset, bytes per element (2: the engine's 16-bit type, 4: fp32), whether it holds one image set per
- * Monte-Carlo sample of the chunk ([chunk*B][h][w][c], image = t_local*B + b) or the once-per-batch B images, and its extent.
+ * workspace: byte offset, bytes per element (2: the engine's 16-bit type, 4: fp32 or pair32), per_sample bit 0: it holds one image set per
+ * Monte-Carlo sample of the chunk ([chunk*B][h][w][c], image = t_local*B + b) rather than the once-per-batch B images; bit 1: the tensor
+ * is in the split engines' pair32 layout (per pixel, 32-channel blocks of 32 heads + 32 tails, 16-bit each); and its extent.
  * Suffix tensors share workspace ranges by live range unless the engine was planned under bmi_set_option("ws_no_reuse", 1);
  * a fused launch may leave a tensor unwritten (set "mask_lazy" = 0, "conv_pool" = 0 for a full trace).  Keep-bit tensors and
  * tensors nothing reads are BMI_ERR_UNSUPPORTED.  No reference counterpart (a forward hook on an nn.Module). */

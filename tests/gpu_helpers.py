@@ -80,3 +80,19 @@ def run_conv(x, w, scale, bias, res, relu, stride, pad, n, in_mod, res_mod, site
     _lib.check(rc, "bmi_conv_igemm_fwd")
     torch.cuda.synchronize()
     return out
+
+
+# ---- the split engines' activation layout ("pair32", csrc/conv_epilogue.h): per pixel, 32-channel blocks [32 heads | 32 tails] ---------
+def pair32_encode(x, dt16):
+    """fp32 [N, H, W, C] (C % 32 == 0) -> 16-bit [N, H, W, C/32, 2, 32]: hi = rn16(v), lo = rn16(v - hi)."""
+    n, h, w, c = x.shape
+    b = x.float().reshape(n, h, w, c // 32, 32)
+    hi = b.to(dt16)
+    lo = (b - hi.float()).to(dt16)
+    return torch.stack([hi, lo], dim=4).contiguous()
+
+
+def pair32_decode(p):
+    """the inverse: 16-bit [N, H, W, C/32, 2, 32] -> fp32 [N, H, W, C]."""
+    n, h, w, cb = p.shape[:4]
+    return (p[..., 0, :].float() + p[..., 1, :].float()).reshape(n, h, w, cb * 32)

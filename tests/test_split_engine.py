@@ -97,7 +97,10 @@ def _run_split(x, w, dt, scale, bias, res, relu, stride, pad, n, in_mod, res_mod
     n_in, H, W, cin = x.shape
     cout, k = w.shape[0], w.shape[1]
     ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    out = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.float32, device=DEV)
+    # activations cross the C ABI in the split engines' pair32 layout (16-bit head + tail per element, 32-channel blocks)
+    x = gh.pair32_encode(x, TORCH16[dt])
+    res = gh.pair32_encode(res, TORCH16[dt]) if res is not None else None
+    out = torch.full((n, ho, wo, cout // 32, 2, 32), float("nan"), dtype=TORCH16[dt], device=DEV)
     keep = []
     s = gh.site_struct(kw.get("site"), keep)
     rc = lib.bmi_conv_igemm_fwd(gh.ptr(x), None, 1.0, gh.ptr(wp), gh.ptr(scale), gh.ptr(bias), gh.ptr(res), gh.ptr(out), n, in_mod, res_mod, H, W,
@@ -105,7 +108,75 @@ def _run_split(x, w, dt, scale, bias, res, relu, stride, pad, n, in_mod, res_mod
                                 kw.get("t0", 0), kw.get("seed", 0), kw.get("cnt0", 0), gh.stream())
     _lib.check(rc, "bmi_conv_igemm_fwd")
     torch.cuda.synchronize()
-    return out
+    return gh.pair32_decode(out)
+
+
+@pytest.mark.gpu
+def test_split_stem_mask_maxpool_head_and_dense_on_pair32(split_entries):
+    """The split engines' other kernels on pair32 tensors, through the unit entry points: the stem writes the encoding of its fp32 result;
+    the stand-alone site and the max-pool read and write it (a dropped element is exactly 0, a kept one the encoding of x / (1 - p); the
+    maximum is one of its four inputs); the exit head and a hidden dense layer read it (against their fp32-input forms on the decoded
+    tensor: the same numbers)."""
+    dt = split_entries
+    t16 = TORCH16[dt]
+    eps = 2.0 ** -20 if dt == "f16x2" else 2.0 ** -15
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    n = 5
+    x = torch.randn(n, 3, 32, 32, generator=g).to(DEV)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+    scale, bias = 0.5 + torch.rand(64, generator=g), 0.2 * torch.randn(64, generator=g)
+    out = torch.empty(n, 32, 32, 2, 2, 32, dtype=t16, device=DEV)
+    wd, sd, bd = w.to(DEV), scale.to(DEV), bias.to(DEV)
+    _lib.check(lib.bmi_stem_conv_fwd(gh.ptr(x), gh.ptr(wd), gh.ptr(sd), gh.ptr(bd), gh.ptr(out), n, 3, 32, 32, 64, 3, 1, 1, 0, gh.stream()), "bmi_stem_conv_fwd")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().permute(0, 3, 1, 2), padding=1) * scale.double()[None, :, None, None] + \
+        bias.double()[None, :, None, None]
+    got = gh.pair32_decode(out).double().cpu().permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= 1e-5 + eps * float(ref.abs().max())
+    # stand-alone site: B deterministic images -> the folded batch
+    B, tc, H, Cc, t0, seed = 3, 4, 6, 64, 2, 99
+    xs = torch.randn(B, H, H, Cc, generator=g).to(DEV)
+    xs = gh.pair32_decode(gh.pair32_encode(xs, t16))            # (values the layout holds exactly)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=0, p=0.375)
+    keep = []
+    s = gh.site_struct(site, keep)
+    om = torch.empty(B * tc, H, H, Cc // 32, 2, 32, dtype=t16, device=DEV)
+    _lib.check(lib.bmi_mask_apply(gh.ptr(gh.pair32_encode(xs, t16)), gh.ptr(om), B * tc, B, H * H, Cc, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_mask_apply")
+    torch.cuda.synchronize()
+    mult = gh.folded_site_mask(site, B, Cc, H, H, tc, t0, seed)
+    want = xs.cpu().permute(0, 3, 1, 2).repeat(tc, 1, 1, 1) * mult
+    gotm = gh.pair32_decode(om).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(gotm == 0, want == 0) and float((gotm - want).abs().max()) <= eps * float(want.abs().max())
+    # max-pool: exact (the maximum is one of the encoded inputs)
+    xp = gh.pair32_decode(gh.pair32_encode(torch.randn(3, 8, 8, 64, generator=g).to(DEV), t16))
+    op = torch.empty(3, 4, 4, 2, 2, 32, dtype=t16, device=DEV)
+    _lib.check(lib.bmi_maxpool2(gh.ptr(gh.pair32_encode(xp, t16)), gh.ptr(op), 3, 8, 8, 64, gh.stream()), "bmi_maxpool2")
+    torch.cuda.synchronize()
+    assert torch.equal(gh.pair32_decode(op).cpu().permute(0, 3, 1, 2), torch.nn.functional.max_pool2d(xp.cpu().permute(0, 3, 1, 2), 2))
+    # exit head and hidden dense layer: pair32 input against the fp32-input form on the decoded tensor
+    Bh, tch, HW, K, Co = 4, 3, 16, 128, 10
+    xh = gh.pair32_decode(gh.pair32_encode(torch.randn(Bh * tch, 4, 4, K, generator=g).abs().to(DEV), t16))
+    wl = torch.zeros(32, K)
+    wl[:Co] = torch.randn(Co, K, generator=g) * 0.1
+    wl, bl = wl.to(DEV), (0.1 * torch.randn(Co, generator=g)).to(DEV)
+    outs = []
+    for is_f32, buf in ((1, xh.contiguous()), (0, gh.pair32_encode(xh, t16))):
+        S = torch.zeros(3, Bh, Co, dtype=torch.float64, device=DEV)
+        _lib.check(lib.bmi_head_fused(gh.ptr(buf), is_f32, Bh * tch, HW, K, gh.ptr(wl), gh.ptr(bl), Co, None, None, Bh, 0, tch, 7, 0,
+                                      gh.ptr(S[0]), gh.ptr(S[1]), gh.ptr(S[2]), gh.stream()), "bmi_head_fused")
+        torch.cuda.synchronize()
+        outs.append(S.clone())
+    assert torch.equal(outs[0], outs[1])
+    xd = gh.pair32_decode(gh.pair32_encode(torch.randn(7, 1, 1, 64, generator=g).to(DEV), t16))
+    wdn, bdn = (torch.randn(64, 64, generator=g) * 0.2).to(DEV), (0.1 * torch.randn(64, generator=g)).to(DEV)
+    od = []
+    for is_f32, buf in ((1, xd.contiguous()), (0, gh.pair32_encode(xd, t16))):
+        o = torch.empty(7, 64, device=DEV)
+        _lib.check(lib.bmi_dense_f32(gh.ptr(buf), is_f32, gh.ptr(wdn), gh.ptr(bdn), gh.ptr(o), 7, 7, 64, 64, 1, None, 7, 0, 0, 0, gh.stream()), "bmi_dense_f32")
+        torch.cuda.synchronize()
+        od.append(o.clone())
+    assert torch.equal(od[0], od[1])
 
 
 @pytest.mark.gpu
