@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbayesnn_fpga_amd.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm_wide.hip", "conv3x3_patch.hip", "conv3x3_pw.hip", "conv3x3_s2.hip", "conv1x1_stream.hip", "conv_exact.hip", "conv_split.hip", "misc_kernels.hip", "dense_f32.hip", "head_fused.hip", "engine.hip"]
+SOURCES = ["conv_igemm.hip", "conv_igemm_wide.hip", "conv3x3_patch.hip", "conv3x3_pw.hip", "conv3x3_s2.hip", "conv1x1_stream.hip", "conv1x1_seam.hip", "conv_exact.hip", "conv_split.hip", "misc_kernels.hip", "dense_f32.hip", "head_fused.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -18,8 +18,8 @@ FP32_ACT_DTYPES = ("f32", "f16x2", "bf16x3")      # engines that keep fp32 activ
 OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
 PROFILE_SLOTS = 8
 CONV_FAMILY_KERNELS = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel", "conv1x1_stream_kernel",
-                       "conv3x3_s2_kernel", "conv_split_kernel")
-ABI_VERSION = 500             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
+                       "conv3x3_s2_kernel", "conv_split_kernel", "conv1x1_seam_kernel")
+ABI_VERSION = 510             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
 CONV_FAMILIES = len(CONV_FAMILY_KERNELS)     # BMI_CONV_FAMILIES
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
                  OP_DENSE: "dense"}
@@ -88,6 +88,7 @@ _PROTOS = {
     "bmi_profile_launches": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)] + [C.POINTER(C.c_int32)] * 4 + [C.POINTER(C.c_double)] * 3),
     "bmi_profile_conv_families": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                             C.POINTER(C.c_double)]),
+    "bmi_conv1x1_seam_fwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 7 + [C.c_void_p]),
     "bmi_conv_pair_fwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 11 + [C.c_void_p]),
     "bmi_mask_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Site),
                                  C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]),

@@ -478,7 +478,7 @@ __host__ __device__ constexpr bool conv_epilogue_is_lite(int epi) {
 // (half4 [4][2 TJ], [i][j] = channels ch0 + wc 64 + 16 i + 4 (lane >> 4) .. of pixel wp 32 TJ + 16 j + (lane & 15)) at the START of its tile:
 // no residual DMA, no wait for it and one barrier less here.
 struct NoResRegs {};
-template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, int SK = -1, class ACC, class PixMap, class OffMap, class RREG = NoResRegs>
+template <int TJ, bool BF, bool RES_IN_LDS = false, bool POOL = false, int SK = -1, int RES_VMCNT = 0, bool NT_OUT = false, class ACC, class PixMap, class OffMap, class RREG = NoResRegs>
 __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char* lds, int tid, int ch0,
                                               PixMap pixmap, OffMap offmap, RREG* rreg = nullptr) {
     constexpr bool RES_REGS = !__is_same(RREG, NoResRegs);
@@ -533,7 +533,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
         }
     }
     if constexpr (!RES_REGS) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RES_VMCNT) : "memory");     // (RES_VMCNT: pieces the caller issued AFTER the residual's and does not need yet)
         lds_barrier();
     }
 #pragma unroll
@@ -620,7 +620,8 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
         const int pl = (tid >> 4) + 16 * it;
         size_t off;
         if (!offmap(pl, off) || BMI_ABL_NOSTORE) continue;
-        *(half8_e*)(a.out + off + ch0 + 8 * k) = o[it];
+        if constexpr (NT_OUT) __builtin_nontemporal_store(o[it], (half8_e*)(a.out + off + ch0 + 8 * k));     // (conv1x1_seam: a streamed tensor must not evict the tile's re-read operands from L2)
+        else *(half8_e*)(a.out + off + ch0 + 8 * k) = o[it];
     }
 }
 

@@ -57,6 +57,9 @@ struct OpInfo {
     bool has_pair = false;  // CONV: a second conv on the same input rides in this launch (conv_igemm_wide pair mode)
     bmi_op_desc pair_d;
     int pair_cout = 0;
+    bool has_seam = false;  // CONV (1x1 expand + residual + ReLU of a Bottleneck): the NEXT op, a plain 1x1 conv that reads this conv's output (conv1 of the
+    bmi_op_desc seam_d;     // following Bottleneck), rides in this launch when conv1x1_seam takes it (else the two launches, in order)
+    int seam_cout = 0;
 };
 
 struct ProfRec {
@@ -187,6 +190,7 @@ int& opt_lazy_order() { static int v = 1; return v; }
 int& opt_dense_exact() { static int v = 0; return v; }
 int& opt_splitk() { static int v = 1; return v; }
 int& opt_conv_stream() { static int v = 1; return v; }
+int& opt_conv_seam() { static int v = 1; return v; }
 int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_mask_lazy() { static int v = 1; return v; }
@@ -262,6 +266,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_wide") == 0) {
         if (value != 0 && value != 1) return BMI_ERR_INVALID;
         opt_conv_wide() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "conv_seam") == 0) {
+        if (value < 0 || value > 3) return BMI_ERR_INVALID;
+        opt_conv_seam() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_stream") == 0) {
@@ -564,6 +573,23 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
             }
         }
     }
+    // Seam fusion (Bottleneck nets): conv3 + BN + residual + ReLU of block k followed at once by conv1 + BN + ReLU of block k+1 on its output:
+    // one conv1x1_seam launch produces both tensors and the wide one is not read back (conv1x1_seam.hip).  Decided per launch in run_op.
+    for (size_t i = 0; !e->f32 && opt_conv_seam() && i + 1 < e->suffix.size(); ++i) {
+        OpInfo& A = e->suffix[i];
+        const OpInfo& Bo = e->suffix[i + 1];
+        auto one = [&](const OpInfo& c) {
+            return c.d.kind == BMI_OP_CONV && c.stoch && !c.has_pair && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE && c.bits_tensor < 0 && c.out_mul == 1.f &&
+                   c.d.ksize == 1 && c.d.stride == 1 && c.d.pad == 0 && c.d.scale && c.d.bias;
+        };
+        if (!one(A) || !one(Bo) || A.d.residual < 0 || !A.d.relu || Bo.d.residual >= 0 || Bo.d.in != A.d.out) continue;
+        if (!e->tensors[A.d.in].stoch || !e->tensors[A.d.residual].stoch) continue;
+        if (!conv_takes_seam_kernel(e->tensors[A.d.in].c, A.cout, Bo.cout)) continue;
+        A.has_seam = true;
+        A.seam_d = Bo.d;
+        A.seam_cout = Bo.cout;
+        e->suffix.erase(e->suffix.begin() + (long)i + 1);
+    }
     // ReLU + global average pool fused into the producing conv: a plain 3x3 stride-2 conv whose 4x4 output map feeds ONE exit head and
     // nothing else (ex1conv3 / ex2conv2 / ex3conv1 of the ResNets: relu -> avg_pool2d(4) -> Linear, resnet18.py:309-314, :320-325,
     // :331-335) may write fp32 means [row][Cout] instead of the map when conv3x3_s2 takes the launch (decided per launch: run_op).
@@ -620,6 +646,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
         if (d.kind == BMI_OP_CONV) touch(d.residual);
         if (d.kind != BMI_OP_HEAD) touch(d.out);
         if (e->suffix[k].has_pair) touch(e->suffix[k].pair_d.out);
+        if (e->suffix[k].has_seam) touch(e->suffix[k].seam_d.out);
     }
     // Lazy sites.  The first elementwise site of a "block"-dropout ResNet expands the once-per-batch prefix (B images) to the folded
     // batch: 3.3 GB written by the MASK op and read back by its consumers on the headline config.  Where a consumer can apply the
@@ -934,6 +961,33 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                            2.0 * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
             if (d.residual >= 0) bytes += tbytes(d.residual);
             if (d.in2 >= 0) bytes += tbytes(d.in2) + 2.0 * op.cout * e->tensors[d.in2].c;
+            if (op.has_seam) {
+                // the next Bottleneck's reduce conv on this conv's output: one conv1x1_seam launch, or the two launches in order
+                ConvArgs b;
+                std::memset(&b, 0, sizeof(b));
+                b.bf16 = e->bf16;
+                b.in = a.out;
+                b.wgt = (const _Float16*)op.seam_d.weight;
+                b.scale = op.seam_d.scale; b.bias = op.seam_d.bias;
+                b.out = (_Float16*)(ws + e->tensors[op.seam_d.out].offset);
+                b.N = N; b.n_ref = a.n_ref; b.imap = rows; b.Bc = Bc; b.in_mod = n_rows;
+                b.H = op.ho; b.W = op.wo; b.Cin = op.cout; b.Ho = op.ho; b.Wo = op.wo; b.Cout = op.seam_cout;
+                b.ksize = 1; b.stride = 1; b.pad = 0; b.relu = op.seam_d.relu;
+                b.M = a.M; b.B = B; b.t0 = t0;
+                b.site = resolve_site(nullptr, seed, cnt0, 0);
+                b.out_mul = 1.f;
+                const double flops_b = 2.0 * N * op.ho * op.wo * (double)op.seam_cout * op.cout;
+                const double bytes_b = 2.0 * N * op.ho * op.wo * (double)op.seam_cout + 2.0 * (double)op.seam_cout * op.cout;   // (its input never leaves the chip)
+                const int rcs = launch_conv1x1_seam(a, b, s);
+                if (rcs != BMI_ERR_UNSUPPORTED) {
+                    prof.tag(BMI_CONV_FAMILY_SEAM, flops + flops_b, bytes + bytes_b);
+                    return rcs;
+                }
+                int fam = -1;
+                const int rc1 = launch_conv(a, s, &fam);
+                prof.tag(fam, flops + flops_b, bytes + bytes_b + 2.0 * N * op.ho * op.wo * (double)op.cout);
+                return rc1 != BMI_OK ? rc1 : launch_conv(b, s);
+            }
             if (op.has_pair) {
                 ConvArgs p = a;
                 p.wgt_b = (const _Float16*)op.pair_d.weight;
@@ -1355,6 +1409,30 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
     if (opt_unit_dtype() == BMI_DTYPE_F32) return launch_conv_exact(a, (hipStream_t)stream);
     if (unit_f32act()) return launch_conv_split(a, opt_unit_dtype() == BMI_DTYPE_BF16X3, (hipStream_t)stream);
     return launch_conv(a, (hipStream_t)stream);
+}
+
+int bmi_conv1x1_seam_fwd(const void* in, const void* weight3, const float* scale3, const float* bias3, const void* res, void* out_wide,
+                         const void* weight1, const float* scale1, const float* bias1, void* out_narrow, int32_t n, int32_t h, int32_t w,
+                         int32_t cmid, int32_t cw, int32_t cn, int32_t relu1, bmi_stream stream) {
+    if (!in || !weight3 || !res || !out_wide || !weight1 || !out_narrow || n <= 0) return BMI_ERR_INVALID;
+    if (opt_unit_dtype() != BMI_DTYPE_F16 && opt_unit_dtype() != BMI_DTYPE_BF16) return BMI_ERR_UNSUPPORTED;
+    ConvArgs a, b;
+    std::memset(&a, 0, sizeof(a));
+    a.bf16 = opt_unit_dtype() == BMI_DTYPE_BF16;
+    a.in = (const _Float16*)in; a.wgt = (const _Float16*)weight3; a.scale = scale3; a.bias = bias3;
+    a.res = (const _Float16*)res; a.out = (_Float16*)out_wide;
+    a.N = n; a.in_mod = n; a.res_mod = n;
+    a.H = a.Ho = h; a.W = a.Wo = w; a.Cin = cmid; a.Cout = cw;
+    a.ksize = 1; a.stride = 1; a.pad = 0; a.relu = 1;
+    a.M = n * h * w; a.B = n; a.out_mul = 1.f;
+    a.site = resolve_site(nullptr, 0, 0);
+    b = a;
+    b.in = a.out; b.wgt = (const _Float16*)weight1; b.scale = scale1; b.bias = bias1; b.res = nullptr; b.res_mod = 0;
+    b.out = (_Float16*)out_narrow; b.Cin = cw; b.Cout = cn; b.relu = relu1;
+    const int rc = launch_conv1x1_seam(a, b, (hipStream_t)stream);
+    if (rc != BMI_ERR_UNSUPPORTED) return rc;
+    const int rc1 = launch_conv(a, (hipStream_t)stream);      // the engine's fallback: the two launches
+    return rc1 != BMI_OK ? rc1 : launch_conv(b, (hipStream_t)stream);
 }
 
 int bmi_conv_pair_fwd(const void* in, const void* weight_a, const float* scale_a, const float* bias_a, void* out_a,

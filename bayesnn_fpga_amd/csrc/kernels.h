@@ -157,6 +157,8 @@ int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, in
 int& opt_pw_persist();         // 1: plain-epilogue launches of conv3x3_pw run in its persistent form (conv3x3_pwp_kernel), 0: never
 int& opt_lazy_planar();        // 1: lazy sites whose readers are all stride-2 consumers store their scaled copy + bits in the planar layout
 int launch_splitk_finish(const ConvArgs& a, hipStream_t s);   // after a split-K conv_igemm launch
+int launch_conv1x1_seam(const ConvArgs& a, const ConvArgs& b, hipStream_t s);   // conv1x1_seam.hip: a = expand conv (+ residual), b = the reduce conv that reads a.out
+bool conv_takes_seam_kernel(int cmid, int cw, int cn);
 int launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);
 
@@ -170,6 +172,7 @@ int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the
 int& opt_mask_lazy();          // 1: a lazy site (engine.hip, bmi_create) writes keep bits + one scaled copy and its consumers mask in LDS, 0: always materialised
 int& opt_conv_pool();          // 1: a conv whose 4x4 map feeds one exit head only writes the pooled means (conv3x3_s2), 0: never
 int& opt_conv_s2();            // 1: plain 3x3 stride-2 convs run in conv3x3_s2 (2 = without its minimum-grid rule: tests), 0: conv_igemm_wide
+int& opt_conv_seam();          // 1: expand conv + residual of Bottleneck k and the reduce conv of Bottleneck k+1 run as one conv1x1_seam launch (2 = without its minimum-grid rule: tests), 0: two launches
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
 int& opt_splitk();             // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch
 int& opt_dense_exact();        // 1: hidden dense layers on the exact-f32 MFMA instead of the split-fp16 form

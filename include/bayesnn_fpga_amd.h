@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BMI_VERSION 500
+#define BMI_VERSION 510
 
 #define BMI_OK 0
 #define BMI_ERR_INVALID (-22)      /* EINVAL: bad descriptor / argument            */
@@ -312,7 +312,8 @@ int bmi_profile_read(bmi_handle h, double ms[BMI_PROFILE_SLOTS], int64_t launche
 #define BMI_CONV_FAMILY_STREAM 4 /* conv1x1_stream_kernel */
 #define BMI_CONV_FAMILY_S2 5    /* conv3x3_s2_kernel */
 #define BMI_CONV_FAMILY_SPLIT 6 /* conv_split_kernel (the split engines; FLOPs = algorithmic, i.e. one third of the MFMA work) */
-#define BMI_CONV_FAMILIES 7
+#define BMI_CONV_FAMILY_SEAM 7  /* conv1x1_seam_kernel (two 1x1 convs of neighbouring Bottlenecks in one launch; FLOPs and bytes of both) */
+#define BMI_CONV_FAMILIES 8
 int bmi_profile_conv_families(bmi_handle h, double ms[BMI_CONV_FAMILIES], int64_t launches[BMI_CONV_FAMILIES],
                               double flops[BMI_CONV_FAMILIES], double bytes[BMI_CONV_FAMILIES]);
 
@@ -352,6 +353,15 @@ int bmi_conv_igemm_fwd(const void* in, const void* in_keep_bits, float out_mul, 
 int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2, const void* weight2, const float* bias,
                              void* out, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t cin2,
                              int32_t relu, bmi_stream stream);
+
+/* The seam between two Bottleneck blocks as one launch (csrc/conv1x1_seam.hip): out_wide = relu(bn3(conv1x1(in; weight3)) + res) [n][h][w][cw] and
+ * out_narrow = relu1?(bn1(conv1x1(out_wide; weight1))) [n][h][w][cn], the second conv fed from the tile the first has just produced (out_wide
+ * is written, not read back).  cmid % 64 == 0, cmid <= 512, cw % 128 == 0, cn = 128 | 256; other shapes run as the two launches.  Bit-identical
+ * to bmi_conv_igemm_fwd twice.  Replaces conv3 + bn3 + shortcut add + ReLU of one Bottleneck and conv1 + bn1 + ReLU of the next (the
+ * Bottleneck form of SA/models/resnet18/resnet18.py:51-85; BASELINE configs[4]). */
+int bmi_conv1x1_seam_fwd(const void* in, const void* weight3, const float* scale3, const float* bias3, const void* res, void* out_wide,
+                         const void* weight1, const float* scale1, const float* bias1, void* out_narrow, int32_t n, int32_t h, int32_t w,
+                         int32_t cmid, int32_t cw, int32_t cn, int32_t relu1, bmi_stream stream);
 
 /* Two convolutions that read the SAME input with the same geometry, as one launch of the 256 x 256-tile kernel:
  * out_a = relu?(bn_a(conv(in; weight_a))) [..][cout_a], out_b likewise [..][cout_b].  cout_a % 128 == 0,

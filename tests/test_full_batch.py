@@ -182,6 +182,36 @@ def test_lazy_planar_layout_is_bit_for_bit_the_nhwc_one(name, batch, T):
     assert torch.equal(out[1], out[0]) and float(out[1][1].max()) > 0
 
 
+@pytest.mark.parametrize("seam", [1, 2, 3])
+def test_bottleneck_seam_launch_is_bit_for_bit_the_two_launches(seam):
+    """conv1x1_seam in the engine (ResNet-50 multi-exit: conv3 + shortcut add + ReLU of one Bottleneck and conv1 of the next in one launch,
+    csrc/conv1x1_seam.hip) against the same engine with "conv_seam" = 0: equal moment buffers, bit for bit.  1 = the default (128 narrow
+    channels: layer2; this small plan's grids are under the kernel's minimum, so the launches fall back — the merged op must still run both
+    convs), 2 = every seam the kernel can take, no minimum grid, 3 = ... with the unpipelined loop."""
+    from bayesnn_fpga_amd import _lib
+    cls, _, kw, _ = CONFIGS["resnet50_block_exit"]
+    m = build_seeded(cls, kw)
+    synthetic_weights_(m, 0)
+    batch, T = 24, 3
+    x = synthetic_images(batch, seed=1234).to(DEV)
+    out = {}
+    for arm in (seam, 0):
+        _lib.set_option("conv_seam", arm)
+        try:
+            eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=batch, chunk_samples=T)       # (created under the option)
+            out[arm] = eng.accumulate(x, eng.new_moments(batch), 0, T, seed=7).clone()
+            torch.cuda.synchronize()
+            eng.profile(True)
+            eng.accumulate(x, eng.new_moments(batch), 0, T, seed=7)
+            eng.profile_read()
+            eng.profile(False)
+            assert ("conv1x1_seam_kernel" in eng.conv_families) == (arm >= 2), eng.conv_families.keys()
+        finally:
+            _lib.set_option("conv_seam", 1)
+        m._engines = {}
+    assert torch.equal(out[seam], out[0]) and float(out[seam][1].max()) > 0
+
+
 def test_p_one_drops_everything_like_the_reference():
     """dropout_p = 1.0 (F.dropout zeroes every element): the drop-all path of every site kernel.  Block sites zero the stage outputs, exit
     sites the pooled features: every logit is its classifier's bias, the predictive mean softmax(bias) for every image, the variance 0 —

@@ -827,6 +827,45 @@ def test_conv1x1_stream_kernel(cin, cout, H, stride, n, dt, use_res, use_site):
     assert torch.equal(out.view(torch.int16), out_other.view(torch.int16))
 
 
+@pytest.mark.parametrize("cmid,cw,cn,H,n,dt", [(128, 512, 128, 16, 37, "f16"), (256, 1024, 256, 8, 131, "f16"), (128, 512, 128, 5, 7, "f16"),
+                                               (64, 256, 128, 16, 3, "bf16"), (256, 1024, 256, 3, 25, "bf16"), (512, 2048, 512, 4, 40, "f16")])
+def test_conv1x1_seam_equals_the_two_launches(cmid, cw, cn, H, n, dt):
+    """conv1x1_seam (expand conv + residual + ReLU of one Bottleneck and the reduce conv of the next in one launch, the wide tensor fed to
+    the second GEMM from LDS) against the chain it replaces: both tensors bit for bit (the same epilogue code for the wide tensor, the same
+    K order for the narrow one), ragged pixel counts (H x H x n not a multiple of the 128-pixel tile), and the fp32 reference.  The last
+    shape (512 output channels) is outside the kernel: the entry point runs the two launches itself."""
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = _gen(43)
+    m = torch.randn(n, H, H, cmid, generator=g).to(tdt).to(DEV)
+    res = torch.randn(n, H, H, cw, generator=g).to(tdt).to(DEV)
+    w3 = (torch.randn(cw, 1, 1, cmid, generator=g) * (2.0 / cmid) ** 0.5).to(tdt).to(DEV)
+    w1 = (torch.randn(cn, 1, 1, cw, generator=g) * (2.0 / cw) ** 0.5).to(tdt).to(DEV)
+    s3, b3 = (0.5 + torch.rand(cw, generator=g)).to(DEV), (0.2 * torch.randn(cw, generator=g)).to(DEV)
+    s1, b1 = (0.5 + torch.rand(cn, generator=g)).to(DEV), (0.2 * torch.randn(cn, generator=g)).to(DEV)
+    y = torch.full((n, H, H, cw), float("nan"), dtype=tdt, device=DEV)
+    z = torch.full((n, H, H, cn), float("nan"), dtype=tdt, device=DEV)
+    lib = _lib.lib()
+    if dt == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    try:
+        _lib.set_option("conv_seam", 2)            # no minimum grid
+        _lib.check(lib.bmi_conv1x1_seam_fwd(gh.ptr(m), gh.ptr(w3), gh.ptr(s3), gh.ptr(b3), gh.ptr(res), gh.ptr(y), gh.ptr(w1), gh.ptr(s1), gh.ptr(b1),
+                                            gh.ptr(z), n, H, H, cmid, cw, cn, 1, gh.stream()), "bmi_conv1x1_seam_fwd")
+        torch.cuda.synchronize()
+        y2 = gh.run_conv(m, w3, s3, b3, res, True, 1, 0, n, n, n, out_dtype=tdt)
+        z2 = gh.run_conv(y2, w1, s1, b1, None, True, 1, 0, n, n, n, out_dtype=tdt)
+    finally:
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+        _lib.set_option("conv_seam", 1)
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    assert torch.equal(z.view(torch.int16), z2.view(torch.int16))
+    ref_y = gh.conv_ref(m, w3, s3, b3, res, True, 1, 0, n, n, n)
+    ref_z = gh.conv_ref(ref_y.permute(0, 2, 3, 1).to(tdt), w1, s1, b1, None, True, 1, 0, n, n, n)
+    tol = 2e-3 if dt == "f16" else 1e-2
+    torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref_y, rtol=tol, atol=tol)
+    torch.testing.assert_close(z.float().cpu().permute(0, 3, 1, 2), ref_z, rtol=4 * tol, atol=4 * tol)
+
+
 @pytest.mark.parametrize("in_f32", [0, 1])
 def test_dense_split_fp16_is_fp32_equivalent(in_f32):
     """The default dense kernel multiplies fp16 head + tail pairs on the fp16 MFMA (fp32 accumulation); against the exact-f32

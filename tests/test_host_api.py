@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.bmi_version() == _lib.ABI_VERSION == 500
+    assert lib.bmi_version() == _lib.ABI_VERSION == 510
     assert _lib.error_string(0) == "ok" and "workspace" in _lib.error_string(-12)
 
 
