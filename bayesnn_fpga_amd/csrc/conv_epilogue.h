@@ -276,6 +276,12 @@ typedef _Float16 half8_e __attribute__((ext_vector_type(8)));
 #ifndef BMI_ABL_NORES
 #define BMI_ABL_NORES 0      // the lite epilogue neither fetches nor adds the residual
 #endif
+#ifndef BMI_EPI_NT_RES
+#define BMI_EPI_NT_RES 0     // 1: epilogue_lite's residual DMA carries the non-temporal hint (A/B)
+#endif
+#ifndef BMI_EPI_NT_STORE
+#define BMI_EPI_NT_STORE 0   // 1: the coalesced epilogues' stores carry the non-temporal hint (A/B)
+#endif
 #ifndef BMI_ABL_NOSTORE
 #define BMI_ABL_NOSTORE 0    // the plain / lite epilogues store nothing
 #endif
@@ -391,7 +397,8 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, ACC& acc, char
         if (!offmap(pl, off) || BMI_ABL_NOSTORE) continue;
         half8_e v = o[it];
         if (it & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);   // (pl >> 4) & 1 == it & 1: quads swapped
-        *(half8_e*)(a.out + off + ch0 + 8 * k) = v;
+        if constexpr (BMI_EPI_NT_STORE) __builtin_nontemporal_store(v, (half8_e*)(a.out + off + ch0 + 8 * k));
+        else *(half8_e*)(a.out + off + ch0 + 8 * k) = v;
     }
 }
 
@@ -518,7 +525,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
                          : a.res;   // rows beyond the tensor are never stored
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds + (i * 256 + wave * 64) * 16), 16, 0, BMI_EPI_NT_RES ? 2 : 0);
         }
     }
     philox4 mine[TJ / 2];
@@ -620,7 +627,7 @@ __device__ __forceinline__ void epilogue_lite(const ConvArgs& a, ACC& acc, char*
         const int pl = (tid >> 4) + 16 * it;
         size_t off;
         if (!offmap(pl, off) || BMI_ABL_NOSTORE) continue;
-        if constexpr (NT_OUT) __builtin_nontemporal_store(o[it], (half8_e*)(a.out + off + ch0 + 8 * k));     // (conv1x1_seam: a streamed tensor must not evict the tile's re-read operands from L2)
+        if constexpr (NT_OUT || BMI_EPI_NT_STORE) __builtin_nontemporal_store(o[it], (half8_e*)(a.out + off + ch0 + 8 * k));     // (conv1x1_seam: a streamed tensor must not evict the tile's re-read operands from L2)
         else *(half8_e*)(a.out + off + ch0 + 8 * k) = o[it];
     }
 }
@@ -778,7 +785,8 @@ __device__ __forceinline__ void epilogue_coalesced(const ConvArgs& a, ACC& acc, 
             half8_e o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = a16_from_f32<BF>(v[e]);
-            *(half8_e*)(a.out + px.out_off + c8) = o;
+            if constexpr (BMI_EPI_NT_STORE) __builtin_nontemporal_store(o, (half8_e*)(a.out + px.out_off + c8));
+            else *(half8_e*)(a.out + px.out_off + c8) = o;
         }
     }
 }

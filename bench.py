@@ -132,7 +132,7 @@ def hbm_traffic(workload, launches_per_step, family=None):
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     if not os.path.exists(path):
         return None, None
-    allk = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw", "conv3x3_s2", "conv1x1_stream", "conv_split"))}
+    allk = {k: v for k, v in json.load(open(path))["kernels"].items() if k.startswith(("conv_igemm", "conv3x3_patch", "conv3x3_pw", "conv3x3_s2", "conv1x1_stream", "conv1x1_seam", "conv_split"))}
     n_all = sum(v["launches"] for v in allk.values())
     if n_all == 0 or n_all % launches_per_step:
         return None, None                   # collected for another batch / T / chunking: do not quote it

@@ -828,7 +828,8 @@ def test_conv1x1_stream_kernel(cin, cout, H, stride, n, dt, use_res, use_site):
 
 
 @pytest.mark.parametrize("cmid,cw,cn,H,n,dt", [(128, 512, 128, 16, 37, "f16"), (256, 1024, 256, 8, 131, "f16"), (128, 512, 128, 5, 7, "f16"),
-                                               (64, 256, 128, 16, 3, "bf16"), (256, 1024, 256, 3, 25, "bf16"), (512, 2048, 512, 4, 40, "f16")])
+                                               (64, 256, 128, 16, 3, "bf16"), (256, 1024, 256, 3, 25, "bf16"), (512, 2048, 512, 4, 40, "f16"),
+                                               (128, 512, 128, 16, 9, "bf16"), (128, 1024, 128, 7, 11, "f16")])
 def test_conv1x1_seam_equals_the_two_launches(cmid, cw, cn, H, n, dt):
     """conv1x1_seam (expand conv + residual + ReLU of one Bottleneck and the reduce conv of the next in one launch, the wide tensor fed to
     the second GEMM from LDS) against the chain it replaces: both tensors bit for bit (the same epilogue code for the wide tensor, the same
