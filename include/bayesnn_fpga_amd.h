@@ -359,7 +359,8 @@ int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2
 
 /* The seam between two Bottleneck blocks as one launch (csrc/conv1x1_seam.hip): out_wide = relu(bn3(conv1x1(in; weight3)) + res) [n][h][w][cw] and
  * out_narrow = relu1?(bn1(conv1x1(out_wide; weight1))) [n][h][w][cn], the second conv fed from the tile the first has just produced (out_wide
- * is written, not read back).  cmid % 64 == 0, cmid <= 512, cw % 128 == 0, cn = 128 | 256; other shapes run as the two launches.  Bit-identical
+ * is written, not read back).  cmid % 64 == 0, cmid <= 512, cw % 128 == 0, cn = 128 (256 too under "conv_seam" >= 2: slower than the
+ * two launches, kept for the tests); anything else, and launches under the kernel's minimum grid, run as the two launches.  Bit-identical
  * to bmi_conv_igemm_fwd twice.  Replaces conv3 + bn3 + shortcut add + ReLU of one Bottleneck and conv1 + bn1 + ReLU of the next (the
  * Bottleneck form of SA/models/resnet18/resnet18.py:51-85; BASELINE configs[4]). */
 int bmi_conv1x1_seam_fwd(const void* in, const void* weight3, const float* scale3, const float* bias3, const void* res, void* out_wide,
