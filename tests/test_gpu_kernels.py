@@ -867,6 +867,35 @@ def test_conv1x1_seam_equals_the_two_launches(cmid, cw, cn, H, n, dt):
     torch.testing.assert_close(z.float().cpu().permute(0, 3, 1, 2), ref_z, rtol=4 * tol, atol=4 * tol)
 
 
+def test_conv1x1_seam_full_grid_repeats_bit_for_bit():
+    """Race screen for conv1x1_seam's DMA / barrier choreography (three rotating weight slots, counted vmcnt, the residual landing in the
+    buffer stage B has just read): a grid of 6000 tiles (every CU holds two workgroups at different phases for dozens of rounds), five
+    launches, each bit for bit the two-launch chain."""
+    cmid, cw, cn, H, n = 128, 512, 128, 16, 3000
+    g = _gen(47)
+    m = torch.randn(n, H, H, cmid, generator=g).to(torch.float16).to(DEV)
+    res = torch.randn(n, H, H, cw, generator=g).to(torch.float16).to(DEV)
+    w3 = (torch.randn(cw, 1, 1, cmid, generator=g) * (2.0 / cmid) ** 0.5).to(torch.float16).to(DEV)
+    w1 = (torch.randn(cn, 1, 1, cw, generator=g) * (2.0 / cw) ** 0.5).to(torch.float16).to(DEV)
+    s3, b3 = (0.5 + torch.rand(cw, generator=g)).to(DEV), (0.2 * torch.randn(cw, generator=g)).to(DEV)
+    s1, b1 = (0.5 + torch.rand(cn, generator=g)).to(DEV), (0.2 * torch.randn(cn, generator=g)).to(DEV)
+    lib = _lib.lib()
+    _lib.set_option("conv_seam", 0)
+    try:
+        y2 = gh.run_conv(m, w3, s3, b3, res, True, 1, 0, n, n, n)
+        z2 = gh.run_conv(y2, w1, s1, b1, None, True, 1, 0, n, n, n)
+    finally:
+        _lib.set_option("conv_seam", 1)
+    for rep in range(5):
+        y = torch.full((n, H, H, cw), float("nan"), dtype=torch.float16, device=DEV)
+        z = torch.full((n, H, H, cn), float("nan"), dtype=torch.float16, device=DEV)
+        _lib.check(lib.bmi_conv1x1_seam_fwd(gh.ptr(m), gh.ptr(w3), gh.ptr(s3), gh.ptr(b3), gh.ptr(res), gh.ptr(y), gh.ptr(w1), gh.ptr(s1), gh.ptr(b1),
+                                            gh.ptr(z), n, H, H, cmid, cw, cn, 1, gh.stream()), "bmi_conv1x1_seam_fwd")
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), rep
+        assert torch.equal(z.view(torch.int16), z2.view(torch.int16)), rep
+
+
 @pytest.mark.parametrize("in_f32", [0, 1])
 def test_dense_split_fp16_is_fp32_equivalent(in_f32):
     """The default dense kernel multiplies fp16 head + tail pairs on the fp16 MFMA (fp32 accumulation); against the exact-f32
