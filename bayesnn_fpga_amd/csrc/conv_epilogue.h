@@ -217,16 +217,18 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs& a, const PixelCtx&
 // arithmetic and order of epilogue_quad, fp32 residual row (`resp`, or null), the finished quad left in v[] for the caller's store.
 // (rq: the four residual VALUES of the quad, added when has_res — a flag, not a null pointer: a select between a local array's address
 //  and null sends the array to scratch)
-__device__ __forceinline__ void epilogue_quad_f32v(const ConvArgs& a, const PixelCtx& p, const float* rq, bool has_res, float v[4], int c4) {
-    if (a.scale) {
-        const float4 s4 = *(const float4*)(a.scale + c4);
+// (sc / bi: the folded-BN vectors indexed by c4 — a.scale / a.bias, or the second conv's of a pair launch moved back by the launch's split)
+__device__ __forceinline__ void epilogue_quad_f32sb(const ConvArgs& a, const float* sc, const float* bi, const PixelCtx& p, const float* rq, bool has_res,
+                                                    float v[4], int c4) {
+    if (sc) {
+        const float4 s4 = *(const float4*)(sc + c4);
         v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
     } else if (a.out_mul != 1.f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
     }
-    if (a.bias) {
-        const float4 b4 = *(const float4*)(a.bias + c4);
+    if (bi) {
+        const float4 b4 = *(const float4*)(bi + c4);
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
     }
     float m[4];
@@ -248,6 +250,9 @@ __device__ __forceinline__ void epilogue_quad_f32v(const ConvArgs& a, const Pixe
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = m[e] == 0.f ? 0.f : v[e] * m[e];
     }
+}
+__device__ __forceinline__ void epilogue_quad_f32v(const ConvArgs& a, const PixelCtx& p, const float* rq, bool has_res, float v[4], int c4) {
+    epilogue_quad_f32sb(a, a.scale, a.bias, p, rq, has_res, v, c4);
 }
 __device__ __forceinline__ void epilogue_quad_f32(const ConvArgs& a, const PixelCtx& p, const float* resp, float v[4], int c4) {
     float rq[4] = {0.f, 0.f, 0.f, 0.f};

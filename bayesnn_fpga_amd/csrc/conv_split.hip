@@ -117,7 +117,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int q0 = 512 * i + (TI == 1 ? 256 * (wave >> 2) : 0), plane = q0 / (4 * CT), row0 = (q0 - plane * 4 * CT) >> 2;
-        wbase[i] = (const char*)(a.wgt + ((size_t)plane * a.Cout + ch0 + row0) * Ktot);
+        // pair mode (two convs on one input in one launch, kernels.h): the rows from a.split on are the second conv's, from its own planes
+        const int rowg = ch0 + row0;
+        if (a.wgt_b && rowg >= a.split) wbase[i] = (const char*)(a.wgt_b + ((size_t)plane * (a.Cout - a.split) + rowg - a.split) * Ktot);
+        else wbase[i] = (const char*)(a.wgt + ((size_t)plane * (a.wgt_b ? a.split : a.Cout) + rowg) * Ktot);
     }
 #define SP_ISSUE_W1(I, KOFF, ST) SP_GLDS16S(woff_l, wbase[I] + (SP_ABL_NOW ? 0 : 2 * (KOFF)), (ST) + ((I) * 512 + wave * 64) * 16)
 
@@ -353,9 +356,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
                 pair_decode<BF, 4>(rp + 4, rb);
             }
             float va[4] = {r0[0], r0[1], r0[2], r0[3]}, vb[4] = {r1[0], r1[1], r1[2], r1[3]};
-            epilogue_quad_f32v(a, p, ra, a.res != nullptr, va, c8);
-            epilogue_quad_f32v(a, p, rb, a.res != nullptr, vb, c8 + 4);
-            _Float16* op = a.out + pair32_off((size_t)n * HoWo + rem, a.Cout, c8);
+            // pair mode: channels from a.split on belong to the second conv (its BN vectors moved back by the split, its own output tensor)
+            const bool second = a.wgt_b && c8 >= a.split;
+            const float* const sc = second ? a.scale_b - a.split : a.scale;
+            const float* const bi = second ? a.bias_b - a.split : a.bias;
+            epilogue_quad_f32sb(a, sc, bi, p, ra, a.res != nullptr, va, c8);
+            epilogue_quad_f32sb(a, sc, bi, p, rb, a.res != nullptr, vb, c8 + 4);
+            _Float16* op = second ? a.out_b + pair32_off((size_t)n * HoWo + rem, a.Cout - a.split, c8 - a.split)
+                                  : a.out + pair32_off((size_t)n * HoWo + rem, a.wgt_b ? a.split : a.Cout, c8);
             const float v8[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
             pair_encode<BF, 8>(op, v8);
         }
@@ -382,7 +390,11 @@ bool conv_takes_split_kernel(int cin, int cout) { return cin % 32 == 0 && cout %
 // a.in / a.res / a.out: pair32 tensors (conv_epilogue.h); a.wgt: 16-bit [2][Cout][k*k*Cin] head / tail planes
 int launch_conv_split(const ConvArgs& a, int bf16, hipStream_t s) {
     if (!conv_takes_split_kernel(a.Cin, a.Cout)) return BMI_ERR_UNSUPPORTED;
-    if (a.in2 || a.wgt_b || a.in_bits || a.in2_bits || a.pool || a.pool_b || a.partial || a.imap) return BMI_ERR_UNSUPPORTED;
+    if (a.in2 || a.in_bits || a.in2_bits || a.pool || a.pool_b || a.partial || a.imap) return BMI_ERR_UNSUPPORTED;
+    // pair mode: both convs plain (BN + ReLU), the split on a 128-row block of the weight DMA, both outputs whole 32-channel blocks
+    if (a.wgt_b && (!a.out_b || a.split <= 0 || a.split >= a.Cout || a.split % 128 != 0 || (a.Cout - a.split) % 128 != 0 || a.res || a.site.kind != BMI_SITE_NONE ||
+                    !a.scale || !a.bias || !a.scale_b || !a.bias_b))
+        return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
     return bf16 ? launch_split_t<true>(a, s) : launch_split_t<false>(a, s);
 }

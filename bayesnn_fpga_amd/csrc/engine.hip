@@ -549,7 +549,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     // in between).  BMI_CONV_PAIR=0 keeps them separate (A/B, tests).
     {
         const char* env = std::getenv("BMI_CONV_PAIR");
-        const bool enable = (!env || std::atoi(env) != 0) && !e->f32;
+        const bool enable = (!env || std::atoi(env) != 0) && (!e->f32 || e->split);      // (the exact engine's kernel has no pair mode)
         auto plain = [&](const OpInfo& c) {
             return c.d.kind == BMI_OP_CONV && !c.has_pair && c.d.residual < 0 && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE &&
                    c.bits_tensor < 0 && c.out_mul == 1.f && c.d.scale && c.d.bias;
@@ -565,6 +565,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     Bo.d.pad != A.d.pad || Bo.d.relu != A.d.relu)
                     continue;
                 if (A.cout % 128 != 0 || !conv_takes_wide_kernel(ti.c, A.cout + Bo.cout)) continue;
+                if (e->split && Bo.cout % 128 != 0) continue;
                 e->suffix[i].has_pair = true;
                 e->suffix[i].pair_d = Bo.d;
                 e->suffix[i].pair_cout = Bo.cout;
@@ -945,10 +946,25 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             };
             if (e->f32) {   // the exact / split engines: one generic kernel each (a.in / a.res / a.out hold fp32)
                 if (!e->split) { prof.tag(-1, 0, 0); return launch_conv_exact(a, s); }
-                const double fl = 2.0 * N * op.ho * op.wo * (double)op.cout * d.ksize * d.ksize * tin.c;
+                const int cout_l = op.cout + (op.has_pair ? op.pair_cout : 0);      // pair mode: two convs on this input in one launch (the 256-channel tile)
+                const double fl = 2.0 * N * op.ho * op.wo * (double)cout_l * d.ksize * d.ksize * tin.c;
                 auto tb = [&](int id) { const TensorInfo& t = e->tensors[id]; return 4.0 * (t.stoch ? N : B) * t.h * t.w * t.c; };
-                prof.tag(BMI_CONV_FAMILY_SPLIT, fl, tb(d.in) + 4.0 * N * op.ho * op.wo * (double)op.cout + 4.0 * (double)op.cout * d.ksize * d.ksize * tin.c +
+                prof.tag(BMI_CONV_FAMILY_SPLIT, fl, tb(d.in) + 4.0 * N * op.ho * op.wo * (double)cout_l + 4.0 * (double)cout_l * d.ksize * d.ksize * tin.c +
                                                     (d.residual >= 0 ? tb(d.residual) : 0.0));
+                if (op.has_pair) {
+                    ConvArgs p = a;
+                    p.wgt_b = (const _Float16*)op.pair_d.weight;
+                    p.scale_b = op.pair_d.scale; p.bias_b = op.pair_d.bias;
+                    p.out_b = (_Float16*)(ws + e->tensors[op.pair_d.out].offset);
+                    p.split = op.cout;
+                    p.Cout = cout_l;
+                    const int rcp = launch_conv_split(p, e->split == 2, s);
+                    if (rcp != BMI_ERR_UNSUPPORTED) return rcp;
+                    ConvArgs q = a;          // not taken: two launches
+                    q.wgt = p.wgt_b; q.scale = p.scale_b; q.bias = p.bias_b; q.out = p.out_b; q.Cout = op.pair_cout;
+                    const int rc1 = launch_conv_split(a, e->split == 2, s);
+                    return rc1 != BMI_OK ? rc1 : launch_conv_split(q, e->split == 2, s);
+                }
                 return launch_conv_split(a, e->split == 2, s);
             }
             double flops = 2.0 * N * op.ho * op.wo * (double)(op.cout + (op.has_pair ? op.pair_cout : 0)) * d.ksize * d.ksize * tin.c;
@@ -1453,6 +1469,8 @@ int bmi_conv_pair_fwd(const void* in, const void* weight_a, const float* scale_a
     a.M = n * a.Ho * a.Wo;
     a.B = n; a.out_mul = 1.f;
     a.site = resolve_site(nullptr, 0, 0);
+    if (opt_unit_dtype() == BMI_DTYPE_F32) return BMI_ERR_UNSUPPORTED;
+    if (unit_f32act()) return launch_conv_split(a, opt_unit_dtype() == BMI_DTYPE_BF16X3, (hipStream_t)stream);     // (pair32 tensors, head / tail weight planes)
     const int rc = launch_conv3x3_s2(a, (hipStream_t)stream);      // the engine's order: conv3x3_s2 where it applies, else conv_igemm_wide
     return rc != BMI_ERR_UNSUPPORTED ? rc : launch_conv_igemm_wide(a, (hipStream_t)stream);
 }

@@ -180,6 +180,37 @@ def test_split_stem_mask_maxpool_head_and_dense_on_pair32(split_entries):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,ca,cb,H,k,stride,n", [(64, 128, 128, 32, 3, 2, 21), (128, 128, 128, 16, 3, 2, 9), (64, 128, 384, 8, 1, 1, 70)])
+def test_split_pair_launch_equals_the_two_launches(split_entries, cin, ca, cb, H, k, stride, n):
+    """Pair mode of conv_split (two plain convs on one input in one launch: layerN[0].conv1 and the first conv of the exit head in front of
+    it, on the 256-channel tile instead of two 128-channel ones): both outputs bit for bit the single launches' (the same K order per
+    accumulator), through bmi_conv_pair_fwd under the split unit dtypes."""
+    dt = split_entries
+    t16 = TORCH16[dt]
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    pad = k // 2
+    x = torch.randn(n, H, H, cin, generator=g).to(DEV)
+    ho = (H + 2 * pad - k) // stride + 1
+    outs = {}
+    ws, ss, bs = [], [], []
+    for co in (ca, cb):
+        w = (torch.randn(co, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5)
+        ws.append(w)
+        ss.append((0.5 + torch.rand(co, generator=g)).to(DEV))
+        bs.append((0.2 * torch.randn(co, generator=g)).to(DEV))
+    single = [_run_split(x, ws[i].to(DEV), dt, ss[i], bs[i], None, True, stride, pad, n, n, n) for i in range(2)]
+    xp = gh.pair32_encode(x, t16)
+    wp = [split_planes(w, dt).to(DEV) for w in ws]
+    oa = torch.full((n, ho, ho, ca // 32, 2, 32), float("nan"), dtype=t16, device=DEV)
+    ob = torch.full((n, ho, ho, cb // 32, 2, 32), float("nan"), dtype=t16, device=DEV)
+    _lib.check(lib.bmi_conv_pair_fwd(gh.ptr(xp), gh.ptr(wp[0]), gh.ptr(ss[0]), gh.ptr(bs[0]), gh.ptr(oa), gh.ptr(wp[1]), gh.ptr(ss[1]), gh.ptr(bs[1]),
+                                     gh.ptr(ob), n, n, H, H, cin, ca, cb, k, stride, pad, 1, gh.stream()), "bmi_conv_pair_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(gh.pair32_decode(oa), single[0]) and torch.equal(gh.pair32_decode(ob), single[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["elementwise", "channel", "masksemble"])
 def test_split_conv_fused_site_is_bit_exact_on_the_mask(kind, split_entries):
     dt = split_entries
