@@ -122,7 +122,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         if (a.wgt_b && rowg >= a.split) wbase[i] = (const char*)(a.wgt_b + ((size_t)plane * (a.Cout - a.split) + rowg - a.split) * Ktot);
         else wbase[i] = (const char*)(a.wgt + ((size_t)plane * (a.wgt_b ? a.split : a.Cout) + rowg) * Ktot);
     }
-#define SP_ISSUE_W1(I, KOFF, ST) SP_GLDS16S(woff_l, wbase[I] + (SP_ABL_NOW ? 0 : 2 * (KOFF)), (ST) + ((I) * 512 + wave * 64) * 16)
+    // fused 1x1 strided shortcut (ConvArgs::in2 / wgt2: the BasicBlock downsample path as Cin2 / 32 extra K-steps behind the conv's own, both BN
+    // scales folded into the weight planes by the host): the same pieces from wgt2's planes [2][Cout][Cin2] — another row pitch, so another
+    // lane offset; which of the two a K-step uses is a scalar select (SP_SC(): the request state has run past the conv's own K-steps)
+    const uint32_t woff2_l = (uint32_t)(((tid >> 2) & (TI == 1 ? 63 : 127)) * a.Cin2 + (((tid & 3) ^ ((tid >> 4) & 3)) << 3)) * 2u;
+    const char* wbase2[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int q0 = 512 * i + (TI == 1 ? 256 * (wave >> 2) : 0), plane = q0 / (4 * CT), row0 = (q0 - plane * 4 * CT) >> 2;
+        wbase2[i] = a.in2 ? (const char*)(a.wgt2 + ((size_t)plane * a.Cout + ch0 + row0) * a.Cin2) : wbase[i];
+    }
+#define SP_ISSUE_W1(I, KOFF, ST)                                                                         \
+    SP_GLDS16S(SP_SC() ? woff2_l : woff_l, (SP_SC() ? wbase2[I] : wbase[I]) + (SP_ABL_NOW ? 0 : 2 * (KOFF)), (ST) + ((I) * 512 + wave * 64) * 16)
 
     // ---- input DMA: piece q = tid + 512 i (i < 4) of the slot's image: tile row (pixel) (tid >> 3) + 64 i, 16-byte slot tid & 7 of its
     // 128-byte line (slots 0-3: the heads of the K-step's 32 channels, 4-7: the tails), read from source slot (tid & 7) ^ ((row >> 1) & 7)
@@ -130,6 +141,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     // (0, 0), chunk 0 — outside the image where the padding says so, never dereferenced there: a K-step adds its wave-uniform offset and
     // fetches from a page of zeros instead when its tap is out of bounds (a select, no branch)
     const _Float16* xorg[4];
+    const _Float16* x2org[4];         // (fused shortcut) the pixel's line in in2 at chunk 0, or the page of zeros for a row beyond M
     int iy0[4], ix0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -143,12 +155,16 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         ix0[i] = ox * a.stride - a.pad;
         xorg[i] = a.in + ((long)(n % a.in_mod) * a.H * a.W + (long)(oy * a.stride - a.pad) * a.W + ix0[i]) * (2 * a.Cin) +
                   (((tid & 7) ^ ((tid >> 4) & 7)) << 3);
+        x2org[i] = (a.in2 && vm) ? a.in2 + ((long)(n % a.in2_mod) * a.H2 * a.W2 + (long)(oy * a.stride2) * a.W2 + ox * a.stride2) * (2 * a.Cin2) +
+                                       (((tid & 7) ^ ((tid >> 4) & 7)) << 3)
+                                 : nullptr;
     }
 #define SP_ISSUE_X1(I, KY, KX, C0, ST)                                                                   \
     {                                                                                                    \
         const bool ok_ = (unsigned)(iy0[I] + (KY)) < (unsigned)a.H && (unsigned)(ix0[I] + (KX)) < (unsigned)a.W;   \
         const long so_ = (long)((KY) * a.W + (KX)) * (2 * a.Cin) + 2 * min((C0), a.Cin - 32);          /* (C0 = Cin: past the last K-step) */ \
         const _Float16* p_ = (ok_ && !SP_ABL_NOX) ? xorg[I] + so_ : (const _Float16*)g_split_zero + ((tid & 7) << 3);                  \
+        if (SP_SC()) p_ = x2org[I] ? x2org[I] + 2 * min(c2, a.Cin2 - 32) : (const _Float16*)g_split_zero + ((tid & 7) << 3);           \
         SP_GLDS16V(p_, (ST) + ((I) * 512 + wave * 64) * 16);                                             \
     }
 
@@ -200,11 +216,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);             \
     }
 
-    const int nK = a.ksize * a.ksize * (a.Cin / 32);
+    const int nK = a.ksize * a.ksize * (a.Cin / 32) + (a.in2 ? a.Cin2 / 32 : 0);
     // (ky, kx, c0) of the K-step whose operands are requested next.  Every step requests (at the end: clamped, unused), so the number of
     // DMA pieces in flight — what the counted vmcnt waits below rely on — never changes
-    int ky = 0, kx = 0, c0 = 0;
-    auto advance = [&]() {            // scalar selects, no branch; runs past the last K-step (c0 = Cin) at the end: the requests of
+    int ky = 0, kx = 0, c0 = 0, c2 = 0;        // c2: channel offset of the fused shortcut's K-step, once c0 has reached Cin
+#define SP_SC() (a.in2 != nullptr && c0 >= a.Cin)
+    auto advance = [&]() {
+        const bool past = c0 >= a.Cin;          // the conv's own K-steps are all requested: the shortcut's chunks follow (or clamped, unused requests)
+        c2 += past ? 32 : 0;            // scalar selects, no branch; runs past the last K-step (c0 = Cin) at the end: the requests of
 #if SP_TAP_MAJOR                      // those steps are clamped to valid addresses and never used
         const int c1 = c0 + 32;
         const bool wrapc = c1 == a.Cin;
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         // K order: 32-channel chunk outer, tap inner.  The k*k K-steps of a chunk read the SAME 128-byte lines of the tile's pixels
         // and their halo (a tap is a shift by whole pixels), so all but the first find them in L1 / L2; tap-major, a line came back
         // Cin / 32 K-steps later, behind 32 KB x Cin / 32 of other input per workgroup — beyond an XCD's L2 share
-        const int kx1 = kx + 1;
+        const int kx1 = kx + (past ? 0 : 1);
         const bool wrapx = kx1 == a.ksize;
         kx = wrapx ? 0 : kx1;
         const int ky1 = ky + (wrapx ? 1 : 0);
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 #endif
     };
     // (the weight offset of (ky, kx, c0), clamped for the K-steps past the end)
-#define SP_KOFF() min((min(ky, a.ksize - 1) * a.ksize + kx) * a.Cin + min(c0, a.Cin - 32), Ktot - 32)
+#define SP_KOFF() (SP_SC() ? min(c2, a.Cin2 - 32) : min((min(ky, a.ksize - 1) * a.ksize + kx) * a.Cin + min(c0, a.Cin - 32), Ktot - 32))
     // all of one K-step's pieces: TI of weights, 4 of input
 #define SP_ISSUE_ALL(SLOT)                                                                               \
     {                                                                                                    \
@@ -303,6 +322,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 #undef SP_MFMA
 #undef SP_BARRIER
 #undef SP_KOFF
+#undef SP_SC
 
     // ---- epilogue, coalesced through LDS (the slots are dead: every wave is behind the loop's last barrier) ---------------------------
     // In two rounds (pixel tile j = 0, 1 of every wave: 128 of the tile's pixels x all CT channels = CT / 2 KB of fp32): the raw
@@ -390,7 +410,11 @@ bool conv_takes_split_kernel(int cin, int cout) { return cin % 32 == 0 && cout %
 // a.in / a.res / a.out: pair32 tensors (conv_epilogue.h); a.wgt: 16-bit [2][Cout][k*k*Cin] head / tail planes
 int launch_conv_split(const ConvArgs& a, int bf16, hipStream_t s) {
     if (!conv_takes_split_kernel(a.Cin, a.Cout)) return BMI_ERR_UNSUPPORTED;
-    if (a.in2 || a.in_bits || a.in2_bits || a.pool || a.pool_b || a.partial || a.imap) return BMI_ERR_UNSUPPORTED;
+    if (a.in_bits || a.in2_bits || a.pool || a.pool_b || a.partial || a.imap) return BMI_ERR_UNSUPPORTED;
+    // fused 1x1 shortcut: in2 a pair32 tensor of Cin2 channels read at stride2 (no padding), wgt2 the planes [2][Cout][Cin2]
+    if (a.in2 && (!a.wgt2 || a.wgt_b || a.Cin2 % 32 != 0 || a.Cin2 <= 0 || a.stride2 < 1 || a.in2_mod <= 0 || (a.Ho - 1) * a.stride2 >= a.H2 ||
+                  (a.Wo - 1) * a.stride2 >= a.W2))
+        return BMI_ERR_UNSUPPORTED;
     // pair mode: both convs plain (BN + ReLU), the split on a 128-row block of the weight DMA, both outputs whole 32-channel blocks
     if (a.wgt_b && (!a.out_b || a.split <= 0 || a.split >= a.Cout || a.split % 128 != 0 || (a.Cout - a.split) % 128 != 0 || a.res || a.site.kind != BMI_SITE_NONE ||
                     !a.scale || !a.bias || !a.scale_b || !a.bias_b))

@@ -382,13 +382,14 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                     in_st = in_st || tr.stoch;
                 }
                 int64_t macs = (int64_t)op.ho * op.wo * op.cout * d.ksize * d.ksize * tin.c;
-                if (d.kind == BMI_OP_CONV && d.in2 >= 0 && e->f32) { rc = BMI_ERR_UNSUPPORTED; break; }   // a speed feature (BN scales folded into 16-bit weights)
+                if (d.kind == BMI_OP_CONV && d.in2 >= 0 && e->f32 && !e->split) { rc = BMI_ERR_UNSUPPORTED; break; }   // a speed feature (BN scales folded into the weights): never in the exact engine
                 if (d.kind == BMI_OP_CONV && d.in2 >= 0) {
                     if (!tensor_ok(d.in2) || !written[d.in2] || d.in2 == 0 || !d.weight2 || d.scale) { rc = BMI_ERR_INVALID; break; }
                     const TensorInfo& t2 = e->tensors[d.in2];
-                    if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || t2.c % 64 != 0 || t2.h % op.ho != 0 ||
-                        t2.h / op.ho != t2.w / op.wo || t2.w % op.wo != 0 ||
-                        !conv_takes_patch_kernel(3, 1, 1, tin.c, op.cout, op.ho, op.wo)) {
+                    if (t2.h % op.ho != 0 || t2.h / op.ho != t2.w / op.wo || t2.w % op.wo != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
+                    // fp16 / bf16: conv3x3_patch / conv3x3_pw carry the shortcut; the split engines: extra K-steps of conv_split (any conv geometry)
+                    if (e->split ? t2.c % 32 != 0
+                                 : (d.ksize != 3 || d.stride != 1 || d.pad != 1 || t2.c % 64 != 0 || !conv_takes_patch_kernel(3, 1, 1, tin.c, op.cout, op.ho, op.wo))) {
                         rc = BMI_ERR_UNSUPPORTED; break;
                     }
                     in_st = in_st || t2.stoch;
@@ -947,10 +948,11 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             if (e->f32) {   // the exact / split engines: one generic kernel each (a.in / a.res / a.out hold fp32)
                 if (!e->split) { prof.tag(-1, 0, 0); return launch_conv_exact(a, s); }
                 const int cout_l = op.cout + (op.has_pair ? op.pair_cout : 0);      // pair mode: two convs on this input in one launch (the 256-channel tile)
-                const double fl = 2.0 * N * op.ho * op.wo * (double)cout_l * d.ksize * d.ksize * tin.c;
+                const int cin2_l = d.in2 >= 0 ? e->tensors[d.in2].c : 0;            // fused 1x1 shortcut: extra K-steps
+                const double fl = 2.0 * N * op.ho * op.wo * (double)cout_l * (d.ksize * d.ksize * tin.c + cin2_l);
                 auto tb = [&](int id) { const TensorInfo& t = e->tensors[id]; return 4.0 * (t.stoch ? N : B) * t.h * t.w * t.c; };
-                prof.tag(BMI_CONV_FAMILY_SPLIT, fl, tb(d.in) + 4.0 * N * op.ho * op.wo * (double)cout_l + 4.0 * (double)cout_l * d.ksize * d.ksize * tin.c +
-                                                    (d.residual >= 0 ? tb(d.residual) : 0.0));
+                prof.tag(BMI_CONV_FAMILY_SPLIT, fl, tb(d.in) + 4.0 * N * op.ho * op.wo * (double)cout_l + 4.0 * (double)cout_l * (d.ksize * d.ksize * tin.c + cin2_l) +
+                                                    (d.residual >= 0 ? tb(d.residual) : 0.0) + (d.in2 >= 0 ? tb(d.in2) : 0.0));
                 if (op.has_pair) {
                     ConvArgs p = a;
                     p.wgt_b = (const _Float16*)op.pair_d.weight;
@@ -1488,6 +1490,8 @@ int bmi_conv3x3_shortcut_fwd(const void* in, const void* weight, const void* in2
     a.in2 = (const _Float16*)in2; a.wgt2 = (const _Float16*)weight2; a.in2_mod = n; a.H2 = 2 * h; a.W2 = 2 * w;
     a.Cin2 = cin2; a.stride2 = 2;
     a.site = resolve_site(nullptr, 0, 0);
+    if (opt_unit_dtype() == BMI_DTYPE_F32) return BMI_ERR_UNSUPPORTED;
+    if (unit_f32act()) return launch_conv_split(a, opt_unit_dtype() == BMI_DTYPE_BF16X3, (hipStream_t)stream);     // (pair32 tensors, head / tail weight planes)
     return launch_conv(a, (hipStream_t)stream);     // conv3x3_pw where it applies, else conv3x3_patch
 }
 

@@ -114,7 +114,7 @@ class GraphBuilder:
             x2, conv_s, bn_s = shortcut
             s_scale, s_bias = fold_bn(bn_s, conv_s.bias)
             wk = wk.float() * scale[:, None, None, None]
-            w2dev = self.dev(conv_s.weight.detach().float()[:, :, 0, 0] * s_scale[:, None], self.act_dtype)   # [Cout][Cin2]
+            w2dev = self.conv_weight(conv_s.weight.detach().float()[:, :, 0, 0] * s_scale[:, None])   # [Cout][Cin2] (split engines: head / tail planes)
             bias = bias + s_bias
             scale = None
             in2 = x2
@@ -182,10 +182,12 @@ def _can_fuse_shortcut(t_in, blk, dtype="f16"):
     (16x16 / 8x8 / 4x4 maps, Cout % 128 == 0) and the block input has a multiple of 64 channels.
     BMI_FUSE_SHORTCUT=0 keeps the separate launch + residual (A/B, tests); the exact engine never fuses (the fusion folds
     the BN scales into the 16-bit weights: a speed feature)."""
-    if os.environ.get("BMI_FUSE_SHORTCUT", "1") == "0" or dtype in _lib.FP32_ACT_DTYPES:
+    if os.environ.get("BMI_FUSE_SHORTCUT", "1") == "0" or dtype == "f32":
         return False
     h, w, c = t_in
     ds = blk.downsample[0]
+    if dtype in _lib.FP32_ACT_DTYPES:       # the split engines: extra K-steps of the generic kernel, whatever the map (csrc/conv_split.hip)
+        return c % 32 == 0 and ds.in_channels % 32 == 0 and ds.kernel_size == (1, 1) and ds.bias is None and ds.padding == (0, 0)
     return ((h, w) in ((16, 16), (8, 8), (4, 4)) and blk.conv2.out_channels % 128 == 0 and c % 64 == 0
             and ds.in_channels % 64 == 0 and ds.kernel_size == (1, 1) and ds.stride == (2, 2) and ds.bias is None)
 

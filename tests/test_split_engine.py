@@ -211,6 +211,35 @@ def test_split_pair_launch_equals_the_two_launches(split_entries, cin, ca, cb, H
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,cin2,H,n", [(128, 128, 64, 16, 5), (256, 256, 128, 8, 37), (512, 512, 256, 4, 70), (64, 64, 32, 6, 3)])
+def test_split_conv_fused_shortcut_against_float64(split_entries, cin, cout, cin2, H, n):
+    """The BasicBlock downsample path as extra K-steps of conv_split (ConvArgs::in2 / wgt2: out = relu(conv3x3(x; w) + conv1x1_stride2(x2; w2) +
+    bias), both BN scales folded into the weight planes) against float64 on the same fp32 operands, ragged pixel counts included."""
+    dt = split_entries
+    t16 = TORCH16[dt]
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, H, H, cin, generator=g)
+    x2 = torch.randn(n, 2 * H, 2 * H, cin2, generator=g)
+    w = torch.randn(cout, 3, 3, cin, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    w2 = torch.randn(cout, cin2, generator=g) * (2.0 / cin2) ** 0.5
+    bias = 0.2 * torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1) + \
+        torch.nn.functional.conv2d(x2.double().permute(0, 3, 1, 2), w2.double()[:, :, None, None], stride=2) + bias.double()[None, :, None, None]
+    ref = torch.relu(ref)
+    out = torch.full((n, H, H, cout // 32, 2, 32), float("nan"), dtype=t16, device=DEV)
+    xp, x2p = gh.pair32_encode(x.to(DEV), t16), gh.pair32_encode(x2.to(DEV), t16)
+    wp, w2p, bd = split_planes(w, dt).to(DEV), split_planes(w2, dt).to(DEV), bias.to(DEV)
+    _lib.check(lib.bmi_conv3x3_shortcut_fwd(gh.ptr(xp), gh.ptr(wp), gh.ptr(x2p), gh.ptr(w2p), gh.ptr(bd), gh.ptr(out), n, H, H, cin, cout, cin2, 1,
+                                            gh.stream()), "bmi_conv3x3_shortcut_fwd")
+    torch.cuda.synchronize()
+    got = gh.pair32_decode(out).double().cpu().permute(0, 3, 1, 2)
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    print(f"{dt} fused shortcut {cin}->{cout} + {cin2}: max err / max|ref| = {err:.2e}")
+    assert torch.isfinite(got).all() and err <= (4e-6 if dt == "f16x2" else 4e-5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["elementwise", "channel", "masksemble"])
 def test_split_conv_fused_site_is_bit_exact_on_the_mask(kind, split_entries):
     dt = split_entries
