@@ -40,16 +40,25 @@ def split_planes(w, dt):
 
 # ---- CPU side ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["f16x2", "bf16x3"])
-def test_split_graph_layout(dt):
-    """Host-only (bmi_create / bmi_plan run on a CPU box): head / tail weight planes, no fused shortcut, fp32 activations in the plan,
-    the same MACs as the fp16 graph; head + tail reproduce the fp32 weight to the split's precision."""
+def test_split_graph_layout(dt, monkeypatch):
+    """Host-only (bmi_create / bmi_plan run on a CPU box): head / tail weight planes, 4-byte (pair32) activations in the plan, the same MACs
+    as the fp16 graph; head + tail reproduce the fp32 weight to the split's precision; the three downsample paths of ResNet-18 ride in
+    their block's conv2 as extra K-steps (in2 / weight2 planes, BN scale folded) unless BMI_FUSE_SHORTCUT = 0."""
     kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
     m = synthetic_weights_(build_seeded(ResNet18MCEarlyExit, kw), 0)
     c16, c32, cs = CompiledGraph(m, "cpu", 8, 2), CompiledGraph(m, "cpu", 8, 2, dtype="f32"), CompiledGraph(m, "cpu", 8, 2, dtype=dt)
-    assert not any(op.get("in2", -1) >= 0 for op in cs.graph.ops)
-    assert cs.workspace_bytes == c32.workspace_bytes
+    fused = [op for op in cs.graph.ops if op.get("in2", -1) >= 0]
+    assert len(fused) == 3 and not any(op.get("in2", -1) >= 0 for op in c32.graph.ops)
+    for op in fused:
+        cout, cin2 = op["weight"].shape[1], cs.graph.tensors[op["in2"]][2]
+        assert op["weight2"].dtype == TORCH16[dt] and tuple(op["weight2"].shape) == (2, cout, cin2) and op["scale"] is None
+    assert abs(cs.workspace_bytes - c32.workspace_bytes) <= 0.1 * c32.workspace_bytes   # (no shortcut tensors, but a block's input lives until its conv2)
     assert cs.prefix_macs + 8 * cs.suffix_macs == c16.prefix_macs + 8 * c16.suffix_macs
-    convs = [(a, b) for a, b in zip(cs.graph.ops, c32.graph.ops) if a["kind"] == _lib.OP_CONV]
+    monkeypatch.setenv("BMI_FUSE_SHORTCUT", "0")
+    cu = CompiledGraph(m, "cpu", 8, 2, dtype=dt)
+    assert not any(op.get("in2", -1) >= 0 for op in cu.graph.ops)
+    assert abs(cu.workspace_bytes - c32.workspace_bytes) <= 0.1 * c32.workspace_bytes    # (4-byte elements; pair launches move two live ranges)
+    convs = [(a, b) for a, b in zip(cu.graph.ops, c32.graph.ops) if a["kind"] == _lib.OP_CONV]
     assert convs
     rel = 2.0 ** -21 if dt == "f16x2" else 2.0 ** -16
     for a, b in convs:
