@@ -29,11 +29,12 @@
 //               1.86 ms at 16000 image-samples) — kept for the tests ("conv_seam" = 2 | 3), not selected.
 //   registers   every per-lane address is re-derived per chunk from an opaque copy of threadIdx (SEAM_LANE_SETUP): hoisted out of the chunk
 //               loop they were ~60 VGPRs next to the 128 accumulator registers (the first build spilled 34-58 VGPRs; now 206-218, none).
-// Measured (MI355X, 16000 image-samples of 16x16 x 128 -> 512 -> 128): 2.29-2.35 ms per launch inside the ResNet-50 step against 1.90-2.01 +
-// 0.99 ms for the two launches (profiles/r05_resnet50_me_per_launch*.log); the step 54.1 -> 52.8 ms (same box, bench.py).  What bounds it
-// (same-box ablations, profiles/experiments/r5_seam_ablation.log): without the residual DMA and the stores 1.70 ms — the LDS pipe (480 KB
-// of LDS traffic per chunk and workgroup: 64 x 64 wave tiles read 8 KB per 16 MFMAs) and the chain of nine barriers per chunk; HBM adds
-// ~0.6-1.0 ms on top because two workgroups per CU overlap the two poorly.
+// Measured (MI355X, 16000 image-samples of 16x16 x 128 -> 512 -> 128, profiles/r05_resnet50_me_*): 2.24-2.29 ms per launch inside the ResNet-50
+// step against 1.90-2.01 + 0.99 ms for the two launches; rocprofv3 FETCH + WRITE per launch 5.28 + 5.24 = 10.5 GB against 9.45 + 5.25 = 14.7 GB
+// (without the non-temporal hints on the residual DMA and the wide stores 14.1 GB: the narrow input tile, re-fetched for each chunk, missed L2
+// behind the streams); the step 55.8 -> 54.1 ms (same box).  What bounds it (same-box ablations, profiles/experiments/r5_seam_ablation.log):
+// without the residual DMA and the stores 1.70 ms — the LDS pipe (480 KB of LDS traffic per chunk and workgroup: 64 x 64 wave tiles read 8 KB
+// per 16 MFMAs) and the chain of nine barriers per chunk; HBM adds ~0.6 ms on top because two workgroups per CU overlap the two poorly.
 // Taken for: expand = ksize 1, stride 1, Cmid % 64 == 0, Cmid <= 512, Cw % 128 == 0, a residual with one row per output row, ReLU,
 // no site; reduce = ksize 1, stride 1, plain epilogue, Cn = 128 (256 under "conv_seam" >= 2) output channels (NB = Cn / 128).
 #include "conv_epilogue.h"
