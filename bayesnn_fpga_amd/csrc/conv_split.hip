@@ -216,10 +216,20 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);             \
     }
 
-    const int nK = a.ksize * a.ksize * (a.Cin / 32) + (a.in2 ? a.Cin2 / 32 : 0);
+    // split-K (ConvArgs::partial / nsplit; plain convs on small grids): blockIdx.y takes a contiguous range of the K-steps and the epilogue
+    // stores the raw fp32 accumulators [split][M][Cout]; splitk_finish_pair_kernel adds them in split order and applies BN / ReLU
+    const int nK_all = a.ksize * a.ksize * (a.Cin / 32) + (a.in2 ? a.Cin2 / 32 : 0);
+    const int ks_begin = a.partial ? (int)((long)blockIdx.y * nK_all / a.nsplit) : 0;
+    const int nK = a.partial ? (int)((long)(blockIdx.y + 1) * nK_all / a.nsplit) - ks_begin : nK_all;
     // (ky, kx, c0) of the K-step whose operands are requested next.  Every step requests (at the end: clamped, unused), so the number of
     // DMA pieces in flight — what the counted vmcnt waits below rely on — never changes
     int ky = 0, kx = 0, c0 = 0, c2 = 0;        // c2: channel offset of the fused shortcut's K-step, once c0 has reached Cin
+    if (!SP_TAP_MAJOR && ks_begin) {           // (split-K: the state of K-step ks_begin in the chunk-major order)
+        const int kk = a.ksize * a.ksize, tap = ks_begin % kk;
+        c0 = (ks_begin / kk) * 32;
+        ky = tap / a.ksize;
+        kx = tap - ky * a.ksize;
+    }
 #define SP_SC() (a.in2 != nullptr && c0 >= a.Cin)
     auto advance = [&]() {
         const bool past = c0 >= a.Cin;          // the conv's own K-steps are all requested: the shortcut's chunks follow (or clamped, unused requests)
@@ -368,6 +378,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
             p.e_pix = p.b * HoWo + rem;
             p.mrow = a.site.kind == BMI_SITE_MASKSEMBLE ? a.site.masks + (size_t)((a.site.cnt0 + p.t) % a.site.num_masks) * a.Cout : nullptr;
             const int c8 = ch0 + c8l;
+            if (a.partial) {                                   // split-K: the raw sums of this K range
+                float* const pp = a.partial + ((size_t)blockIdx.y * a.M + m_o) * a.Cout + c8;
+                *(f32x4_s*)pp = r0;
+                *(f32x4_s*)(pp + 4) = r1;
+                continue;
+            }
             // (two separate quads, not halves of one array: pointer arithmetic on a local array sends it to scratch)
             float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
             if (a.res) {
@@ -392,16 +408,61 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     round(std::integral_constant<int, 1>{});
 }
 
+// out (pair32) = encode(relu?(bn(sum over the splits, in split order))): conv_split's epilogue arithmetic on the added partial sums
+template <bool BF>
+__global__ __launch_bounds__(256) void splitk_finish_pair_kernel(ConvArgs a) {
+    const long total = (long)a.M * (a.Cout >> 3);
+    const int HoWo = a.Ho * a.Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % (a.Cout >> 3)) * 8;
+        const long m = i / (a.Cout >> 3);
+        const float* pp = a.partial + (size_t)m * a.Cout + c8;
+        f32x4_s s0 = *(const f32x4_s*)pp, s1 = *(const f32x4_s*)(pp + 4);
+        for (int sp = 1; sp < a.nsplit; ++sp) {
+            const float* q = pp + (size_t)sp * a.M * a.Cout;
+            s0 += *(const f32x4_s*)q;
+            s1 += *(const f32x4_s*)(q + 4);
+        }
+        PixelCtx p;
+        p.out_off = 0; p.resp = nullptr; p.b = 0; p.t = 0; p.e_pix = 0; p.mrow = nullptr;       // (plain epilogue: no site, no residual)
+        float va[4] = {s0[0], s0[1], s0[2], s0[3]}, vb[4] = {s1[0], s1[1], s1[2], s1[3]};
+        const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+        epilogue_quad_f32sb(a, a.scale, a.bias, p, zero, false, va, c8);
+        epilogue_quad_f32sb(a, a.scale, a.bias, p, zero, false, vb, c8 + 4);
+        const float v8[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        pair_encode<BF, 8>(a.out + pair32_off((size_t)m, a.Cout, c8), v8);
+    }
+    (void)HoWo;
+}
+
 template <bool BF>
 static int launch_split_t(const ConvArgs& a, hipStream_t s) {
-    const int ct = a.Cout % 256 == 0 ? 256 : (a.Cout % 128 == 0 ? 128 : 64);
+    // Channel tile: the widest that still fills the chip.  A 256-channel tile shares a pixel tile among the most MFMAs, but the B-image prefix
+    // launches (VGG-11: 250 images of 8x8 ... 2x2 maps) are a few dozen workgroups of 72-144 K-steps each with it; narrower tiles give 2-4x
+    // the workgroups at the same K order per accumulator (the same bits: tests/test_split_engine.py).  Decided on the engine's full-chunk image
+    // count (n_ref), never on this launch's, like every other kernel selection; a pair launch keeps the 256-channel tile it was merged for.
+    static const int n_cu = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+        return cu > 0 ? cu : 256;
+    }();
+    const long ptiles_sel = ((long)(a.n_ref > 0 ? a.n_ref : a.N) * a.Ho * a.Wo + SP_PT - 1) / SP_PT;
+    int ct = a.Cout % 256 == 0 ? 256 : (a.Cout % 128 == 0 ? 128 : 64);
+    while (!a.wgt_b && opt_split_tile() && ct > 64 && ptiles_sel * (a.Cout / ct) < 3L * n_cu / 4) ct >>= 1;     // (250 workgroups of 128 channels beat 500 of 64)
     const long blocks = (long)((a.M + SP_PT - 1) / SP_PT) * (a.Cout / ct);
     if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)blocks), block(512);
+    const dim3 grid((unsigned)blocks, a.partial ? (unsigned)a.nsplit : 1u), block(512);
     if (ct == 256) hipLaunchKernelGGL((conv_split_kernel<BF, 4>), grid, block, 0, s, a);
     else if (ct == 128) hipLaunchKernelGGL((conv_split_kernel<BF, 2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_split_kernel<BF, 1>), grid, block, 0, s, a);
     BMI_CHECK_LAUNCH();
+    if (a.partial) {
+        const long total = (long)a.M * (a.Cout >> 3);
+        long fb = (total + 255) / 256;
+        if (fb > 256 * 8) fb = 256 * 8;
+        hipLaunchKernelGGL(splitk_finish_pair_kernel<BF>, dim3((unsigned)fb), dim3(256), 0, s, a);
+        BMI_CHECK_LAUNCH();
+    }
     return BMI_OK;
 }
 
@@ -410,7 +471,7 @@ bool conv_takes_split_kernel(int cin, int cout) { return cin % 32 == 0 && cout %
 // a.in / a.res / a.out: pair32 tensors (conv_epilogue.h); a.wgt: 16-bit [2][Cout][k*k*Cin] head / tail planes
 int launch_conv_split(const ConvArgs& a, int bf16, hipStream_t s) {
     if (!conv_takes_split_kernel(a.Cin, a.Cout)) return BMI_ERR_UNSUPPORTED;
-    if (a.in_bits || a.in2_bits || a.pool || a.pool_b || a.partial || a.imap) return BMI_ERR_UNSUPPORTED;
+    if (a.in_bits || a.in2_bits || a.pool || a.pool_b || a.imap) return BMI_ERR_UNSUPPORTED;
     // fused 1x1 shortcut: in2 a pair32 tensor of Cin2 channels read at stride2 (no padding), wgt2 the planes [2][Cout][Cin2]
     if (a.in2 && (!a.wgt2 || a.wgt_b || a.Cin2 % 32 != 0 || a.Cin2 <= 0 || a.stride2 < 1 || a.in2_mod <= 0 || (a.Ho - 1) * a.stride2 >= a.H2 ||
                   (a.Wo - 1) * a.stride2 >= a.W2))
@@ -420,5 +481,8 @@ int launch_conv_split(const ConvArgs& a, int bf16, hipStream_t s) {
                     !a.scale || !a.bias || !a.scale_b || !a.bias_b))
         return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.M <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
+    // split-K: plain convs only (BN + ReLU in the finishing pass), K ranges of at least one K-step
+    if (a.partial && (a.nsplit < 2 || a.nsplit > a.ksize * a.ksize * (a.Cin / 32) || a.res || a.in2 || a.wgt_b || a.site.kind != BMI_SITE_NONE || SP_TAP_MAJOR))
+        return BMI_ERR_UNSUPPORTED;
     return bf16 ? launch_split_t<true>(a, s) : launch_split_t<false>(a, s);
 }

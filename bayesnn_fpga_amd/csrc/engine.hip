@@ -191,6 +191,7 @@ int& opt_dense_exact() { static int v = 0; return v; }
 int& opt_splitk() { static int v = 1; return v; }
 int& opt_conv_stream() { static int v = 1; return v; }
 int& opt_conv_seam() { static int v = 1; return v; }
+int& opt_split_tile() { static int v = 1; return v; }
 int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_mask_lazy() { static int v = 1; return v; }
@@ -266,6 +267,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_wide") == 0) {
         if (value != 0 && value != 1) return BMI_ERR_INVALID;
         opt_conv_wide() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "split_tile") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_split_tile() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "conv_seam") == 0) {
@@ -757,11 +763,22 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     for (OpInfo& op : h->prefix) {
         op.nsplit = 0;
         const bmi_op_desc& d = op.d;
-        if (d.kind != BMI_OP_CONV || h->f32 || !opt_splitk() || d.ksize != 3 || d.residual >= 0 || d.in2 >= 0 || d.site.kind != BMI_SITE_NONE ||
+        if (d.kind != BMI_OP_CONV || (h->f32 && !h->split) || !opt_splitk() || d.ksize != 3 || d.residual >= 0 || d.in2 >= 0 || d.site.kind != BMI_SITE_NONE ||
             op.has_pair || op.bits_tensor >= 0 || op.cout % 128 != 0)
             continue;
         const TensorInfo& ti = h->tensors[d.in];
         const size_t M = B * op.ho * op.wo;
+        if (h->split) {
+            // the split engines (conv_split: 256-pixel tiles, 64-channel tiles on small grids): enough contiguous K ranges per tile for two
+            // workgroups per CU (256 CUs), nine at most, four at least (three ranges of a 252-workgroup launch measured slower: 85 -> 110 us);
+            // 72 K-steps (Cin = 256) or more
+            const size_t blocks = (M + 255) / 256 * (op.cout / 64);
+            const int ns = (int)std::min<size_t>(9, (512 + blocks - 1) / blocks);
+            if (ti.c < 256 || ns < 4) continue;
+            op.nsplit = ns;
+            sk_bytes = std::max(sk_bytes, align_up((size_t)op.nsplit * M * op.cout * sizeof(float), 256));
+            continue;
+        }
         const size_t tiles = (M + 127) / 128 * (op.cout / 128);
         if (ti.c % 64 != 0 || ti.c < 256 || tiles > 64) continue;      // stride 1 or 2 (VGG-19's 256 -> 512 exit convs: 37 -> 22 us); at
                                                                        // Cin = 128 (18 K-steps) the split measured slower: 23 -> 28 us
@@ -953,6 +970,10 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 auto tb = [&](int id) { const TensorInfo& t = e->tensors[id]; return 4.0 * (t.stoch ? N : B) * t.h * t.w * t.c; };
                 prof.tag(BMI_CONV_FAMILY_SPLIT, fl, tb(d.in) + 4.0 * N * op.ho * op.wo * (double)cout_l + 4.0 * (double)cout_l * (d.ksize * d.ksize * tin.c + cin2_l) +
                                                     (d.residual >= 0 ? tb(d.residual) : 0.0) + (d.in2 >= 0 ? tb(d.in2) : 0.0));
+                if (op.nsplit > 1 && !op.stoch) {       // split-K (bmi_plan): raw fp32 partial sums per K range, then the finishing pass
+                    a.partial = (float*)(ws + e->splitk_off);
+                    a.nsplit = op.nsplit;
+                }
                 if (op.has_pair) {
                     ConvArgs p = a;
                     p.wgt_b = (const _Float16*)op.pair_d.weight;

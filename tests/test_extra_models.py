@@ -98,3 +98,30 @@ def test_gpu_splitk_prefix_convs_match_unsplit():
             _lib.set_option("splitk", 1)
     assert ws[1] > ws[0]                                  # the partial-sum scratch was planned, i.e. the split path ran
     np.testing.assert_allclose(out[1], out[0], rtol=0, atol=5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,B", [("f16x2", 6), ("bf16x3", 250)])
+def test_gpu_split_engines_splitk_and_narrow_tiles_match(dt, B):
+    """The split engines on VGG-11's B-image prefix (a few dozen 256-channel tiles on 256 CUs): conv_split narrows its channel tile on
+    small grids ("split_tile": the same K order per accumulator, so the same bits) and bmi_plan gives the 3x3 convs with 256+ input
+    channels contiguous K ranges per tile (split-K: raw fp32 sums in workspace scratch, a finishing pass that encodes pair32; the same
+    function up to the fp32 summation order over K)."""
+    from bayesnn_fpga_amd import _lib
+    T, seed = 3, 3
+    x = synthetic_images(B, seed=7).to("cuda:0")
+    out, ws = {}, {}
+    for arm, (sk, tile) in {"both": (1, 1), "wide": (1, 0), "unsplit": (0, 1), "neither": (0, 0)}.items():
+        _lib.set_option("splitk", sk)
+        _lib.set_option("split_tile", tile)
+        try:
+            m = synthetic_weights_(build_seeded(bx.VGG11MC, dict(num_bayes_layer=3, dropout_p=0.25, out_dim=10)), 0).to("cuda:0").eval()
+            eng = m.engine(x.device, max_batch=B, dtype=dt)
+            ws[arm] = eng.workspace_bytes
+            out[arm] = eng.predict(x, T, seed=seed)["mean"].cpu().numpy()
+        finally:
+            _lib.set_option("splitk", 1)
+            _lib.set_option("split_tile", 1)
+    assert ws["both"] > ws["unsplit"]                    # the partial-sum scratch was planned, i.e. the split path ran
+    assert np.array_equal(out["unsplit"], out["neither"]) and np.array_equal(out["both"], out["wide"])      # tile width: the same bits
+    np.testing.assert_allclose(out["both"], out["unsplit"], rtol=0, atol=2e-6 if dt == "f16x2" else 2e-5)
