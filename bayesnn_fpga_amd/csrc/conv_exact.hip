@@ -168,9 +168,71 @@ __global__ __launch_bounds__(256) void mask_apply_f32_kernel(EltArgs a) {
     }
 }
 
+// The first "block" site of the split engines (an elementwise 2-bit site on a deterministic tensor: B images in, chunk x B images out, 6.5 GB of
+// pair32 on the headline) with ONE Philox call per 64 elements instead of one per 8: a wave owns 512 consecutive 8-channel items (= 64 calls, one per
+// lane), and in pass k lane l takes item 64 k + l, whose call lane 8 k + (l >> 3) holds (four ds_bpermute).  The generic kernel above spends more
+// than half of its VALU time recomputing each call eight times.  Launcher: a sample's items are a multiple of 512 (a wave never straddles two
+// samples), the site's index offset a whole number of calls.
+template <bool BF>
+__global__ __launch_bounds__(256) void mask_apply_pair_lb1_kernel(EltArgs a) {
+    const int cg = a.C >> 3;
+    const long per_sample = (long)a.B * a.HW * cg;
+    const long waves = per_sample / 512;                             // input tiles of 512 items
+    const int T = a.N / a.B;
+    const int lane = threadIdx.x & 63;
+    const int t_lo = blockIdx.y * a.tchunk, t_hi = min(T, t_lo + a.tchunk);
+    for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w < waves; w += (long)gridDim.x * 4) {
+        const long r0 = w * 512;                                     // item index inside a sample
+        // the tile's input, decoded once for all the samples of this workgroup's range (the deterministic tensor is B images: read per
+        // sample it was as many fabric bytes again as the output)
+        float x[8][8];
+        size_t ooff[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long r = r0 + 64 * k + lane;                        // this lane's item: image b, pixel p, channels c8 ..
+            const int c8 = (int)(r % cg) * 8;
+            const long bp = r / cg;                                   // b * HW + p
+            pair_decode<BF, 8>((const _Float16*)a.in + pair32_off((size_t)bp, a.C, c8), x[k]);
+            ooff[k] = pair32_off((size_t)bp, a.C, c8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[k][e] *= a.site.scale;
+        }
+        for (int tl = t_lo; tl < t_hi; ++tl) {
+            const philox4 mine = philox_site_call(a.site, (uint64_t)(r0 + 8 * lane) * 8, (uint32_t)(a.t0 + tl));      // call r0 / 8 + lane
+            _Float16* const ot = (_Float16*)a.out + (size_t)tl * a.B * a.HW * (2 * (size_t)a.C);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int src = 8 * k + (lane >> 3);
+                philox4 c;
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) c.w[wd] = (uint32_t)__shfl((int)mine.w[wd], src, 64);
+                const uint32_t keep = a.site.drop_all ? 0u : philox_keep8(c, (uint32_t)((r0 + 64 * k + lane) * 8), a.site.log2_bits, a.site.thresh);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? x[k][e] : 0.f;
+                pair_encode<BF, 8>(ot + ooff[k], v);
+            }
+        }
+    }
+}
+
 int launch_mask_apply_f32(const EltArgs& a, hipStream_t s) {
     if (a.C % 8 != 0 || (a.pair && a.C % 32 != 0)) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0) return BMI_ERR_INVALID;
+    if (a.pair && a.site.kind == BMI_SITE_ELEMENTWISE && a.site.log2_bits == 1 && !a.bias_post && !a.relu && a.N % a.B == 0 && a.in_mod == a.B &&
+        ((long)a.B * a.HW * (a.C >> 3)) % 512 == 0 && a.site.elem_off % 64 == 0) {
+        const long waves = ((long)a.B * a.HW * (a.C >> 3)) / 512;
+        const long blocks = (waves + 3) / 4;
+        const int T = a.N / a.B;
+        EltArgs b = a;
+        // samples per workgroup: as many as still leave ~16 workgroups per CU (the input tile is read once per workgroup)
+        b.tchunk = (int)std::max<long>(1, std::min<long>(T, (long)T * blocks / (256 * 16)));
+        const dim3 grid((unsigned)std::min<long>(blocks, 0x7fffffffL), (unsigned)((T + b.tchunk - 1) / b.tchunk));
+        if (a.pair == 1) hipLaunchKernelGGL(mask_apply_pair_lb1_kernel<false>, grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL(mask_apply_pair_lb1_kernel<true>, grid, dim3(256), 0, s, b);
+        BMI_CHECK_LAUNCH();
+        return BMI_OK;
+    }
     long blocks = ((long)a.N * a.HW * (a.C >> 3) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (a.pair == 1) hipLaunchKernelGGL(mask_apply_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);

@@ -143,20 +143,21 @@ def test_split_stem_mask_maxpool_head_and_dense_on_pair32(split_entries):
         bias.double()[None, :, None, None]
     got = gh.pair32_decode(out).double().cpu().permute(0, 3, 1, 2)
     assert float((got - ref).abs().max()) <= 1e-5 + eps * float(ref.abs().max())
-    # stand-alone site: B deterministic images -> the folded batch
-    B, tc, H, Cc, t0, seed = 3, 4, 6, 64, 2, 99
-    xs = torch.randn(B, H, H, Cc, generator=g).to(DEV)
-    xs = gh.pair32_decode(gh.pair32_encode(xs, t16))            # (values the layout holds exactly)
-    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=0, p=0.375)
-    keep = []
-    s = gh.site_struct(site, keep)
-    om = torch.empty(B * tc, H, H, Cc // 32, 2, 32, dtype=t16, device=DEV)
-    _lib.check(lib.bmi_mask_apply(gh.ptr(gh.pair32_encode(xs, t16)), gh.ptr(om), B * tc, B, H * H, Cc, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_mask_apply")
-    torch.cuda.synchronize()
-    mult = gh.folded_site_mask(site, B, Cc, H, H, tc, t0, seed)
-    want = xs.cpu().permute(0, 3, 1, 2).repeat(tc, 1, 1, 1) * mult
-    gotm = gh.pair32_decode(om).cpu().permute(0, 3, 1, 2)
-    assert torch.equal(gotm == 0, want == 0) and float((gotm - want).abs().max()) <= eps * float(want.abs().max())
+    # stand-alone site: B deterministic images -> the folded batch (the second shape and p = 0.25: the one-call-per-64-elements kernel, a
+    # sample's 8-channel items a multiple of 512)
+    for B, tc, H, Cc, t0, seed, p in ((3, 4, 6, 64, 2, 99, 0.375), (4, 3, 8, 64, 1, 7, 0.25), (4, 2, 8, 128, 0, 5, 0.75)):
+        xs = torch.randn(B, H, H, Cc, generator=g).to(DEV)
+        xs = gh.pair32_decode(gh.pair32_encode(xs, t16))            # (values the layout holds exactly)
+        site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=0, p=p)
+        keep = []
+        s = gh.site_struct(site, keep)
+        om = torch.empty(B * tc, H, H, Cc // 32, 2, 32, dtype=t16, device=DEV)
+        _lib.check(lib.bmi_mask_apply(gh.ptr(gh.pair32_encode(xs, t16)), gh.ptr(om), B * tc, B, H * H, Cc, C.byref(s), B, t0, seed, 0, gh.stream()), "bmi_mask_apply")
+        torch.cuda.synchronize()
+        mult = gh.folded_site_mask(site, B, Cc, H, H, tc, t0, seed)
+        want = xs.cpu().permute(0, 3, 1, 2).repeat(tc, 1, 1, 1) * mult
+        gotm = gh.pair32_decode(om).cpu().permute(0, 3, 1, 2)
+        assert torch.equal(gotm == 0, want == 0) and float((gotm - want).abs().max()) <= eps * float(want.abs().max()), (B, tc, H, Cc, p)
     # max-pool: exact (the maximum is one of the encoded inputs)
     xp = gh.pair32_decode(gh.pair32_encode(torch.randn(3, 8, 8, 64, generator=g).to(DEV), t16))
     op = torch.empty(3, 4, 4, 2, 2, 32, dtype=t16, device=DEV)
