@@ -59,6 +59,7 @@ typedef float f32x4_s __attribute__((ext_vector_type(4)));
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                            \
                  :: "s"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(LDSPTR)), "v"(VPTR) : "m0", "memory")
 
+typedef unsigned int u32x4_sp __attribute__((ext_vector_type(4)));
 static __device__ unsigned int g_split_zero[64];   // zeros: what an out-of-image tap / a tile row beyond M fetches (256 B)
 
 // timing probes (tools/ab_split.sh name:-DSP_ABL_...=1; wrong results by construction, never in the product build)
@@ -77,11 +78,20 @@ static __device__ unsigned int g_split_zero[64];   // zeros: what an out-of-imag
 #ifndef SP_ABL_NOW
 #define SP_ABL_NOW 0
 #endif
+#ifndef SP_ABL_X3
+#define SP_ABL_X3 0          // timing probe: the pixel tile is fetched for the kx = 0 tap of a row of taps only (what a padded-row slot shared by the three
+#endif                       // taps of a row would land in LDS); wrong results
 #ifndef SP_TAP_MAJOR
 #define SP_TAP_MAJOR 0
 #endif
 
-template <bool BF, int TI>
+// SHX (3x3, stride 1, pad 1): the three taps of a tap row read ONE pixel slot.  The slot holds the row's centre column (kx = 1: pixel p's line is
+// input (oy + ky - 1, ox)); the kx = 0 / 2 taps read the slot rows of the tile pixels p - 1 / p + 1 — the same image row unless p sits on the
+// map's left / right edge, where the tap is padding: those lanes' fragments are cleared in registers.  The swizzle key of a row is a function of the
+// row index, so a shifted read is as conflict-free as a straight one.  Two thirds of the pixel DMA — the larger part of what a K-step lands in
+// LDS — is not issued at all: same-box probe (pixel DMA on the kx = 0 taps only, wrong results) 3x3 stride-1 launches -13 % (128 channels) ...
+// -22 % (256 / 512), the headline step -17 %.  Bit-identical to the unshared loop (the same operands in the same order).
+template <bool BF, int TI, bool SHX>
 __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     constexpr int CT = 64 * TI;
     constexpr int WPL = CT * 64;                       // bytes of one weight plane of a slot
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     // line that sits in L2, which all but the first tap of a chunk do) and TI <= 2 two (their K-steps are 384 / 192 cycles per group)
     constexpr int D = TI == 4 ? 1 : 2, NS = D + 1;
     constexpr int XBASE = NS * WSLOT;
-    __shared__ __attribute__((aligned(16))) char smem[NS * (WSLOT + XSLOT)];
+    __shared__ __attribute__((aligned(16))) char smem[NS * (WSLOT + XSLOT) + (SHX ? 128 : 0)];      // (SHX: the last slot's row 256, read by edge lanes and cleared)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,11 +171,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     }
 #define SP_ISSUE_X1(I, KY, KX, C0, ST)                                                                   \
     {                                                                                                    \
-        const bool ok_ = (unsigned)(iy0[I] + (KY)) < (unsigned)a.H && (unsigned)(ix0[I] + (KX)) < (unsigned)a.W;   \
-        const long so_ = (long)((KY) * a.W + (KX)) * (2 * a.Cin) + 2 * min((C0), a.Cin - 32);          /* (C0 = Cin: past the last K-step) */ \
+        const int kxe_ = SHX ? 1 : (KX);                /* SHX: the centre column, whatever tap of the row asks */                   \
+        const bool ok_ = (unsigned)(iy0[I] + (KY)) < (unsigned)a.H && (unsigned)(ix0[I] + kxe_) < (unsigned)a.W;   \
+        const long so_ = (long)((KY) * a.W + kxe_) * (2 * a.Cin) + 2 * min((C0), a.Cin - 32);          /* (C0 = Cin: past the last K-step) */ \
         const _Float16* p_ = (ok_ && !SP_ABL_NOX) ? xorg[I] + so_ : (const _Float16*)g_split_zero + ((tid & 7) << 3);                  \
         if (SP_SC()) p_ = x2org[I] ? x2org[I] + 2 * min(c2, a.Cin2 - 32) : (const _Float16*)g_split_zero + ((tid & 7) << 3);           \
-        SP_GLDS16V(p_, (ST) + ((I) * 512 + wave * 64) * 16);                                             \
+        if (!SP_ABL_X3 || (KX) == 0) SP_GLDS16V(p_, (ST) + ((I) * 512 + wave * 64) * 16);               \
     }
 
     f32x16_s acc[TI][2];
@@ -180,16 +191,40 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     const int b_off = XBASE + (wp * 64 + r) * 128;
     // fragments of one 16-deep sub-step SS of a K-step (weight slot WS, input slot XS): (TI + 2) x 2 ds_read_b128
     half8_t ah[TI], al[TI], bh[2], bl[2];
-#define SP_READ(WS, XS, SS)                                                                              \
+    // SHX: per fragment j, is this lane's pixel on the left / right edge of its map row (the kx = 0 / 2 tap is padding there)
+    bool edge_l[2] = {false, false}, edge_r[2] = {false, false};
+    if constexpr (SHX) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = (pix0 + wp * 64 + 32 * j + r) % a.Wo;
+            edge_l[j] = ox == 0;
+            edge_r[j] = ox == a.Wo - 1;
+        }
+    }
+    // (SHIFT = kx - 1 of a SHX tap: the slot row of tile pixel p + SHIFT, with THAT row's swizzle key; 0 otherwise)
+#define SP_READ(WS, XS, SS, SHIFT)                                                                       \
     if (!SP_ABL_NOREAD || ks == 0) {                                                                     \
         const int coff = ((2 * (SS) + kq) ^ sw) << 4;                                                    \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) {                                                 \
             ah[i] = *(const half8_t*)((WS) + a_off + i * 32 * 64 + coff);                                \
             al[i] = *(const half8_t*)((WS) + WPL + a_off + i * 32 * 64 + coff);                          \
         }                                                                                                \
+        const int sxs_ = SHX ? (((r + (SHIFT)) >> 1) & 7) : sx;                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-            bh[j] = *(const half8_t*)((XS) + b_off + j * 32 * 128 + (((2 * (SS) + kq) ^ sx) << 4));      \
-            bl[j] = *(const half8_t*)((XS) + b_off + j * 32 * 128 + (((4 + 2 * (SS) + kq) ^ sx) << 4));  \
+            bh[j] = *(const half8_t*)((XS) + b_off + (j * 32 + (SHX ? (SHIFT) : 0)) * 128 + (((2 * (SS) + kq) ^ sxs_) << 4));      \
+            bl[j] = *(const half8_t*)((XS) + b_off + (j * 32 + (SHX ? (SHIFT) : 0)) * 128 + (((4 + 2 * (SS) + kq) ^ sxs_) << 4));  \
+        }                                                                                                \
+        if (SHX && (SHIFT) != 0) {           /* (wave-uniform) */                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+                const bool z_ = (SHIFT) < 0 ? edge_l[j] : edge_r[j];                                     \
+                u32x4_sp vh_ = __builtin_bit_cast(u32x4_sp, bh[j]), vl_ = __builtin_bit_cast(u32x4_sp, bl[j]);   \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
+                    vh_[e] = z_ ? 0u : vh_[e];                                                           \
+                    vl_[e] = z_ ? 0u : vl_[e];                                                           \
+                }                                                                                        \
+                bh[j] = __builtin_bit_cast(half8_t, vh_);                                                \
+                bl[j] = __builtin_bit_cast(half8_t, vl_);                                                \
+            }                                                                                            \
         }                                                                                                \
     }
     // the 6 TI MFMAs of a sub-step in NG groups — the small products first (lo . hi, hi . lo), then hi . hi — with HOOK(g) behind group
@@ -258,18 +293,29 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     // (the weight offset of (ky, kx, c0), clamped for the K-steps past the end)
 #define SP_KOFF() (SP_SC() ? min(c2, a.Cin2 - 32) : min((min(ky, a.ksize - 1) * a.ksize + kx) * a.Cin + min(c0, a.Cin - 32), Ktot - 32))
     // all of one K-step's pieces: TI of weights, 4 of input
+    // SHX: the pixel slots are a ring of their own — filled for the first tap of a tap row (and for every K-step of a fused shortcut), so the
+    // request state says whether this request carries pixel pieces (SP_NEEDX) and xq is the slot they go to
+    int xq = 0, xc = 0;                                  // pixel slot of the next fill | of the K-step being computed
+#define SP_NEEDX() (!SHX || SP_SC() || kx == 0)
+#define SP_XDST(SLOT) (smem + XBASE + (SHX ? xq : (SLOT)) * XSLOT)
 #define SP_ISSUE_ALL(SLOT)                                                                               \
     {                                                                                                    \
         const int koff_ = SP_KOFF();                                                                     \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) SP_ISSUE_W1(i, koff_, smem + (SLOT) * WSLOT);     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) SP_ISSUE_X1(i, ky, kx, c0, smem + XBASE + (SLOT) * XSLOT);   \
+        if (SP_NEEDX()) { _Pragma("unroll") for (int i = 0; i < 4; ++i) SP_ISSUE_X1(i, ky, kx, c0, SP_XDST(SLOT)); }   \
+    }
+    // (after a request: the fill slot moves on if the request carried pixel pieces; then the request state)
+#define SP_NEXT_REQUEST()                                                                                \
+    {                                                                                                    \
+        if (SHX && SP_NEEDX()) xq = xq + 1 == NS ? 0 : xq + 1;                                           \
+        advance();                                                                                       \
     }
     constexpr int PIECES = TI + 4;                       // DMA pieces a wave issues per K-step
     // K-steps 0 .. D-1 -> slots 0 .. D-1
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         SP_ISSUE_ALL(d);
-        advance();
+        SP_NEXT_REQUEST();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -289,12 +335,17 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     const int g = wc;
     if (g == 1) SP_BARRIER();
     int slot = 0;                                        // ring index of K-step ks
+    const int nK_own = a.ksize * a.ksize * (a.Cin / 32);  // the conv's own K-steps (then the fused shortcut's)
+    int ckx = 0;                                         // SHX: kx of K-step ks (taps inner, three per row)
     for (int ks = 0; ks < nK; ++ks) {
         const char* const ws = smem + slot * WSLOT;
-        const char* const xs = smem + slot * XSLOT;      // (+ XBASE inside b_off)
+        const char* const xs = smem + (SHX ? xc : slot) * XSLOT;      // (+ XBASE inside b_off)
         const int nslot = slot + D >= NS ? slot + D - NS : slot + D;      // ring index of K-step ks + D
+        const bool own = ks < nK_own;                    // (SHX: a shortcut K-step reads its own slot straight)
+        const int shift = SHX && own ? ckx - 1 : 0;
+        const bool needx = SP_NEEDX();                   // does the request issued during this K-step carry pixel pieces
         // LOAD(0)
-        SP_READ(ws, xs, 0);
+        SP_READ(ws, xs, 0, shift);
         if constexpr (D == 1) { SP_ISSUE_ALL(nslot); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SP_BARRIER();
@@ -303,18 +354,20 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     {                                                                                                    \
         if constexpr (D == 2) {          /* two groups: half of the K-step's pieces behind each */       \
             const int koff_ = SP_KOFF();                                                                 \
-            if ((G) == 0) { SP_ISSUE_X1(0, ky, kx, c0, smem + XBASE + nslot * XSLOT); SP_ISSUE_X1(1, ky, kx, c0, smem + XBASE + nslot * XSLOT); SP_ISSUE_W1(0, koff_, smem + nslot * WSLOT); } \
-            if ((G) == 1) { SP_ISSUE_X1(2, ky, kx, c0, smem + XBASE + nslot * XSLOT); SP_ISSUE_X1(3, ky, kx, c0, smem + XBASE + nslot * XSLOT); \
+            if ((G) == 0) { if (needx) { SP_ISSUE_X1(0, ky, kx, c0, SP_XDST(nslot)); SP_ISSUE_X1(1, ky, kx, c0, SP_XDST(nslot)); } SP_ISSUE_W1(0, koff_, smem + nslot * WSLOT); } \
+            if ((G) == 1) { if (needx) { SP_ISSUE_X1(2, ky, kx, c0, SP_XDST(nslot)); SP_ISSUE_X1(3, ky, kx, c0, SP_XDST(nslot)); } \
                             if constexpr (TI == 2) { SP_ISSUE_W1(TI - 1, koff_, smem + nslot * WSLOT); } } \
         }                                                                                                \
     }
         SP_MFMA(SP_HOOK0);
 #undef SP_HOOK0
-        advance();
+        SP_NEXT_REQUEST();
         SP_BARRIER();
         // LOAD(1)
-        SP_READ(ws, xs, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * PIECES) : "memory");     // K-step ks + 1's operands have landed (this wave's pieces)
+        SP_READ(ws, xs, 1, shift);
+        // K-step ks + 1's operands have landed (this wave's pieces): all but the pieces of the request issued during this K-step (D = 2)
+        if (SHX && !needx) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * TI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * PIECES) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SP_BARRIER();
         // MFMA(1)
@@ -323,11 +376,18 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
 #undef SP_HOOK1
         SP_BARRIER();
         slot = slot + 1 == NS ? 0 : slot + 1;
+        if constexpr (SHX) {                             // the pixel slot moves on behind the third tap of a row (behind every shortcut K-step)
+            if (!own || ckx == 2) xc = xc + 1 == NS ? 0 : xc + 1;
+            ckx = ckx == 2 ? 0 : ckx + 1;
+        }
     }
     if (g == 0) SP_BARRIER();
 #undef SP_ISSUE_W1
 #undef SP_ISSUE_X1
 #undef SP_ISSUE_ALL
+#undef SP_NEEDX
+#undef SP_XDST
+#undef SP_NEXT_REQUEST
 #undef SP_READ
 #undef SP_MFMA
 #undef SP_BARRIER
@@ -452,9 +512,16 @@ static int launch_split_t(const ConvArgs& a, hipStream_t s) {
     const long blocks = (long)((a.M + SP_PT - 1) / SP_PT) * (a.Cout / ct);
     if (blocks <= 0 || blocks > 0x7fffffffL) return BMI_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)blocks, a.partial ? (unsigned)a.nsplit : 1u), block(512);
-    if (ct == 256) hipLaunchKernelGGL((conv_split_kernel<BF, 4>), grid, block, 0, s, a);
-    else if (ct == 128) hipLaunchKernelGGL((conv_split_kernel<BF, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_split_kernel<BF, 1>), grid, block, 0, s, a);
+    // the three taps of a tap row share a pixel slot (SHX): 3x3, stride 1, pad 1, whole K range per workgroup
+    // (a tile must start and end on a map row boundary, so that a pixel's horizontal neighbours are in its own tile: 256 % Wo == 0)
+    const bool shx = opt_split_shx() && !SP_TAP_MAJOR && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.partial && SP_PT % a.Wo == 0;
+#define SP_LAUNCH(TI_)                                                                                           \
+    {                                                                                                            \
+        if (shx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, true>), grid, block, 0, s, a);                   \
+        else hipLaunchKernelGGL((conv_split_kernel<BF, TI_, false>), grid, block, 0, s, a);                      \
+    }
+    if (ct == 256) SP_LAUNCH(4) else if (ct == 128) SP_LAUNCH(2) else SP_LAUNCH(1)
+#undef SP_LAUNCH
     BMI_CHECK_LAUNCH();
     if (a.partial) {
         const long total = (long)a.M * (a.Cout >> 3);

@@ -192,6 +192,7 @@ int& opt_splitk() { static int v = 1; return v; }
 int& opt_conv_stream() { static int v = 1; return v; }
 int& opt_conv_seam() { static int v = 1; return v; }
 int& opt_split_tile() { static int v = 1; return v; }
+int& opt_split_shx() { static int v = 1; return v; }
 int& opt_conv_wide() { static int v = 1; return v; }
 int& opt_conv_pool() { static int v = 1; return v; }
 int& opt_mask_lazy() { static int v = 1; return v; }
@@ -267,6 +268,11 @@ int bmi_set_option(const char* name, int32_t value) {
     if (std::strcmp(name, "conv_wide") == 0) {
         if (value != 0 && value != 1) return BMI_ERR_INVALID;
         opt_conv_wide() = value;
+        return BMI_OK;
+    }
+    if (std::strcmp(name, "split_shx") == 0) {
+        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        opt_split_shx() = value;
         return BMI_OK;
     }
     if (std::strcmp(name, "split_tile") == 0) {

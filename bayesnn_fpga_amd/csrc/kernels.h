@@ -172,6 +172,7 @@ int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the
 int& opt_mask_lazy();          // 1: a lazy site (engine.hip, bmi_create) writes keep bits + one scaled copy and its consumers mask in LDS, 0: always materialised
 int& opt_conv_pool();          // 1: a conv whose 4x4 map feeds one exit head only writes the pooled means (conv3x3_s2), 0: never
 int& opt_conv_s2();            // 1: plain 3x3 stride-2 convs run in conv3x3_s2 (2 = without its minimum-grid rule: tests), 0: conv_igemm_wide
+int& opt_split_shx();         // 1: conv_split's 3x3 stride-1 launches fetch a tap row's pixel tile once for its three taps (0: once per tap: A/B, tests)
 int& opt_split_tile();        // 1: conv_split narrows its channel tile on small grids (0: always the widest that divides Cout: A/B, tests)
 int& opt_conv_seam();          // 1: expand conv + residual of Bottleneck k and the reduce conv of Bottleneck k+1 run as one conv1x1_seam launch (2 = without its minimum-grid rule: tests), 0: two launches
 int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never

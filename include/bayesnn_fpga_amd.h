@@ -161,7 +161,7 @@ const char* bmi_error_string(int code);
 
 /* Process-wide switches: kernel selection (used for same-process A/B measurement and by the tests to cover both code
  * paths) and the element type of the unit-test entry points.  Results are equal TO ROUNDING across them, not always bit for
- * bit: "mfma_shape_*", "epilogue_lite", "conv_seam" and "split_tile" leave every bit alone; "conv_pw", "conv_s2", "conv_stream" and "conv_wide" move a
+ * bit: "mfma_shape_*", "epilogue_lite", "conv_seam", "split_tile" and "split_shx" leave every bit alone; "conv_pw", "conv_s2", "conv_stream" and "conv_wide" move a
  * conv to a kernel family that sums its K dimension in another order, "splitk" adds nine fp32 partial sums separately,
  * "dense_exact" swaps the split-fp16 product for the exact-f32 MFMA.  (Kernel selection itself looks at the conv's shape
  * and the engine's planned batch x chunk only, so two runs of one engine — whole, t-sharded, image-sharded, partial chunks —
@@ -177,6 +177,8 @@ const char* bmi_error_string(int code);
  *   "conv_stream"                           0 | 1 | 2 (= 1 without the minimum-grid rule and for plain launches too: tests) | 3 (= 1 with the
  *                                           256-pixel tile: A/B): HBM-bound 1x1 convs (Cin <= 512; with a residual, or Cout % 256 != 0) run
  *                                           in conv1x1_stream (128 x 128 tile, three or four workgroups per CU) instead of conv_igemm_wide
+ *   "split_shx"                             0 | 1: the split engines' 3x3 stride-1 convs fetch the pixel tile of a tap row once for its three taps (the same
+ *                                           bits; 0: once per tap)
  *   "split_tile"                            0 | 1: the split engines' conv kernel narrows its channel tile (256 -> 128 -> 64) while a launch of the planned
  *                                           batch x chunk would be fewer than two workgroups per CU (the same bits; 0: always the widest tile)
  *   "conv_seam"                             0 | 1 | 2 | 3, read by bmi_create and per launch: conv3 + BN + shortcut add + ReLU of one Bottleneck and conv1 + BN +

@@ -250,6 +250,50 @@ def test_split_conv_fused_shortcut_against_float64(split_entries, cin, cout, cin
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,H,n,res", [(128, 128, 16, 5, True), (256, 256, 8, 37, False), (512, 512, 4, 70, True), (64, 64, 32, 3, False),
+                                              (128, 256, 2, 300, True), (64, 128, 6, 9, False), (32, 64, 1, 700, True)])
+def test_split_conv_shared_pixel_slot_is_bit_for_bit(split_entries, cin, cout, H, n, res):
+    """conv_split's 3x3 stride-1 launches fetch the pixel tile of a tap row ONCE and read it shifted by one pixel for the kx = 0 / 2 taps
+    (edge lanes cleared in registers): bit for bit the loop that fetches it per tap ("split_shx" 1 / 0) — 16x16 ... 1x1 maps (every lane an
+    edge), 32x32 (four tiles per image), ragged last tiles, a 6x6 map (256 % 6 != 0: the shared form is not taken), with and without a
+    residual; and the fused-shortcut form, whose extra K-steps read their own slots."""
+    dt = split_entries
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(n, H, H, cin, generator=g).to(DEV)
+    w = (torch.randn(cout, 3, 3, cin, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    r = torch.randn(n, H, H, cout, generator=g).to(DEV) if res else None
+    out = {}
+    for shx in (1, 0):
+        _lib.set_option("split_shx", shx)
+        try:
+            out[shx] = _run_split(x, w, dt, scale, bias, r, True, 1, 1, n, n, n)
+        finally:
+            _lib.set_option("split_shx", 1)
+    assert torch.isfinite(out[1]).all() and torch.equal(out[1], out[0])
+    if H in (16, 8, 4):                                   # the fused shortcut on top (in2 = the block input at twice the map size)
+        lib = _lib.lib()
+        t16 = TORCH16[dt]
+        cin2 = cin // 2
+        x2 = torch.randn(n, 2 * H, 2 * H, cin2, generator=g).to(DEV)
+        w2 = (torch.randn(cout, cin2, generator=g) * (2.0 / cin2) ** 0.5)
+        xp, x2p = gh.pair32_encode(x, t16), gh.pair32_encode(x2, t16)
+        wp, w2p = split_planes(w.cpu(), dt).to(DEV), split_planes(w2, dt).to(DEV)
+        outs = {}
+        for shx in (1, 0):
+            _lib.set_option("split_shx", shx)
+            try:
+                o = torch.full((n, H, H, cout // 32, 2, 32), float("nan"), dtype=t16, device=DEV)
+                _lib.check(lib.bmi_conv3x3_shortcut_fwd(gh.ptr(xp), gh.ptr(wp), gh.ptr(x2p), gh.ptr(w2p), gh.ptr(bias), gh.ptr(o), n, H, H, cin, cout, cin2, 1,
+                                                        gh.stream()), "bmi_conv3x3_shortcut_fwd")
+                torch.cuda.synchronize()
+                outs[shx] = o
+            finally:
+                _lib.set_option("split_shx", 1)
+        assert torch.equal(outs[1].view(torch.int16), outs[0].view(torch.int16))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["elementwise", "channel", "masksemble"])
 def test_split_conv_fused_site_is_bit_exact_on_the_mask(kind, split_entries):
     dt = split_entries
