@@ -91,18 +91,24 @@ static __device__ unsigned int g_split_zero[64];   // zeros: what an out-of-imag
 // row index, so a shifted read is as conflict-free as a straight one.  Two thirds of the pixel DMA — the larger part of what a K-step lands in
 // LDS — is not issued at all: same-box probe (pixel DMA on the kx = 0 taps only, wrong results) 3x3 stride-1 launches -13 % (128 channels) ...
 // -22 % (256 / 512), the headline step -17 %.  Bit-identical to the unshared loop (the same operands in the same order).
-template <bool BF, int TI, bool SHX>
+// SHX = 2 (map rows of 8, 16, 32 ... pixels): no clearing at all — the slot keeps one ZERO cell in front of every map row (cell of tile pixel p =
+// p + p / Wo + 1; written once at kernel start, never by the DMA, whose eight-pixel pieces never straddle a row), so a shifted read at an edge lands
+// on padding by itself.  (SHX = 1 clears 16 registers per 16-deep sub-step behind the fragment reads, in the LOAD part the other wave group's MFMA
+// part has to cover: measured +0.8 % instead of the probe's 17 %.)
+template <bool BF, int TI, int SHX>
 __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
+    constexpr bool PADX = SHX == 2;
     constexpr int CT = 64 * TI;
     constexpr int WPL = CT * 64;                       // bytes of one weight plane of a slot
     constexpr int WSLOT = 2 * WPL;
-    constexpr int XSLOT = SP_PT * 128;                 // bytes of one input slot: 256 rows [hi 64 B | lo 64 B]
+    constexpr int XSLOT = PADX ? 296 * 128 : SP_PT * 128;   // bytes of one input slot: 256 rows [hi 64 B | lo 64 B] (PADX: + up to 33 zero cells)
     // fetch distance: the operands of K-step ks + D are requested during K-step ks.  D = 2 needs rings of three: 96 + 96 KB at TI = 4
     // — more than the CU has — so TI = 4 fetches one K-step ahead (its K-step is 2 x 768 cycles of MFMA per wave group: enough for a
     // line that sits in L2, which all but the first tap of a chunk do) and TI <= 2 two (their K-steps are 384 / 192 cycles per group)
     constexpr int D = TI == 4 ? 1 : 2, NS = D + 1;
     constexpr int XBASE = NS * WSLOT;
-    __shared__ __attribute__((aligned(16))) char smem[NS * (WSLOT + XSLOT) + (SHX ? 128 : 0)];      // (SHX: the last slot's row 256, read by edge lanes and cleared)
+    __shared__ __attribute__((aligned(16))) char smem[NS * (WSLOT + XSLOT) + (SHX == 1 ? 128 : 0)];      // (SHX = 1: the last slot's row 256, read by edge lanes and cleared)
+    static_assert(sizeof(smem) <= 163840, "one workgroup's LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,6 +159,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     const _Float16* xorg[4];
     const _Float16* x2org[4];         // (fused shortcut) the pixel's line in in2 at chunk 0, or the page of zeros for a row beyond M
     int iy0[4], ix0[4];
+    // PADX: piece i of a wave is the eight tile pixels 8 rb .. 8 rb + 7 (rb = 8 i + wave), one map row segment -> eight consecutive cells from
+    // xcell0[i]; the swizzle key of a line is that of its CELL
+    const int wlog = 31 - __builtin_clz(a.Wo);
+    int xcell0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xcell0[i] = 8 * (8 * i + wave) + ((8 * (8 * i + wave)) >> wlog) + 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 3) + 64 * i;
@@ -163,10 +175,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;      // a row beyond M never passes the bounds test
         ix0[i] = ox * a.stride - a.pad;
-        xorg[i] = a.in + ((long)(n % a.in_mod) * a.H * a.W + (long)(oy * a.stride - a.pad) * a.W + ix0[i]) * (2 * a.Cin) +
-                  (((tid & 7) ^ ((tid >> 4) & 7)) << 3);
+        const int key = PADX ? ((xcell0[i] + ((tid >> 3) & 7)) >> 1) & 7 : (tid >> 4) & 7;
+        xorg[i] = a.in + ((long)(n % a.in_mod) * a.H * a.W + (long)(oy * a.stride - a.pad) * a.W + ix0[i]) * (2 * a.Cin) + (((tid & 7) ^ key) << 3);
         x2org[i] = (a.in2 && vm) ? a.in2 + ((long)(n % a.in2_mod) * a.H2 * a.W2 + (long)(oy * a.stride2) * a.W2 + ox * a.stride2) * (2 * a.Cin2) +
-                                       (((tid & 7) ^ ((tid >> 4) & 7)) << 3)
+                                       (((tid & 7) ^ key) << 3)
                                  : nullptr;
     }
 #define SP_ISSUE_X1(I, KY, KX, C0, ST)                                                                   \
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const long so_ = (long)((KY) * a.W + kxe_) * (2 * a.Cin) + 2 * min((C0), a.Cin - 32);          /* (C0 = Cin: past the last K-step) */ \
         const _Float16* p_ = (ok_ && !SP_ABL_NOX) ? xorg[I] + so_ : (const _Float16*)g_split_zero + ((tid & 7) << 3);                  \
         if (SP_SC()) p_ = x2org[I] ? x2org[I] + 2 * min(c2, a.Cin2 - 32) : (const _Float16*)g_split_zero + ((tid & 7) << 3);           \
-        if (!SP_ABL_X3 || (KX) == 0) SP_GLDS16V(p_, (ST) + ((I) * 512 + wave * 64) * 16);               \
+        if (!SP_ABL_X3 || (KX) == 0) SP_GLDS16V(p_, (ST) + (PADX ? xcell0[I] * 128 : ((I) * 512 + wave * 64) * 16));   \
     }
 
     f32x16_s acc[TI][2];
@@ -193,7 +205,12 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     half8_t ah[TI], al[TI], bh[2], bl[2];
     // SHX: per fragment j, is this lane's pixel on the left / right edge of its map row (the kx = 0 / 2 tap is padding there)
     bool edge_l[2] = {false, false}, edge_r[2] = {false, false};
-    if constexpr (SHX) {
+    int bcell[2] = {0, 0};            // PADX: the cell of this lane's pixel of fragment j
+    if constexpr (PADX) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bcell[j] = (wp * 64 + 32 * j + r) + ((wp * 64 + 32 * j + r) >> wlog) + 1;
+    }
+    if constexpr (SHX == 1) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ox = (pix0 + wp * 64 + 32 * j + r) % a.Wo;
@@ -209,12 +226,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
             ah[i] = *(const half8_t*)((WS) + a_off + i * 32 * 64 + coff);                                \
             al[i] = *(const half8_t*)((WS) + WPL + a_off + i * 32 * 64 + coff);                          \
         }                                                                                                \
-        const int sxs_ = SHX ? (((r + (SHIFT)) >> 1) & 7) : sx;                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-            bh[j] = *(const half8_t*)((XS) + b_off + (j * 32 + (SHX ? (SHIFT) : 0)) * 128 + (((2 * (SS) + kq) ^ sxs_) << 4));      \
-            bl[j] = *(const half8_t*)((XS) + b_off + (j * 32 + (SHX ? (SHIFT) : 0)) * 128 + (((4 + 2 * (SS) + kq) ^ sxs_) << 4));  \
+            const int cell_ = bcell[j] + (SHIFT);                                                        \
+            const int sxs_ = PADX ? ((cell_ >> 1) & 7) : (SHX ? (((r + (SHIFT)) >> 1) & 7) : sx);        \
+            const char* const row_ = PADX ? (XS) + XBASE + cell_ * 128 : (XS) + b_off + (j * 32 + (SHX ? (SHIFT) : 0)) * 128;       \
+            bh[j] = *(const half8_t*)(row_ + (((2 * (SS) + kq) ^ sxs_) << 4));                           \
+            bl[j] = *(const half8_t*)(row_ + (((4 + 2 * (SS) + kq) ^ sxs_) << 4));                       \
         }                                                                                                \
-        if (SHX && (SHIFT) != 0) {           /* (wave-uniform) */                                        \
+        if (SHX == 1 && (SHIFT) != 0) {      /* (wave-uniform) */                                        \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
                 const bool z_ = (SHIFT) < 0 ? edge_l[j] : edge_r[j];                                     \
                 u32x4_sp vh_ = __builtin_bit_cast(u32x4_sp, bh[j]), vl_ = __builtin_bit_cast(u32x4_sp, bl[j]);   \
@@ -311,6 +330,13 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         advance();                                                                                       \
     }
     constexpr int PIECES = TI + 4;                       // DMA pieces a wave issues per K-step
+    if constexpr (PADX) {             // the zero cells of every slot: cell 0 and the cell in front of every further map row + the one behind the last
+        const int npad = (SP_PT >> wlog) + 1;
+        for (int idx = tid; idx < NS * npad * 8; idx += 512) {
+            const int sl = idx / (npad * 8), rem = idx - sl * npad * 8, k = rem >> 3;
+            *(u32x4_sp*)(smem + XBASE + sl * XSLOT + k * (a.Wo + 1) * 128 + (rem & 7) * 16) = u32x4_sp{0u, 0u, 0u, 0u};
+        }
+    }
     // K-steps 0 .. D-1 -> slots 0 .. D-1
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -515,10 +541,12 @@ static int launch_split_t(const ConvArgs& a, hipStream_t s) {
     // the three taps of a tap row share a pixel slot (SHX): 3x3, stride 1, pad 1, whole K range per workgroup
     // (a tile must start and end on a map row boundary, so that a pixel's horizontal neighbours are in its own tile: 256 % Wo == 0)
     const bool shx = opt_split_shx() && !SP_TAP_MAJOR && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.partial && SP_PT % a.Wo == 0;
+    const bool padx = shx && a.Wo % 8 == 0 && opt_split_shx() != 2;      // ("split_shx" = 2: the clearing form everywhere: A/B, tests)
 #define SP_LAUNCH(TI_)                                                                                           \
     {                                                                                                            \
-        if (shx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, true>), grid, block, 0, s, a);                   \
-        else hipLaunchKernelGGL((conv_split_kernel<BF, TI_, false>), grid, block, 0, s, a);                      \
+        if (padx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 2>), grid, block, 0, s, a);                     \
+        else if (shx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 1>), grid, block, 0, s, a);                 \
+        else hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 0>), grid, block, 0, s, a);                          \
     }
     if (ct == 256) SP_LAUNCH(4) else if (ct == 128) SP_LAUNCH(2) else SP_LAUNCH(1)
 #undef SP_LAUNCH

@@ -271,7 +271,7 @@ int bmi_set_option(const char* name, int32_t value) {
         return BMI_OK;
     }
     if (std::strcmp(name, "split_shx") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
+        if (value < 0 || value > 2) return BMI_ERR_INVALID;
         opt_split_shx() = value;
         return BMI_OK;
     }

@@ -264,13 +264,13 @@ def test_split_conv_shared_pixel_slot_is_bit_for_bit(split_entries, cin, cout, H
     scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
     r = torch.randn(n, H, H, cout, generator=g).to(DEV) if res else None
     out = {}
-    for shx in (1, 0):
+    for shx in (1, 2, 0):           # 1: a zero cell in front of every map row where rows are multiples of 8 pixels, else edge lanes cleared; 2: cleared everywhere
         _lib.set_option("split_shx", shx)
         try:
             out[shx] = _run_split(x, w, dt, scale, bias, r, True, 1, 1, n, n, n)
         finally:
             _lib.set_option("split_shx", 1)
-    assert torch.isfinite(out[1]).all() and torch.equal(out[1], out[0])
+    assert torch.isfinite(out[1]).all() and torch.equal(out[1], out[0]) and torch.equal(out[2], out[0])
     if H in (16, 8, 4):                                   # the fused shortcut on top (in2 = the block input at twice the map size)
         lib = _lib.lib()
         t16 = TORCH16[dt]
@@ -280,7 +280,7 @@ def test_split_conv_shared_pixel_slot_is_bit_for_bit(split_entries, cin, cout, H
         xp, x2p = gh.pair32_encode(x, t16), gh.pair32_encode(x2, t16)
         wp, w2p = split_planes(w.cpu(), dt).to(DEV), split_planes(w2, dt).to(DEV)
         outs = {}
-        for shx in (1, 0):
+        for shx in (1, 2, 0):
             _lib.set_option("split_shx", shx)
             try:
                 o = torch.full((n, H, H, cout // 32, 2, 32), float("nan"), dtype=t16, device=DEV)
@@ -290,7 +290,7 @@ def test_split_conv_shared_pixel_slot_is_bit_for_bit(split_entries, cin, cout, H
                 outs[shx] = o
             finally:
                 _lib.set_option("split_shx", 1)
-        assert torch.equal(outs[1].view(torch.int16), outs[0].view(torch.int16))
+        assert torch.equal(outs[1].view(torch.int16), outs[0].view(torch.int16)) and torch.equal(outs[2].view(torch.int16), outs[0].view(torch.int16))
 
 
 @pytest.mark.gpu
