@@ -78,6 +78,9 @@ static __device__ unsigned int g_split_zero[64];   // zeros: what an out-of-imag
 #ifndef SP_ABL_NOW
 #define SP_ABL_NOW 0
 #endif
+#ifndef SP_ABL_SHIFT0
+#define SP_ABL_SHIFT0 0      // timing probe: the shared slot is always read straight (loop-invariant fragment addresses); wrong results
+#endif
 #ifndef SP_ABL_X3
 #define SP_ABL_X3 0          // timing probe: the pixel tile is fetched for the kx = 0 tap of a row of taps only (what a padded-row slot shared by the three
 #endif                       // taps of a row would land in LDS); wrong results
@@ -91,7 +94,9 @@ static __device__ unsigned int g_split_zero[64];   // zeros: what an out-of-imag
 // row index, so a shifted read is as conflict-free as a straight one.  Two thirds of the pixel DMA — the larger part of what a K-step lands in
 // LDS — is not issued at all: same-box probe (pixel DMA on the kx = 0 taps only, wrong results) 3x3 stride-1 launches -13 % (128 channels) ...
 // -22 % (256 / 512), the headline step -17 %.  Bit-identical to the unshared loop (the same operands in the same order).
-// SHX = 2 (map rows of 8, 16, 32 ... pixels): no clearing at all — the slot keeps one ZERO cell in front of every map row (cell of tile pixel p =
+// SHX = 2 (map rows of 8, 16, 32 ... pixels; the swizzle key stays that of the PIXEL — pixels 2 m and 2 m + 1 share a key and sit in neighbouring
+// cells of one map row, so the eight keys x two cell parities of a ds_read_b128 lane group are still 16 distinct slots; keyed by the cell index the
+// zero cells shifted the parities and the reads conflicted two ways): no clearing at all — the slot keeps one ZERO cell in front of every map row (cell of tile pixel p =
 // p + p / Wo + 1; written once at kernel start, never by the DMA, whose eight-pixel pieces never straddle a row), so a shifted read at an edge lands
 // on padding by itself.  (SHX = 1 clears 16 registers per 16-deep sub-step behind the fragment reads, in the LOAD part the other wave group's MFMA
 // part has to cover: measured +0.8 % instead of the probe's 17 %.)
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;      // a row beyond M never passes the bounds test
         ix0[i] = ox * a.stride - a.pad;
-        const int key = PADX ? ((xcell0[i] + ((tid >> 3) & 7)) >> 1) & 7 : (tid >> 4) & 7;
+        const int key = (tid >> 4) & 7;      // (row >> 1) & 7 of the tile pixel — PADX too: the key follows the PIXEL, not its cell (below)
         xorg[i] = a.in + ((long)(n % a.in_mod) * a.H * a.W + (long)(oy * a.stride - a.pad) * a.W + ix0[i]) * (2 * a.Cin) + (((tid & 7) ^ key) << 3);
         x2org[i] = (a.in2 && vm) ? a.in2 + ((long)(n % a.in2_mod) * a.H2 * a.W2 + (long)(oy * a.stride2) * a.W2 + ox * a.stride2) * (2 * a.Cin2) +
                                        (((tid & 7) ^ key) << 3)
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         }                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
             const int cell_ = bcell[j] + (SHIFT);                                                        \
-            const int sxs_ = PADX ? ((cell_ >> 1) & 7) : (SHX ? (((r + (SHIFT)) >> 1) & 7) : sx);        \
+            const int sxs_ = SHX ? (((r + (SHIFT)) >> 1) & 7) : sx;     /* key of tile pixel p + SHIFT (a zero cell reads the same under any key) */ \
             const char* const row_ = PADX ? (XS) + XBASE + cell_ * 128 : (XS) + b_off + (j * 32 + (SHX ? (SHIFT) : 0)) * 128;       \
             bh[j] = *(const half8_t*)(row_ + (((2 * (SS) + kq) ^ sxs_) << 4));                           \
             bl[j] = *(const half8_t*)(row_ + (((4 + 2 * (SS) + kq) ^ sxs_) << 4));                       \
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const char* const xs = smem + (SHX ? xc : slot) * XSLOT;      // (+ XBASE inside b_off)
         const int nslot = slot + D >= NS ? slot + D - NS : slot + D;      // ring index of K-step ks + D
         const bool own = ks < nK_own;                    // (SHX: a shortcut K-step reads its own slot straight)
-        const int shift = SHX && own ? ckx - 1 : 0;
+        const int shift = SP_ABL_SHIFT0 ? 0 : (SHX && own ? ckx - 1 : 0);
         const bool needx = SP_NEEDX();                   // does the request issued during this K-step carry pixel pieces
         // LOAD(0)
         SP_READ(ws, xs, 0, shift);
