@@ -322,16 +322,16 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     int xq = 0, xc = 0;                                  // pixel slot of the next fill | of the K-step being computed
 #define SP_NEEDX() (!SHX || SP_SC() || kx == 0)
 #define SP_XDST(SLOT) (smem + XBASE + (SHX ? xq : (SLOT)) * XSLOT)
-#define SP_ISSUE_ALL(SLOT)                                                                               \
+#define SP_ISSUE_ALL(SLOT, NEEDX_)                                                                       \
     {                                                                                                    \
         const int koff_ = SP_KOFF();                                                                     \
         _Pragma("unroll") for (int i = 0; i < TI; ++i) SP_ISSUE_W1(i, koff_, smem + (SLOT) * WSLOT);     \
-        if (SP_NEEDX()) { _Pragma("unroll") for (int i = 0; i < 4; ++i) SP_ISSUE_X1(i, ky, kx, c0, SP_XDST(SLOT)); }   \
+        if (NEEDX_) { _Pragma("unroll") for (int i = 0; i < 4; ++i) SP_ISSUE_X1(i, ky, kx, c0, SP_XDST(SLOT)); }   \
     }
     // (after a request: the fill slot moves on if the request carried pixel pieces; then the request state)
-#define SP_NEXT_REQUEST()                                                                                \
+#define SP_NEXT_REQUEST(NEEDX_)                                                                          \
     {                                                                                                    \
-        if (SHX && SP_NEEDX()) xq = xq + 1 == NS ? 0 : xq + 1;                                           \
+        if (SHX && (NEEDX_)) xq = xq + 1 == NS ? 0 : xq + 1;                                             \
         advance();                                                                                       \
     }
     constexpr int PIECES = TI + 4;                       // DMA pieces a wave issues per K-step
@@ -345,8 +345,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     // K-steps 0 .. D-1 -> slots 0 .. D-1
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        SP_ISSUE_ALL(d);
-        SP_NEXT_REQUEST();
+        const bool nx = SP_NEEDX();
+        SP_ISSUE_ALL(d, nx);
+        SP_NEXT_REQUEST(nx);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -367,51 +368,80 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     if (g == 1) SP_BARRIER();
     int slot = 0;                                        // ring index of K-step ks
     const int nK_own = a.ksize * a.ksize * (a.Cin / 32);  // the conv's own K-steps (then the fused shortcut's)
-    int ckx = 0;                                         // SHX: kx of K-step ks (taps inner, three per row)
-    for (int ks = 0; ks < nK; ++ks) {
-        const char* const ws = smem + slot * WSLOT;
-        const char* const xs = smem + (SHX ? xc : slot) * XSLOT;      // (+ XBASE inside b_off)
-        const int nslot = slot + D >= NS ? slot + D - NS : slot + D;      // ring index of K-step ks + D
-        const bool own = ks < nK_own;                    // (SHX: a shortcut K-step reads its own slot straight)
-        const int shift = SP_ABL_SHIFT0 ? 0 : (SHX && own ? ckx - 1 : 0);
-        const bool needx = SP_NEEDX();                   // does the request issued during this K-step carry pixel pieces
-        // LOAD(0)
-        SP_READ(ws, xs, 0, shift);
-        if constexpr (D == 1) { SP_ISSUE_ALL(nslot); }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SP_BARRIER();
-        // MFMA(0)
+    // One K-step.  SHIFT_ = kx - 1 of a shared-slot tap (0: a straight read), NEEDX_ = the request issued during this K-step (for K-step ks + D)
+    // carries pixel pieces.  With literal arguments everything they decide folds at compile time (the unrolled tap rows below).
 #define SP_HOOK0(G)                                                                                      \
     {                                                                                                    \
         if constexpr (D == 2) {          /* two groups: half of the K-step's pieces behind each */       \
             const int koff_ = SP_KOFF();                                                                 \
-            if ((G) == 0) { if (needx) { SP_ISSUE_X1(0, ky, kx, c0, SP_XDST(nslot)); SP_ISSUE_X1(1, ky, kx, c0, SP_XDST(nslot)); } SP_ISSUE_W1(0, koff_, smem + nslot * WSLOT); } \
-            if ((G) == 1) { if (needx) { SP_ISSUE_X1(2, ky, kx, c0, SP_XDST(nslot)); SP_ISSUE_X1(3, ky, kx, c0, SP_XDST(nslot)); } \
+            if ((G) == 0) { if (needx_) { SP_ISSUE_X1(0, ky, kx, c0, SP_XDST(nslot)); SP_ISSUE_X1(1, ky, kx, c0, SP_XDST(nslot)); } SP_ISSUE_W1(0, koff_, smem + nslot * WSLOT); } \
+            if ((G) == 1) { if (needx_) { SP_ISSUE_X1(2, ky, kx, c0, SP_XDST(nslot)); SP_ISSUE_X1(3, ky, kx, c0, SP_XDST(nslot)); } \
                             if constexpr (TI == 2) { SP_ISSUE_W1(TI - 1, koff_, smem + nslot * WSLOT); } } \
         }                                                                                                \
     }
-        SP_MFMA(SP_HOOK0);
-#undef SP_HOOK0
-        SP_NEXT_REQUEST();
-        SP_BARRIER();
-        // LOAD(1)
-        SP_READ(ws, xs, 1, shift);
-        // K-step ks + 1's operands have landed (this wave's pieces): all but the pieces of the request issued during this K-step (D = 2)
-        if (SHX && !needx) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * TI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * PIECES) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SP_BARRIER();
-        // MFMA(1)
 #define SP_HOOK1(G) {}
-        SP_MFMA(SP_HOOK1);
-#undef SP_HOOK1
-        SP_BARRIER();
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        if constexpr (SHX) {                             // the pixel slot moves on behind the third tap of a row (behind every shortcut K-step)
-            if (!own || ckx == 2) xc = xc + 1 == NS ? 0 : xc + 1;
-            ckx = ckx == 2 ? 0 : ckx + 1;
+#define SP_STEP(SHIFT_, NEEDX_)                                                                          \
+    {                                                                                                    \
+        const char* const ws = smem + slot * WSLOT;                                                      \
+        const char* const xs = smem + (SHX ? xc : slot) * XSLOT;      /* (+ XBASE inside b_off) */       \
+        const int nslot = slot + D >= NS ? slot + D - NS : slot + D;  /* ring index of K-step ks + D */  \
+        const bool needx_ = (NEEDX_);                                                                    \
+        /* LOAD(0) */                                                                                    \
+        SP_READ(ws, xs, 0, SHIFT_);                                                                      \
+        if constexpr (D == 1) { SP_ISSUE_ALL(nslot, needx_); }                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+        SP_BARRIER();                                                                                    \
+        /* MFMA(0) */                                                                                    \
+        SP_MFMA(SP_HOOK0);                                                                               \
+        SP_NEXT_REQUEST(needx_);                                                                         \
+        SP_BARRIER();                                                                                    \
+        /* LOAD(1) */                                                                                    \
+        SP_READ(ws, xs, 1, SHIFT_);                                                                      \
+        /* K-step ks + 1's operands have landed (this wave's pieces): all but the pieces of the request issued during this K-step (D = 2) */ \
+        if (SHX && !needx_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * TI) : "memory");         \
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * PIECES) : "memory");                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+        SP_BARRIER();                                                                                    \
+        /* MFMA(1) */                                                                                    \
+        SP_MFMA(SP_HOOK1);                                                                               \
+        SP_BARRIER();                                                                                    \
+        slot = slot + 1 == NS ? 0 : slot + 1;                                                            \
+    }
+    int ks0 = 0;                                         // K-steps done by the unrolled rows
+    if constexpr (SHX != 0) {
+        // Whole tap rows, the three taps unrolled — which tap reads the slot shifted which way and which K-step's request
+        // carries the next row's pixel pieces (the one D K-steps ahead of a row's first tap) are compile-time, the loop is ONE basic block again
+        // (with run-time decisions it was 124 scalar and 8 lane-spill instructions and 9 branches per K-step against 72 / 0 / 1, and kept 4-10 %
+        // of the 16-24 % the probe promised).  Requests past the last K-step follow the same pattern (clamped addresses, never read).  With a
+        // fused shortcut the last tap row and the shortcut's K-steps (a slot each) stay with the run-time loop below.
+        if (!SP_ABL_SHIFT0) {
+            const int rows = nK_own / 3 - (a.in2 ? 1 : 0);
+            ks0 = 3 * rows;
+            for (int row = 0; row < rows; ++row) {
+                const int ks = row;                              // (SP_READ's probe switch only)
+                SP_STEP(-1, false);                              // kx = 0: requests kx = 1 (D = 1) | kx = 2 (D = 2) of this row
+                SP_STEP(0, D == 2);                              // kx = 1: requests kx = 2 | the next row's first tap
+                SP_STEP(1, D == 1);                              // kx = 2: requests the next row's first tap | its second
+                xc = xc + 1 == NS ? 0 : xc + 1;
+            }
         }
     }
+    {
+        int ckx = 0;                                     // SHX: kx of K-step ks (taps inner, three per row)
+        for (int ks = ks0; ks < nK; ++ks) {
+            const bool own = ks < nK_own;                // (SHX: a shortcut K-step reads its own slot straight)
+            const int shift = SP_ABL_SHIFT0 ? 0 : (SHX && own ? ckx - 1 : 0);
+            const bool needx = SP_NEEDX();               // does the request issued during this K-step carry pixel pieces
+            SP_STEP(shift, needx);
+            if constexpr (SHX != 0) {                    // the pixel slot moves on behind the third tap of a row (behind every shortcut K-step)
+                if (!own || ckx == 2) xc = xc + 1 == NS ? 0 : xc + 1;
+                ckx = ckx == 2 ? 0 : ckx + 1;
+            }
+        }
+    }
+#undef SP_STEP
+#undef SP_HOOK0
+#undef SP_HOOK1
     if (g == 0) SP_BARRIER();
 #undef SP_ISSUE_W1
 #undef SP_ISSUE_X1
