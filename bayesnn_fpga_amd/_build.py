@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so
 travels to the GPU box with the snapshot (it is git-ignored, not gpurun-ignored).
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -22,17 +23,48 @@ def _hipcc():
     return exe
 
 
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "bayesnn_fpga_amd.h")]
+
+
+def _want(src, hdr_sha):
+    """Content key of one object: its source, every header, the flags (NOT mtimes: a snapshot copied to the GPU box, or a checkout, gives
+    every file a fresh timestamp in arbitrary order, and an object that was not recompiled could look newer than its edited source)."""
+    return _sha([os.path.join(CSRC, src)], hdr_sha + " ".join(FLAGS))
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _lib_key(keys):
+    return hashlib.sha256("".join(keys).encode()).hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "bayesnn_fpga_amd.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    hdr_sha = _sha(_headers())
+    return _read(LIB + ".sha256") != _lib_key([_want(src, hdr_sha) for src in SOURCES])
 
 
 def build(force=False, verbose=False):
-    """Compiles what is stale: an object is rebuilt when its source or any header is newer than it; objects of sources that no
-    longer exist are removed (csrc/build/ travels to the GPU box with the snapshot)."""
+    """Compiles what is stale BY CONTENT: beside every object sits the sha256 of (its source + all headers + the flags) it was compiled
+    from, beside the library the digest of those keys; anything whose key differs is rebuilt, objects of sources that no longer exist are
+    removed (csrc/build/ and the stamps travel to the GPU box with the snapshot)."""
     if not force and not _stale():
         return LIB
     hipcc = _hipcc()
@@ -40,29 +72,34 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     wanted = {src.replace(".hip", ".o") for src in SOURCES}
     for f in os.listdir(objdir):
-        if f.endswith(".o") and f not in wanted:
+        if (f.endswith(".o") and f not in wanted) or (f.endswith(".o.sha256") and f[:-len(".sha256")] not in wanted):
             os.remove(os.path.join(objdir, f))
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "bayesnn_fpga_amd.h")]
-    t_hdr = max(os.path.getmtime(h) for h in headers)
+    hdr_sha = _sha(_headers())
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(CSRC, src)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(t_hdr, os.path.getmtime(path)):
-            return obj
+        key = _want(src, hdr_sha)
+        if not force and os.path.exists(obj) and _read(obj + ".sha256") == key:
+            return obj, key
         cmd = [hipcc, *FLAGS, "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr)
-        return obj
+        with open(obj + ".sha256", "w") as f:
+            f.write(key)
+        return obj, key
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(cc, SOURCES))
+        done = list(ex.map(cc, SOURCES))
+    objs = [o for o, _ in done]
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    with open(LIB + ".sha256", "w") as f:
+        f.write(_lib_key([k for _, k in done]))
     return LIB
 
 

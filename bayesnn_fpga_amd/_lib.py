@@ -19,7 +19,7 @@ OP_STEM, OP_CONV, OP_MASK, OP_HEAD, OP_MAXPOOL, OP_DENSE = 1, 2, 3, 4, 5, 6
 PROFILE_SLOTS = 8
 CONV_FAMILY_KERNELS = ("conv3x3_patch_kernel", "conv_igemm_wide_kernel", "conv_igemm_kernel", "conv3x3_pw_kernel", "conv1x1_stream_kernel",
                        "conv3x3_s2_kernel", "conv_split_kernel", "conv1x1_seam_kernel")
-ABI_VERSION = 510             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
+ABI_VERSION = 600             # BMI_VERSION of include/bayesnn_fpga_amd.h this binding was written against
 CONV_FAMILIES = len(CONV_FAMILY_KERNELS)     # BMI_CONV_FAMILIES
 PROFILE_NAMES = {OP_STEM: "stem", OP_CONV: "conv_igemm", OP_MASK: "mask", OP_HEAD: "head", OP_MAXPOOL: "maxpool",
                  OP_DENSE: "dense"}
@@ -58,6 +58,7 @@ _PROTOS = {
     "bmi_version": (C.c_int, []),
     "bmi_error_string": (C.c_char_p, [C.c_int]),
     "bmi_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "bmi_engine_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "bmi_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "bmi_destroy": (C.c_int, [C.c_void_p]),
     "bmi_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
@@ -76,6 +77,8 @@ _PROTOS = {
                                        C.c_void_p]),
     "bmi_finalize": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    "bmi_finalize_checked": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "bmi_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "bmi_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bmi_philox_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
@@ -143,7 +146,8 @@ def check(code, what):
 
 
 def set_option(name, value):
-    """Process-wide kernel-selection switch (bmi_set_option): e.g. set_option("mfma_shape_patch", 16)."""
+    """Process DEFAULT of a kernel-selection switch (bmi_set_option): e.g. set_option("mfma_shape_patch", 16).  Read by the single-kernel entry
+    points and COPIED into every engine created afterwards; a live engine keeps its copy (``MCDEngine.set_option`` edits one engine's)."""
     check(lib().bmi_set_option(name.encode(), int(value)), f"bmi_set_option({name})")
 
 

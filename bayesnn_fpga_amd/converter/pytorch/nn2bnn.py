@@ -98,7 +98,7 @@ class MCDropout(EngineModelMixin, nn.Module):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise RuntimeError("bayesnn_fpga_amd models run on an MI355X through the HIP engine; got a CPU tensor "
                                "(there is no CPU fallback)")
-        eng = self.engine(x.device, max_batch=x.shape[0])
+        eng = self.engine(x.device, max_batch=x.shape[0], calib=x)
         r = eng.predict(x, self.nSamples, seed=self.mc_seed, t_begin=self.mc_pass)
         self.advance(self.nSamples)
         mean = [r["logit_mean"][e].to(torch.float32) for e in range(self.n_exits)]

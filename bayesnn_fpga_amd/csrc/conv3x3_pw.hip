@@ -1004,7 +1004,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pwp_kernel(ConvArgs a, int n_t
 #undef BLDS16
 }
 
-int& opt_pw_persist() { static int v = 1; return v; }
 
 // Shapes this kernel takes: 3x3 / stride 1 / pad 1 on 8x8 or 4x4 maps with Cout % 256 == 0.
 bool conv_takes_pw_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo) {

@@ -828,7 +828,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2_kernel(ConvArgs a, int n_ti
 #undef A_TILE
 }
 
-int& opt_conv_s2() { static int v = 1; return v; }
 
 // Shapes this kernel takes: 3x3 / stride 2 / pad 1, 32x32 -> 16x16, 16x16 -> 8x8 or 8x8 -> 4x4, Cout % 256 == 0 (both convs of
 // a pair together), BN + ReLU epilogue.

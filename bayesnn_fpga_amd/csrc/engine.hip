@@ -78,6 +78,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 struct bmi_engine_s {
+    BmiOptions opts;            // the process defaults at bmi_create (bmi_engine_set_option edits this copy): every entry point below runs under it
     std::vector<TensorInfo> tensors;
     std::vector<OpInfo> prefix, suffix;
     int n_exits = 0, out_dim = 0;
@@ -97,7 +98,8 @@ struct bmi_engine_s {
     float* logits_out = nullptr;         // (run time) [t_count][E][batch][C] of the current call, or null
     bool no_moments = false;             // (run time) the heads write per-sample logits only
     int logits_t_begin = 0, logits_batch = 0;
-    int mask_stride = 1, mask_t_begin = 0;    // (run time) stride != 1: a site's mask of sample t is row (t - mask_t_begin) % M of its PERMUTED table
+    int mask_stride = 1, mask_t_begin = 0;    // (run time) mask_permuted: a site's mask of sample t is row (t - mask_t_begin) % M of its PERMUTED table
+    bool mask_permuted = false;
     std::vector<std::pair<const float*, size_t>> perm;   // (bmi_plan) Masksembles tables (device pointer of the site) -> workspace offset of the permuted copy
     // profiling
     bool profiling = false;
@@ -182,28 +184,62 @@ static int shape_from_env(const char* primary, const char* fallback) {
     const int x = v ? std::atoi(v) : 0;
     return x == 16 || x == 32 ? x : BMI_DEFAULT_MFMA_SHAPE;
 }
-int& opt_mfma_shape_patch() { static int v = shape_from_env("BMI_MFMA_SHAPE", nullptr); return v; }
-int& opt_wide_persist_min() { static int v = 10; return v; }   // > one tile per CU (same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
-int& opt_conv_pw() { static int v = 1; return v; }
-int& opt_epilogue_lite() { static int v = 1; return v; }
-int& opt_lazy_order() { static int v = 1; return v; }
-int& opt_dense_exact() { static int v = 0; return v; }
-int& opt_splitk() { static int v = 1; return v; }
-int& opt_conv_stream() { static int v = 1; return v; }
-int& opt_conv_seam() { static int v = 1; return v; }
-int& opt_split_tile() { static int v = 1; return v; }
-int& opt_split_shx() { static int v = 1; return v; }
-int& opt_conv_wide() { static int v = 1; return v; }
-int& opt_conv_pool() { static int v = 1; return v; }
-int& opt_mask_lazy() { static int v = 1; return v; }
-int& opt_unit_dtype() { static int v = BMI_DTYPE_F16; return v; }
+static BmiOptions initial_options() {
+    BmiOptions o;
+    o.mfma_shape_patch = shape_from_env("BMI_MFMA_SHAPE", nullptr);
+    o.mfma_shape_wide = shape_from_env("BMI_MFMA_SHAPE_WIDE", "BMI_MFMA_SHAPE");
+    o.unit_dtype = BMI_DTYPE_F16;
+    const char* e = std::getenv("BMI_XCD_SPLIT");
+    const int x = e ? std::atoi(e) : 0;
+    o.xcd_split = x == 1 || x == 2 || x == 4 ? x : 0;
+    return o;
+}
+BmiOptions& bmi_default_options() { static BmiOptions o = initial_options(); return o; }
+thread_local const BmiOptions* bmi_tl_options = nullptr;
 static int unit_pair() { const int d = opt_unit_dtype(); return d == BMI_DTYPE_F16X2 ? 1 : (d == BMI_DTYPE_BF16X3 ? 2 : 0); }
 static bool unit_f32act() { const int d = opt_unit_dtype(); return d == BMI_DTYPE_F32 || d == BMI_DTYPE_F16X2 || d == BMI_DTYPE_BF16X3; }
-int& opt_ws_no_reuse() { static int v = 0; return v; }
-int& opt_lazy_planar() { static int v = 1; return v; }
-int& opt_xcd_split() {
-    static int v = [] { const char* e = std::getenv("BMI_XCD_SPLIT"); const int x = e ? std::atoi(e) : 0; return x == 1 || x == 2 || x == 4 ? x : 0; }();
-    return v;
+
+// One named switch of an option set (bmi_set_option: the process defaults; bmi_engine_set_option: one engine's snapshot).
+static int set_named_option(BmiOptions& o, const char* name, int32_t value) {
+    if (!name) return BMI_ERR_INVALID;
+    struct Row { const char* name; int BmiOptions::*field; int lo, hi; };
+    static const Row rows[] = {
+        {"unit_entry_dtype", &BmiOptions::unit_dtype, BMI_DTYPE_F16, BMI_DTYPE_BF16X3},
+        {"pw_persist", &BmiOptions::pw_persist, 0, 1},
+        {"lazy_planar", &BmiOptions::lazy_planar, 0, 1},
+        {"ws_no_reuse", &BmiOptions::ws_no_reuse, 0, 1},                 // read by bmi_plan
+        {"wide_persist_min_x10", &BmiOptions::wide_persist_min, 10, 1000},
+        {"conv_pw", &BmiOptions::conv_pw, 0, 4},
+        {"conv_s2", &BmiOptions::conv_s2, 0, 2},
+        {"conv_pool", &BmiOptions::conv_pool, 0, 2},
+        {"mask_lazy", &BmiOptions::mask_lazy, 0, 1},
+        {"conv_wide", &BmiOptions::conv_wide, 0, 1},
+        {"split_shx", &BmiOptions::split_shx, 0, 2},
+        {"split_tile", &BmiOptions::split_tile, 0, 1},
+        {"conv_seam", &BmiOptions::conv_seam, 0, 3},                      // read by bmi_create (which ops merge) and at launch
+        {"conv_stream", &BmiOptions::conv_stream, 0, 3},
+        {"splitk", &BmiOptions::splitk, 0, 1},                            // read by bmi_plan
+        {"dense_exact", &BmiOptions::dense_exact, 0, 1},
+        {"lazy_order", &BmiOptions::lazy_order, 0, 1},
+        {"epilogue_lite", &BmiOptions::epilogue_lite, 0, 2},
+        {"block_fuse", &BmiOptions::block_fuse, 0, 2},                    // read by bmi_create (which ops merge) and at launch
+    };
+    for (const Row& r : rows)
+        if (std::strcmp(name, r.name) == 0) {
+            if (value < r.lo || value > r.hi) return BMI_ERR_INVALID;
+            o.*(r.field) = value;
+            return BMI_OK;
+        }
+    if (std::strcmp(name, "xcd_split") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return BMI_ERR_INVALID;
+        o.xcd_split = value;
+        return BMI_OK;
+    }
+    const bool patch = std::strcmp(name, "mfma_shape_patch") == 0, wide = std::strcmp(name, "mfma_shape_wide") == 0;
+    if (!patch && !wide) return BMI_ERR_INVALID;
+    if (value != 0 && value != 16 && value != 32) return BMI_ERR_INVALID;
+    (patch ? o.mfma_shape_patch : o.mfma_shape_wide) = value ? value : BMI_DEFAULT_MFMA_SHAPE;
+    return BMI_OK;
 }
 // Channel-tile classes for xcd_tile_map: keep the weights one XCD streams under ~2.5 MB of its 4 MB L2.
 int xcd_split_for(int n_ctiles, size_t weight_bytes) {
@@ -212,115 +248,12 @@ int xcd_split_for(int n_ctiles, size_t weight_bytes) {
     while (cs > 1 && n_ctiles % cs != 0) cs >>= 1;
     return cs;
 }
-int& opt_mfma_shape_wide() { static int v = shape_from_env("BMI_MFMA_SHAPE_WIDE", "BMI_MFMA_SHAPE"); return v; }
 
 extern "C" {
 
 int bmi_version(void) { return BMI_VERSION; }
 
-int bmi_set_option(const char* name, int32_t value) {
-    if (!name) return BMI_ERR_INVALID;
-    if (std::strcmp(name, "unit_entry_dtype") == 0) {
-        if (value < BMI_DTYPE_F16 || value > BMI_DTYPE_BF16X3) return BMI_ERR_INVALID;
-        opt_unit_dtype() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "pw_persist") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_pw_persist() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "lazy_planar") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_lazy_planar() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "ws_no_reuse") == 0) {   // read by bmi_plan
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_ws_no_reuse() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "wide_persist_min_x10") == 0) {
-        if (value < 10 || value > 1000) return BMI_ERR_INVALID;
-        opt_wide_persist_min() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "conv_pw") == 0) {
-        if (value < 0 || value > 4) return BMI_ERR_INVALID;
-        opt_conv_pw() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "conv_s2") == 0) {
-        if (value < 0 || value > 2) return BMI_ERR_INVALID;
-        opt_conv_s2() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "conv_pool") == 0) {
-        if (value < 0 || value > 2) return BMI_ERR_INVALID;
-        opt_conv_pool() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "mask_lazy") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_mask_lazy() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "conv_wide") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_conv_wide() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "split_shx") == 0) {
-        if (value < 0 || value > 2) return BMI_ERR_INVALID;
-        opt_split_shx() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "split_tile") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_split_tile() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "conv_seam") == 0) {
-        if (value < 0 || value > 3) return BMI_ERR_INVALID;
-        opt_conv_seam() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "conv_stream") == 0) {
-        if (value < 0 || value > 3) return BMI_ERR_INVALID;
-        opt_conv_stream() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "splitk") == 0) {   // read by bmi_plan
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_splitk() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "dense_exact") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_dense_exact() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "lazy_order") == 0) {
-        if (value != 0 && value != 1) return BMI_ERR_INVALID;
-        opt_lazy_order() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "epilogue_lite") == 0) {
-        if (value != 0 && value != 1 && value != 2) return BMI_ERR_INVALID;
-        opt_epilogue_lite() = value;
-        return BMI_OK;
-    }
-    if (std::strcmp(name, "xcd_split") == 0) {
-        if (value != 0 && value != 1 && value != 2 && value != 4) return BMI_ERR_INVALID;
-        opt_xcd_split() = value;
-        return BMI_OK;
-    }
-    const bool patch = std::strcmp(name, "mfma_shape_patch") == 0, wide = std::strcmp(name, "mfma_shape_wide") == 0;
-    if (!patch && !wide) return BMI_ERR_INVALID;
-    if (value != 0 && value != 16 && value != 32) return BMI_ERR_INVALID;
-    (patch ? opt_mfma_shape_patch() : opt_mfma_shape_wide()) = value ? value : BMI_DEFAULT_MFMA_SHAPE;
-    return BMI_OK;
-}
+int bmi_set_option(const char* name, int32_t value) { return set_named_option(bmi_default_options(), name, value); }
 
 const char* bmi_error_string(int code) {
     switch (code) {
@@ -340,6 +273,8 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     if (desc->dtype < BMI_DTYPE_F16 || desc->dtype > BMI_DTYPE_BF16X3) return BMI_ERR_INVALID;
     bmi_engine_s* e = new (std::nothrow) bmi_engine_s();
     if (!e) return BMI_ERR_NOMEM;
+    e->opts = bmi_default_options();
+    BmiOptionScope opt_scope(&e->opts);
     e->n_exits = desc->n_exits;
     e->out_dim = desc->out_dim;
     e->bf16 = desc->dtype == BMI_DTYPE_BF16;
@@ -396,7 +331,7 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 int64_t macs = (int64_t)op.ho * op.wo * op.cout * d.ksize * d.ksize * tin.c;
                 if (d.kind == BMI_OP_CONV && d.in2 >= 0 && e->f32 && !e->split) { rc = BMI_ERR_UNSUPPORTED; break; }   // a speed feature (BN scales folded into the weights): never in the exact engine
                 if (d.kind == BMI_OP_CONV && d.in2 >= 0) {
-                    if (!tensor_ok(d.in2) || !written[d.in2] || d.in2 == 0 || !d.weight2 || d.scale) { rc = BMI_ERR_INVALID; break; }
+                    if (!tensor_ok(d.in2) || !written[d.in2] || d.in2 == 0 || !d.weight2 || (d.scale && !e->split)) { rc = BMI_ERR_INVALID; break; }   // (split engines: the host's per-channel power-of-two lift comes back as `scale`)
                     const TensorInfo& t2 = e->tensors[d.in2];
                     if (t2.h % op.ho != 0 || t2.h / op.ho != t2.w / op.wo || t2.w % op.wo != 0) { rc = BMI_ERR_UNSUPPORTED; break; }
                     // fp16 / bf16: conv3x3_patch / conv3x3_pw carry the shortcut; the split engines: extra K-steps of conv_split (any conv geometry)
@@ -714,6 +649,11 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
     return BMI_OK;
 }
 
+int bmi_engine_set_option(bmi_handle h, const char* name, int32_t value) {
+    if (!h) return BMI_ERR_INVALID;
+    return set_named_option(h->opts, name, value);
+}
+
 int bmi_destroy(bmi_handle h) {
     if (!h) return BMI_ERR_INVALID;
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -724,6 +664,7 @@ int bmi_destroy(bmi_handle h) {
 
 int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* workspace_bytes) {
     if (!h || max_batch < 1 || chunk_samples < 1 || !workspace_bytes) return BMI_ERR_INVALID;
+    BmiOptionScope opt_scope(&h->opts);
     const size_t B = (size_t)max_batch, NS = (size_t)max_batch * chunk_samples;
     for (const TensorInfo& t : h->tensors)  // pixel indices (N * H * W) stay inside int32
         if (NS * t.h * t.w >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;
@@ -898,7 +839,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
     // (t - t_begin) % M — no kernel knows about the stride
     auto resolve_site = [&](const bmi_site* site, uint64_t sd, int c0, uint64_t elem_off = 0) {
         SiteArgs sa = ::resolve_site(site, sd, c0, elem_off);
-        if (sa.kind == BMI_SITE_MASKSEMBLE && e->mask_stride != 1)
+        if (sa.kind == BMI_SITE_MASKSEMBLE && e->mask_permuted)
             for (const auto& pr : e->perm)
                 if (pr.first == sa.masks) {
                     sa.masks = (const float*)(ws + pr.second);
@@ -1243,6 +1184,7 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
                     int32_t mask_cnt0, double* S1, double* S2, double* SL, void* workspace, size_t workspace_bytes,
                     bmi_stream stream) {
     if (!h || !x_nchw || !S1 || !S2 || !SL || !workspace) return BMI_ERR_INVALID;
+    BmiOptionScope opt_scope(&h->opts);
     if (batch < 1 || t_count < 1 || t_begin < 0 || mask_cnt0 < 0) return BMI_ERR_INVALID;
     if (h->max_batch == 0 || batch > h->max_batch) return BMI_ERR_INVALID;
     if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
@@ -1267,12 +1209,15 @@ int bmi_forward_mcd_samples(bmi_handle h, const float* x_nchw, int32_t batch, in
                             int32_t mask_cnt0, int32_t mask_stride, float* logits, double* S1, double* S2, double* SL, void* workspace,
                             size_t workspace_bytes, bmi_stream stream) {
     if (!h || !logits || !workspace || mask_stride < 1 || t_begin < 0 || mask_cnt0 < 0) return BMI_ERR_INVALID;
+    BmiOptionScope opt_scope(&h->opts);
     if ((S1 || S2 || SL) && !(S1 && S2 && SL)) return BMI_ERR_INVALID;
     if (h->max_batch == 0 || batch < 1 || batch > h->max_batch) return BMI_ERR_INVALID;
     if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
     int cnt0 = mask_cnt0;
-    if (mask_stride != 1 && !h->perm.empty()) {
+    if ((mask_stride != 1 || t_begin != 0) && !h->perm.empty()) {
         // gather every Masksembles table in the order this call walks it: table'[r] = table[(mask_cnt0 + r * stride) % M]
+        // (stride 1 from t_begin > 0 too: the kernels index (cnt0 + t) mod M with the GLOBAL sample index t, which would rotate the walk by t_begin —
+        //  this call's contract is mask_cnt0 for its FIRST sample, whatever t_begin)
         for (const std::vector<OpInfo>* ops : {&h->prefix, &h->suffix})
             for (const OpInfo& op : *ops) {
                 const bmi_site& st = op.d.site;
@@ -1287,6 +1232,7 @@ int bmi_forward_mcd_samples(bmi_handle h, const float* x_nchw, int32_t batch, in
                     }
             }
         h->mask_stride = mask_stride;
+        h->mask_permuted = true;
         h->mask_t_begin = t_begin;
         cnt0 = 0;
     }
@@ -1296,7 +1242,7 @@ int bmi_forward_mcd_samples(bmi_handle h, const float* x_nchw, int32_t batch, in
     h->no_moments = !moments;
     const int rc = bmi_forward_mcd(h, x_nchw, batch, t_begin, t_count, seed, cnt0, moments ? S1 : &dummy, moments ? S2 : &dummy, moments ? SL : &dummy,
                                    workspace, workspace_bytes, stream);
-    h->logits_out = nullptr; h->mask_stride = 1; h->mask_t_begin = 0; h->no_moments = false;
+    h->logits_out = nullptr; h->mask_stride = 1; h->mask_t_begin = 0; h->mask_permuted = false; h->no_moments = false;
     return rc;
 }
 
@@ -1304,6 +1250,7 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
                          double threshold, int32_t first_exit, double* S1, double* S2, double* SL, int32_t* exit_of_image,
                          int32_t* active_after, void* workspace, size_t workspace_bytes, bmi_stream stream) {
     if (!h || !x_nchw || !S1 || !S2 || !SL || !workspace || !exit_of_image || !active_after) return BMI_ERR_INVALID;
+    BmiOptionScope opt_scope(&h->opts);
     if (batch < 1 || t_count < 1 || mask_cnt0 < 0 || first_exit < 0) return BMI_ERR_INVALID;
     if (h->max_batch == 0 || batch > h->max_batch) return BMI_ERR_INVALID;
     if (t_count > h->chunk || h->f32) return BMI_ERR_UNSUPPORTED;     // an exit's decision needs ALL samples of the stage in the workspace
@@ -1353,7 +1300,13 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
 int bmi_finalize(int64_t n, int32_t t_total, const double* S1, const double* S2, const double* SL, double* mean,
                  double* var, double* logit_mean, bmi_stream stream) {
     if (!S1 || !S2 || !SL || !mean || !var || !logit_mean) return BMI_ERR_INVALID;
-    return launch_finalize(n, t_total, S1, S2, SL, mean, var, logit_mean, (hipStream_t)stream);
+    return launch_finalize(n, t_total, S1, S2, SL, mean, var, logit_mean, nullptr, (hipStream_t)stream);
+}
+
+int bmi_finalize_checked(int64_t n, int32_t t_total, const double* S1, const double* S2, const double* SL, double* mean,
+                         double* var, double* logit_mean, int32_t* nonfinite, bmi_stream stream) {
+    if (!S1 || !S2 || !SL || !mean || !var || !logit_mean || !nonfinite) return BMI_ERR_INVALID;
+    return launch_finalize(n, t_total, S1, S2, SL, mean, var, logit_mean, nonfinite, (hipStream_t)stream);
 }
 
 int bmi_profile_enable(bmi_handle h, int32_t enable) {

@@ -148,39 +148,61 @@ int launch_fill_int(int* p, int n, int v, hipStream_t s);
 int launch_mask_permute(const float* src, float* dst, int m, int c, int cnt0, int stride, hipStream_t s);
 int launch_expand_rows(const int* active, int bc, int batch, int tc, int* rows, hipStream_t s);   // rows[tl*bc + i] = tl*batch + active[i]
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
-                    double* var, double* lm, hipStream_t s);
+                    double* var, double* lm, int* nonfinite, hipStream_t s);
 int launch_philox_mask(uint8_t* keep, int64_t n, uint64_t seed, int site, int t, float p, hipStream_t s);
 // planar_w > 0: the bits in the lazy site's planar layout (rows of planar_w pixels; 2-bit sites, c % 64 == 0)
 int launch_mask_bits(uint8_t* bits, int n, int hw, int c, const SiteArgs& site, int batch, int t0, hipStream_t s, int planar_w = 0);
 // out = round16(in * scale); planar_w > 0: images of planar_hw pixels x planar_c channels stored in the planar layout
 int launch_scale_copy(const _Float16* in, _Float16* out, long n, float scale, int bf16, hipStream_t s, int planar_hw = 0, int planar_w = 0, int planar_c = 0);
-int& opt_pw_persist();         // 1: plain-epilogue launches of conv3x3_pw run in its persistent form (conv3x3_pwp_kernel), 0: never
-int& opt_lazy_planar();        // 1: lazy sites whose readers are all stride-2 consumers store their scaled copy + bits in the planar layout
 int launch_splitk_finish(const ConvArgs& a, hipStream_t s);   // after a split-K conv_igemm launch
 int launch_conv1x1_seam(const ConvArgs& a, const ConvArgs& b, hipStream_t s);   // conv1x1_seam.hip: a = expand conv (+ residual), b = the reduce conv that reads a.out
 bool conv_takes_seam_kernel(int cmid, int cw, int cn);
 int launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo);
 
-// process-wide kernel-selection switches (bmi_set_option); 16 or 32
-int& opt_mfma_shape_patch();
-int& opt_mfma_shape_wide();
-int& opt_unit_dtype();       // BMI_DTYPE_* of the single-kernel entry points
-int& opt_wide_persist_min();   // persistent wide kernel when blocks * 10 > value * n_cu
-int& opt_conv_pw();            // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
-int& opt_conv_wide();          // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
-int& opt_mask_lazy();          // 1: a lazy site (engine.hip, bmi_create) writes keep bits + one scaled copy and its consumers mask in LDS, 0: always materialised
-int& opt_conv_pool();          // 1: a conv whose 4x4 map feeds one exit head only writes the pooled means (conv3x3_s2), 0: never
-int& opt_conv_s2();            // 1: plain 3x3 stride-2 convs run in conv3x3_s2 (2 = without its minimum-grid rule: tests), 0: conv_igemm_wide
-int& opt_split_shx();         // 1: conv_split's 3x3 stride-1 launches fetch a tap row's pixel tile once for its three taps (0: once per tap: A/B, tests)
-int& opt_split_tile();        // 1: conv_split narrows its channel tile on small grids (0: always the widest that divides Cout: A/B, tests)
-int& opt_conv_seam();          // 1: expand conv + residual of Bottleneck k and the reduce conv of Bottleneck k+1 run as one conv1x1_seam launch (2 = without its minimum-grid rule: tests), 0: two launches
-int& opt_conv_stream();        // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
-int& opt_splitk();             // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch
-int& opt_dense_exact();        // 1: hidden dense layers on the exact-f32 MFMA instead of the split-fp16 form
-int& opt_lazy_order();         // 1: the readers of a lazy site walk their tiles sample-minor (lazy_tile_map): speed only, never results
-int& opt_epilogue_lite();      // 1: BN + residual + ReLU + 2-bit elementwise-site launches finish in epilogue_lite
-int& opt_xcd_split();       // 0 = by weight bytes, else 1 | 2 | 4
+// Kernel-selection switches.  bmi_set_option edits the PROCESS DEFAULTS; bmi_create snapshots them into the engine handle, and every entry point
+// that takes a handle runs under that snapshot (a thread-local pointer set for the duration of the call: BmiOptionScope), so a live engine
+// never changes kernels because another thread — or a test — called bmi_set_option; bmi_engine_set_option edits ONE engine's snapshot.
+// The single-kernel entry points (no handle) read the process defaults.
+struct BmiOptions {
+    int mfma_shape_patch = 0, mfma_shape_wide = 0;   // 16 or 32 (0 until first use: the BMI_MFMA_SHAPE environment default)
+    int unit_dtype = 0;          // BMI_DTYPE_* of the single-kernel entry points
+    int wide_persist_min = 10;   // persistent wide kernel when blocks * 10 > value * n_cu (> one tile per CU; same-process A/B at T = 13, 25, 50: neutral vs 2 tiles per CU)
+    int conv_pw = 1;             // 1: conv3x3_pw takes the shapes it supports, 0: conv3x3_patch everywhere
+    int conv_wide = 1;           // 0: conv_igemm_wide is skipped (A/B against the per-tap kernel)
+    int mask_lazy = 1;           // 1: a lazy site (engine.hip, bmi_create) writes keep bits + one scaled copy and its consumers mask in LDS, 0: always materialised
+    int conv_pool = 1;           // 1: a conv whose 4x4 map feeds one exit head only writes the pooled means (conv3x3_s2), 0: never
+    int conv_s2 = 1;             // 1: plain 3x3 stride-2 convs run in conv3x3_s2 (2 = without its minimum-grid rule: tests), 0: conv_igemm_wide
+    int split_shx = 1;           // 1: conv_split's 3x3 stride-1 launches fetch a tap row's pixel tile once for its three taps (0: once per tap: A/B, tests)
+    int split_tile = 1;          // 1: conv_split narrows its channel tile on small grids (0: always the widest that divides Cout: A/B, tests)
+    int conv_seam = 1;           // 1: expand conv + residual of Bottleneck k and the reduce conv of Bottleneck k+1 run as one conv1x1_seam launch (2 = without its minimum-grid rule: tests), 0: two launches
+    int conv_stream = 1;         // 1: HBM-bound 1x1 convs run in conv1x1_stream (2 = without its minimum-grid rule: tests), 0: never
+    int splitk = 1;              // 1: bmi_plan gives skinny deterministic 3x3 convs (<= 64 tiles, Cin >= 256) a split-K launch
+    int dense_exact = 0;         // 1: hidden dense layers on the exact-f32 MFMA instead of the split-fp16 form
+    int lazy_order = 1;          // 1: the readers of a lazy site walk their tiles sample-minor (lazy_tile_map): speed only, never results
+    int epilogue_lite = 1;       // 1: BN + residual + ReLU + 2-bit elementwise-site launches finish in epilogue_lite
+    int xcd_split = 0;           // 0 = by weight bytes, else 1 | 2 | 4
+    int pw_persist = 1;          // 1: plain-epilogue launches of conv3x3_pw run in its persistent form (conv3x3_pwp_kernel), 0: never
+    int lazy_planar = 1;         // 1: lazy sites whose readers are all stride-2 consumers store their scaled copy + bits in the planar layout
+    int ws_no_reuse = 0;         // bmi_plan: every suffix tensor keeps its own workspace range (per-layer traces)
+    int block_fuse = 1;          // 1: conv1 -> conv2 of a BasicBlock on 16x16 maps run as one conv3x3_block launch (2 = without its minimum-grid rule: tests), 0: two launches
+};
+BmiOptions& bmi_default_options();                 // the process defaults (engine.hip)
+extern thread_local const BmiOptions* bmi_tl_options;   // the snapshot of the engine whose entry point is running on this thread, else null
+inline const BmiOptions& bmi_options() { return bmi_tl_options ? *bmi_tl_options : bmi_default_options(); }
+struct BmiOptionScope {
+    const BmiOptions* prev;
+    explicit BmiOptionScope(const BmiOptions* o) : prev(bmi_tl_options) { bmi_tl_options = o; }
+    ~BmiOptionScope() { bmi_tl_options = prev; }
+    BmiOptionScope(const BmiOptionScope&) = delete;
+    BmiOptionScope& operator=(const BmiOptionScope&) = delete;
+};
+#define BMI_OPT(name) inline int opt_##name() { return bmi_options().name; }
+BMI_OPT(mfma_shape_patch) BMI_OPT(mfma_shape_wide) BMI_OPT(unit_dtype) BMI_OPT(wide_persist_min) BMI_OPT(conv_pw) BMI_OPT(conv_wide)
+BMI_OPT(mask_lazy) BMI_OPT(conv_pool) BMI_OPT(conv_s2) BMI_OPT(split_shx) BMI_OPT(split_tile) BMI_OPT(conv_seam) BMI_OPT(conv_stream)
+BMI_OPT(splitk) BMI_OPT(dense_exact) BMI_OPT(lazy_order) BMI_OPT(epilogue_lite) BMI_OPT(xcd_split) BMI_OPT(pw_persist) BMI_OPT(lazy_planar)
+BMI_OPT(ws_no_reuse) BMI_OPT(block_fuse)
+#undef BMI_OPT
 int xcd_split_for(int n_ctiles, size_t weight_bytes);
 
 SiteArgs resolve_site(const bmi_site* site, uint64_t seed, int mask_cnt0, uint64_t elem_off = 0);

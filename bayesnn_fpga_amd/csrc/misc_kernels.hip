@@ -636,22 +636,34 @@ int launch_fill_int(int* p, int n, int v, hipStream_t s) {
     return BMI_OK;
 }
 
+// CHECK: also counts the elements whose sums are not finite (an fp16 activation that saturated at 65 504 turns into inf, then NaN in the
+// softmax) into *nonfinite — one ballot per wavefront, one atomic per wavefront that saw any.
+template <bool CHECK>
 __global__ void finalize_kernel(long n, double inv_t, const double* S1, const double* S2, const double* SL, double* mean,
-                                double* var, double* lm) {
+                                double* var, double* lm, int* nonfinite) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double m = S1[i] * inv_t;
-    const double v = S2[i] * inv_t - m * m;
-    mean[i] = m;
-    var[i] = v > 0 ? v : 0;
-    lm[i] = SL[i] * inv_t;
+    bool bad = false;
+    if (i < n) {
+        const double s1 = S1[i], s2 = S2[i], sl = SL[i];
+        const double m = s1 * inv_t;
+        const double v = s2 * inv_t - m * m;
+        mean[i] = m;
+        var[i] = v > 0 ? v : (v == v ? 0 : v);     // (a NaN stays a NaN: the clamp must not hide it)
+        lm[i] = sl * inv_t;
+        if (CHECK) bad = !(__builtin_isfinite(s1) && __builtin_isfinite(s2) && __builtin_isfinite(sl));
+    }
+    if (CHECK) {
+        const unsigned long long b = __ballot(bad);
+        if (b && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, __popcll(b));
+    }
 }
 
 int launch_finalize(int64_t n, int t_total, const double* S1, const double* S2, const double* SL, double* mean,
-                    double* var, double* lm, hipStream_t s) {
+                    double* var, double* lm, int* nonfinite, hipStream_t s) {
     if (n <= 0 || t_total <= 0) return BMI_ERR_INVALID;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (long)n, 1.0 / t_total, S1,
-                       S2, SL, mean, var, lm);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (nonfinite) hipLaunchKernelGGL(finalize_kernel<true>, grid, block, 0, s, (long)n, 1.0 / t_total, S1, S2, SL, mean, var, lm, nonfinite);
+    else hipLaunchKernelGGL(finalize_kernel<false>, grid, block, 0, s, (long)n, 1.0 / t_total, S1, S2, SL, mean, var, lm, nonfinite);
     BMI_CHECK_LAUNCH();
     return BMI_OK;
 }

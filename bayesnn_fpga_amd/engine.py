@@ -64,15 +64,34 @@ class GraphBuilder:
         self.keep.append(d)
         return d
 
-    def conv_weight(self, w):
+    def conv_weight(self, w, lift=None):
         """Device copy of a conv weight [Cout][ky][kx][Cin] in the engine's layout.  Split engines (BMI_DTYPE_F16X2 / BF16X3): the 16-bit
-        head and tail planes [2][Cout][ky][kx][Cin], hi = rn16(w), lo = rn16(w - hi) — split once here, csrc/conv_split.hip reads both."""
-        if self.dtype not in ("f16x2", "bf16x3"):
-            return self.dev(w, self.act_dtype)
+        head and tail planes [2][Cout][ky][kx][Cin], hi = rn16(w), lo = rn16(w - hi) — split once here, csrc/conv_split.hip reads both.
+        ``lift`` [Cout] (``channel_lift``): the weights of output channel c are multiplied by the power of two lift[c] BEFORE they are
+        rounded / split — exact — and the caller folds 1 / lift[c] into the channel's epilogue scale."""
         w32 = w.detach().float()
+        if lift is not None:
+            w32 = w32 * lift.reshape((-1,) + (1,) * (w32.dim() - 1))
+        if self.dtype not in ("f16x2", "bf16x3"):
+            return self.dev(w32, self.act_dtype)
         hi = w32.to(self.act_dtype)
         lo = (w32 - hi.float()).to(self.act_dtype)
         return self.dev(torch.stack([hi, lo]), self.act_dtype)
+
+    def channel_lift(self, *weights):
+        """Per-output-channel power of two 2^k that brings max|w| of the channel (over ALL the given weights: a conv and its fused shortcut
+        accumulate into one register) to [2^7, 2^8); None in the exact engine (fp32 weights).  Why: fp16 is denormal below 6.1e-5 and the
+        split engines' fp16 TAIL rn16(w - hi) of any weight below 2^-3 is a subnormal (ulp 2^-24) — BN-folded conv weights of 1e-2 .. 1e-3
+        would keep 15-18 of the 22 bits the split form is for, anything under 6e-8 nothing (round-5 advisor finding); the plain fp16 engine
+        loses bits of every weight under 6.1e-5 the same way.  Lifted, every head and every tail that matters is a normal number; 2^-k goes
+        into the fp32 epilogue scale — exact, and for weights that were normal numbers anyway bit for bit the unlifted result (a power of
+        two commutes with every rounding on the way).  bf16 has fp32's exponent range: harmless there, one code path."""
+        if self.dtype == "f32":
+            return None
+        amax = torch.stack([w.detach().float().abs().reshape(w.shape[0], -1).amax(dim=1) for w in weights]).amax(dim=0)
+        k = 7 - torch.floor(torch.log2(amax.clamp_min(1e-30)))
+        k = torch.where(amax > 0, k, torch.zeros_like(k)).clamp_(-8, 30)
+        return torch.pow(2.0, k)
 
     def site(self, module, channelwise=False):
         """Allocates the next site id (call order) for a stochastic layer, or none."""
@@ -114,11 +133,18 @@ class GraphBuilder:
             x2, conv_s, bn_s = shortcut
             s_scale, s_bias = fold_bn(bn_s, conv_s.bias)
             wk = wk.float() * scale[:, None, None, None]
-            w2dev = self.conv_weight(conv_s.weight.detach().float()[:, :, 0, 0] * s_scale[:, None])   # [Cout][Cin2] (split engines: head / tail planes)
+            w2 = conv_s.weight.detach().float()[:, :, 0, 0] * s_scale[:, None]       # [Cout][Cin2]
+            # (the 16-bit engines' shortcut-carrying kernels take no scale beside in2 — both BN scales are in the weights — so no lift there)
+            lift = self.channel_lift(wk, w2) if self.dtype in ("f16x2", "bf16x3") else None
+            w2dev = self.conv_weight(w2, lift)                                         # (split engines: head / tail planes)
             bias = bias + s_bias
-            scale = None
+            scale = None if lift is None else 1.0 / lift
             in2 = x2
-        wdev = self.dev(wk, torch.float32) if stem else self.conv_weight(wk)
+        else:
+            lift = None if stem else self.channel_lift(wk)
+            if lift is not None:
+                scale = scale / lift
+        wdev = self.dev(wk, torch.float32) if stem else self.conv_weight(wk, lift)
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
                              stride=s, pad=p, relu=int(relu), weight=wdev, in2=in2, weight2=w2dev,
                              scale=self.dev(scale, torch.float32) if scale is not None else None,
@@ -312,6 +338,8 @@ class CompiledGraph:
         self.n_prefix_ops, self.n_suffix_ops = npo.value, nso.value
         # MACs that do not run in the MFMA conv kernels (bench.py's roofline accounting): the direct stem and the heads
         t = self.graph.tensors
+        # whether the Philox seed reaches any kernel: Masksembles-only graphs (SA/utils.py: the masks are part of the state_dict) do not draw
+        self.seed_matters = any((o.get("site") or {}).get("kind") in (_lib.SITE_ELEMENTWISE, _lib.SITE_CHANNEL) for o in self.graph.ops)
         self.stem_macs = sum(t[o["out"]][0] * t[o["out"]][1] * t[o["out"]][2] * 27 for o in self.graph.ops if o["kind"] == _lib.OP_STEM)
         self.head_macs = sum(t[o["in_"]][2] * self.out_dim for o in self.graph.ops if o["kind"] == _lib.OP_HEAD)
         self.dense_macs = sum(t[o["in_"]][2] * t[o["out"]][2] for o in self.graph.ops if o["kind"] == _lib.OP_DENSE)
@@ -430,14 +458,42 @@ class MCDEngine(CompiledGraph):
         return rc == _lib.BMI_OK
 
     def finalize(self, S, t_total):
-        """mean / var (ddof=0) / mean logit, float64 [E, B, C] each."""
+        """mean / var (ddof=0) / mean logit, float64 [E, B, C] each.  Also counts the non-finite sums into the engine's device counter
+        (bmi_finalize_checked; no synchronisation here): ``check_finite()`` reads it when the results are read."""
         out = torch.empty_like(S)
         n = S[0].numel()
+        if self._nonfinite is None:
+            self._nonfinite = torch.zeros(1, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = self.lib.bmi_finalize(n, int(t_total), S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
-                                       out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._stream())
-        _lib.check(rc, "bmi_finalize")
+            rc = self.lib.bmi_finalize_checked(n, int(t_total), S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
+                                               out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._nonfinite.data_ptr(), self._stream())
+        _lib.check(rc, "bmi_finalize_checked")
         return dict(mean=out[0], var=out[1], logit_mean=out[2])
+
+    _nonfinite = None
+
+    def nonfinite_count(self, reset=True):
+        """Elements of the moment buffers finalized since the last reset whose sums were inf / NaN (a host read: synchronises)."""
+        if self._nonfinite is None:
+            return 0
+        n = int(self._nonfinite.item())
+        if reset and n:
+            self._nonfinite.zero_()
+        return n
+
+    def check_finite(self):
+        """Raises FloatingPointError if a finalize since the last check saw non-finite sums — on the 16-bit engines an activation past
+        65 504 (fp16) turns into inf and then NaN in the softmax; the reference's fp32 path would have carried the value.  Callers that pull
+        results to the host (FullAnalysis, evaluate, bench) call this right there."""
+        n = self.nonfinite_count()
+        if n:
+            raise FloatingPointError(f"{n} non-finite moment sums on the {self.dtype!r} engine (overflow of a 16-bit activation?): "
+                                     "use engine_dtype='f16x2' / 'bf16x3' (or 'auto', which checks this on the first batch)")
+
+    def set_option(self, name, value):
+        """A kernel-selection switch of THIS engine (bmi_engine_set_option): the engine was created with a copy of the process defaults
+        (``_lib.set_option``) and keeps it whatever those become."""
+        _lib.check(self.lib.bmi_engine_set_option(self.handle, name.encode(), int(value)), f"bmi_engine_set_option({name})")
 
     def predict(self, x, T, seed=0, t_begin=0, cnt0=0):
         S = self.new_moments(x.shape[0])
@@ -567,6 +623,7 @@ class BatchesInFlight:
         self.device = self.engines[0].device
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else [None]
         self.last_stream = None
+        self.last_engine = None
         self.k = 0
 
     def slot(self):
@@ -574,19 +631,48 @@ class BatchesInFlight:
 
     use_graph = False      # step(): one hipGraph replay per batch step (tuned() sets it for launch-bound models)
 
+    def close(self):
+        """Destroys the engines and drops their workspaces, captured graphs and static buffers (a pipe that is being replaced by a larger
+        one, or whose model's weights changed)."""
+        self.synchronize()
+        for attr in ("_graphs", "_gstreams"):
+            if hasattr(self, attr):
+                delattr(self, attr)
+        for e in self.engines:
+            e.close()
+            e.workspace = None
+            e.__dict__.pop("_step_S", None)
+            e.__dict__.pop("_share_parts", None)
+        self.engines = []
+
     @classmethod
-    def tuned(cls, model, device, x, T, seed=0, cnt0=0, threshold_ms=1.0, **engine_kwargs):
+    def tuned(cls, model, device, x, T, seed=0, cnt0=0, threshold_ms=1.0, allow_graph=True, group=None, **engine_kwargs):
         """The pipe a model should run with, decided by MEASUREMENT on its first batch: one engine is built, a batch step (x, T) is
         warmed up and timed with HIP events; a step under ``threshold_ms`` is launch-bound (VGG-11 at batch 250 x T = 30: ~20 launches of
         20-50 us on a ~20 us launch floor, 0.26 ms per step) and gets THREE batches in flight, each step ONE hipGraph replay
         (``predict_graphed``: 28 -> 38 M MCD-samples/s on VGG-11, round-3 measurement); anything longer (the ResNets at T = 100:
         21 ms) gets two eager engines, where a replay buys nothing and a third workspace costs memory.  ``pipe.step(x, T, seed)`` runs a
-        batch either way; results are bit for bit the same in both modes (tests/test_gpu_model.py)."""
+        batch either way; results are bit for bit the same in both modes (tests/test_gpu_model.py).  ``allow_graph=False``: a caller whose launch
+        scalars change from batch to batch (FullAnalysis with MC-dropout sites: the batch index is part of the seed) takes the three batches in
+        flight without the replay.  ``group``: the ranks of a process group time their SHARE of the step and decide together (MAX over ranks)."""
         pipe = cls(model, device, n=1, **engine_kwargs)
-        pipe.step_ms_measured = pipe.measure_ms(lambda e: e.predict(x, T, seed, cnt0=cnt0))
-        launch_bound = pipe.step_ms_measured < threshold_ms
+        from .sharding import _rank_world, accumulate_share
+        rank, world = _rank_world(group) if group is not None else (0, 1)
+        if world > 1:
+            # a rank's SHARE of the step is what it will run; the group takes the slowest rank's figure so that every rank builds the same pipe
+            import torch.distributed as dist
+            S = pipe.engines[0].new_moments(x.shape[0])
+            ms = pipe.measure_ms(lambda e: accumulate_share(e, x, S.zero_(), T, seed, cnt0, rank, world))
+            on_dev = dist.get_backend(group) == "nccl"
+            t = torch.tensor([ms], dtype=torch.float64, device=pipe.device if on_dev else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            ms = float(t.item())
+        else:
+            ms = pipe.measure_ms(lambda e: e.predict(x, T, seed, cnt0=cnt0))
+        pipe.step_ms_measured = ms
+        launch_bound = ms < threshold_ms
         pipe.grow(3 if launch_bound else 2)
-        pipe.use_graph = launch_bound
+        pipe.use_graph = bool(launch_bound and allow_graph)
         return pipe
 
     def measure_ms(self, fn, warm=2, reps=3):
@@ -645,6 +731,7 @@ class BatchesInFlight:
         self.k += 1
         st = self.streams[i]
         self.last_stream = st
+        self.last_engine = self.engines[i]
         if st is None:
             return fn(self.engines[i])
         st.wait_stream(torch.cuda.current_stream(self.device))
@@ -691,6 +778,7 @@ class BatchesInFlight:
         self.k += 1
         st = self._gstreams[i]
         self.last_stream = st
+        self.last_engine = eng
         cur = torch.cuda.current_stream(self.device)
 
         reduce = world > 1 or bool(always_reduce)        # (always_reduce: the collective in a group of ONE rank too — the 1-GPU RCCL probe)

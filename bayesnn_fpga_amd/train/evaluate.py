@@ -97,7 +97,24 @@ def validate_model_acc(loss_f, net, val_iter, gpu):
     return [sum(col) / len(col) for col in zip(*rows)]
 
 
-def _evaluate_folded(loss_fn, test_iter, model, dev, T):
+def _eval_pipe(model, dev, dtype, batch):
+    """The folded evaluation's two engines in flight for (device, dtype), ONE per key: a batch larger than the pipe was built for replaces it —
+    the old engines are closed, their workspaces dropped (like ``EngineModelMixin.engine()`` grows) — so successive evaluations with growing
+    batch sizes, or a loader whose first batch is small, never accumulate workspaces.  ``model.invalidate_engine()`` / ``.to()`` /
+    ``load_state_dict`` clear the cache: after in-place weight updates call ``invalidate_engine()`` before the next evaluate()."""
+    from ..engine import BatchesInFlight
+    pipes = model.__dict__.setdefault("_eval_pipes", {})
+    key = (str(dev), dtype)
+    pipe = pipes.get(key)
+    if pipe is not None and pipe.engines and pipe.engines[0].max_batch >= batch:
+        return pipe
+    if pipe is not None:
+        pipe.close()
+    pipe = pipes[key] = BatchesInFlight(model, dev, n=2, max_batch=batch, dtype=dtype)
+    return pipe
+
+
+def _evaluate_folded(loss_fn, test_iter, model, dev, T, group=None, shard=None):
     """The T outer passes of evaluate() FOLDED per batch: one walk over the loader, every batch's T stochastic forwards as ONE pass of
     the engine (``MCDEngine.forward_samples``: prefix once, samples folded into the launches) and the metric vectors of its T passes in
     one batched device op (``_metrics_passes``); averaged over the batches per pass, then over the passes, as the reference does
@@ -105,63 +122,93 @@ def _evaluate_folded(loss_fn, test_iter, model, dev, T):
     is forward call i n + k, so its Masksembles mask is (cnt + k + i n) mod M (``mask_stride`` = n) and the layers' counters — and the
     mirror's MC pass index — end T n calls further.  MC-dropout masks are i.i.d. draws addressed by the sample index: pass i of batch k
     takes index mc_pass + k T + i here (the unfolded walk numbers them in call order, mc_pass + i n + k: another labelling of the same
-    draws — the averaged metrics agree in distribution, not sample for sample)."""
+    draws — the averaged metrics agree in distribution, not sample for sample).
+
+    MULTI-GPU: under an initialised ``torch.distributed`` with more than one rank (``shard=None``: automatic) every rank walks
+    the same loader and runs passes [lo, hi) of every batch (``sharding.shard_range`` over T: the T samples shard across the GPUs); the
+    per-pass metric rows are disjoint, ONE all-reduce (sum) of the [n_batches, T, n_metrics] float64 table at the end of the walk joins them,
+    and every rank returns the same vector."""
+    from ..sharding import _rank_world, shard_range
     nb = len(test_iter)
     cnt = model.mask_layers()[0].cnt if model.mask_layers() else 0
+    rank, world = (0, 1) if shard is False else _rank_world(group)
+    t_lo, t_hi = shard_range(T, rank, world)
+    Tl = t_hi - t_lo                                    # this rank's passes (0: more ranks than passes — it only takes part in the all-reduce)
     # Two batches in flight (engine.BatchesInFlight: own engine, workspace and stream each): the host-to-device copy of one batch runs
     # beside the engine pass of the other.  The engine passes write their logits into ONE group buffer [G, T, E, B, C] (<= 256 MB), and
     # the metric arithmetic runs once per group: per batch, its dozen tiny launches queued between the other stream's convolutions cost
     # 0.7 ms of a 3.2 ms batch (tools/experiments/evaluate_fold_profile.py).
-    from ..engine import BatchesInFlight
-    rows, pipe, group = [], None, None            # group = [logits buffer, labels, batches filled, capacity, batch size]
+    rows, pipe, group_buf, dtype = [], None, None, None            # group_buf = [logits buffer, labels, batches filled, capacity, batch size]
 
     def flush():
-        nonlocal group
-        if group is not None and group[2]:
+        nonlocal group_buf
+        if group_buf is not None and group_buf[2]:
             pipe.synchronize()
-            rows.append(loss_fn._metrics_passes(group[0][:group[2]], torch.stack(group[1])))
-        group = None
+            lg = group_buf[0][:group_buf[2]]
+            if not bool(torch.isfinite(lg).all()):     # (a 16-bit overflow: inf / NaN logits would turn into plausible-looking accuracies)
+                raise FloatingPointError(f"non-finite logits on the {dtype!r} engine: use engine_dtype='f16x2' / 'bf16x3' (or 'auto')")
+            rows.append(loss_fn._metrics_passes(lg, torch.stack(group_buf[1])))
+        group_buf = None
 
     for k, (X, y) in enumerate(test_iter):
         Bk = int(X.shape[0])
+        Xd, yd = X.to(dev, non_blocking=True), y.to(dev, non_blocking=True)      # (on the caller's stream: the slot's stream waits for it)
+        if Tl == 0:
+            continue
+        if dtype is None:
+            dtype = model.resolve_engine_dtype(dev, None, calib=Xd)              # engine_dtype = "auto": decided on the first batch
         if pipe is None or pipe.engines[0].max_batch < Bk:
             flush()
-            key = (str(dev), getattr(model, "engine_dtype", "f16"), Bk)
-            pipes = model.__dict__.setdefault("_eval_pipes", {})
-            pipe = pipes.get(key) or pipes.setdefault(key, BatchesInFlight(model, dev, n=2, max_batch=Bk, dtype=key[1]))
-        if group is not None and (group[4] != Bk or group[2] == group[3]):
+            pipe = _eval_pipe(model, dev, dtype, Bk)
+        if group_buf is not None and (group_buf[4] != Bk or group_buf[2] == group_buf[3]):
             flush()
-        if group is None:
+        if group_buf is None:
             e0 = pipe.engines[0]
-            cap = max(1, min(nb - k, (1 << 28) // (T * e0.n_exits * Bk * e0.out_dim * 4)))
-            group = [torch.empty(cap, T, e0.n_exits, Bk, e0.out_dim, dtype=torch.float32, device=dev), [], 0, cap, Bk]
-        Xd, yd = X.to(dev, non_blocking=True), y.to(dev, non_blocking=True)      # (on the caller's stream: the slot's stream waits for it)
-        slot = group[0][group[2]]
-        group[1].append(yd)
-        group[2] += 1
-        pipe.submit(lambda eng, Xd=Xd, k=k, slot=slot: eng.forward_samples(Xd, T, seed=model.mc_seed, t_begin=model.mc_pass + k * T, cnt0=cnt + k,
-                                                                          mask_stride=nb, out=slot), inputs=(Xd,))
+            cap = max(1, min(nb - k, (1 << 28) // (Tl * e0.n_exits * Bk * e0.out_dim * 4)))
+            group_buf = [torch.empty(cap, Tl, e0.n_exits, Bk, e0.out_dim, dtype=torch.float32, device=dev), [], 0, cap, Bk]
+        slot = group_buf[0][group_buf[2]]
+        group_buf[1].append(yd)
+        group_buf[2] += 1
+        pipe.submit(lambda eng, Xd=Xd, k=k, slot=slot: eng.forward_samples(Xd, Tl, seed=model.mc_seed, t_begin=model.mc_pass + k * T + t_lo,
+                                                                          cnt0=cnt + k + t_lo * nb, mask_stride=nb, out=slot), inputs=(Xd,))
     flush()
     model.advance(T * nb)
-    per_batch = torch.cat(rows).cpu().numpy()               # [n_batches, T, n_metrics]: one host synchronisation per group of batches
+    n_metrics = len(loss_fn.metric_names)
+    per_batch = torch.zeros(nb, T, n_metrics, dtype=torch.float64, device=dev)
+    if rows:
+        per_batch[:, t_lo:t_hi] = torch.cat(rows)
+    if world > 1:
+        import torch.distributed as dist
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(per_batch, op=dist.ReduceOp.SUM, group=group)
+        else:                                           # (gloo: the CPU tests and the two-ranks-on-one-GPU dry run)
+            host = per_batch.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            per_batch = host
+    per_batch = per_batch.cpu().numpy()                 # [n_batches, T, n_metrics]: one host synchronisation per group of batches
     # per pass: sum over the batches in loader order / n (train_utils.py:38), in Python floats like the reference
     return np.array([[sum(float(per_batch[k, i, j]) for k in range(nb)) / nb for j in range(per_batch.shape[2])] for i in range(T)])
 
 
-def evaluate(loss_fn, test_iter, model, gpu, experiment_id, mc_dropout_passes, create_log=True, fold=True):
+def evaluate(loss_fn, test_iter, model, gpu, experiment_id, mc_dropout_passes, create_log=True, fold=True, shard=None, group=None):
     """SA/train/evaluate.py:8-22.  ``fold`` (default): the T outer passes are folded per batch (``_evaluate_folded``) when the model is one
     of the package's mirrors, the loss a MultiExitAccuracy and the loader has a length; ``fold=False`` keeps the reference's loop order
-    (T walks over the loader, one ``model(X)`` per batch: 25 launches per call, host-bound — 11x slower, tools/loop_bench.py)."""
+    (T walks over the loader, one ``model(X)`` per batch: 25 launches per call, host-bound — 11x slower, tools/loop_bench.py).
+    ``shard`` / ``group``: the folded route partitions the T passes over the ranks of an initialised ``torch.distributed`` (see
+    ``_evaluate_folded``); every rank returns the same vector, rank 0 writes the log."""
     model.eval()
     dev = get_device(gpu)
     foldable = (fold and hasattr(model, "forward_samples_ok") and hasattr(loss_fn, "_metrics_passes") and hasattr(test_iter, "__len__")
                 and len(test_iter) > 0 and dev.type == "cuda")
+    rank = 0
     if foldable:
-        per_pass = _evaluate_folded(loss_fn, test_iter, model, dev, mc_dropout_passes)
+        from ..sharding import _rank_world
+        rank = 0 if shard is False else _rank_world(group)[0]
+        per_pass = _evaluate_folded(loss_fn, test_iter, model, dev, mc_dropout_passes, group=group, shard=shard)
     else:
         per_pass = np.array([validate_model_acc(loss_fn, model, test_iter, gpu) for _ in range(mc_dropout_passes)])
     averaged = list(np.average(per_pass, axis=0))
-    if create_log:
+    if create_log and rank == 0:
         with open(f"log_{experiment_id}.txt", "w") as f:
             f.write(str([(n, f"{v:>8.4f}") for n, v in zip(loss_fn.metric_names, averaged)]))
     return averaged

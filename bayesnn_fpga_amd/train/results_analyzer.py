@@ -33,6 +33,11 @@ def get_device(gpu):
     return torch.device(f"cuda:{gpu}" if gpu >= 0 else "cpu")
 
 
+def _default_group():
+    import torch.distributed as dist
+    return dist.group.WORLD
+
+
 def exit_ensembles(per_exit):
     """Entry i = mean over exits 0..i (results_analyzer.py:260-269, :163-165)."""
     c = np.cumsum(per_exit, axis=0)
@@ -40,7 +45,24 @@ def exit_ensembles(per_exit):
 
 
 class FullAnalysis:
-    def __init__(self, model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="", seed=0, ece="kde"):
+    """``FullAnalysis(model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="")`` as in the reference (:55-64); the keyword-only
+    extras are the build's:
+
+    * ``seed`` — Philox key of the walk (batch k draws under ``seed + k``), ``ece`` — "kde" | "hist".
+    * ``shard`` / ``group`` — MULTI-GPU (the reference is single-device): under an initialised ``torch.distributed`` with more than
+      one rank (``shard=None``: automatic; ``group``: another process group) EVERY rank constructs the same FullAnalysis over the same loader,
+      each batch's T samples (or, for T <= ranks, its images) are partitioned over the ranks (``sharding.accumulate_partitioned``: one float64
+      all-reduce of the [3, E, B, C] moment buffer per engine step) and every rank ends with the full predictions; only rank 0 writes the log
+      and ``.npy`` files.  ``shard=False`` keeps a rank to itself (a data-parallel caller with its own loader per rank).
+    * ``macro_batches`` — K loader batches of one size are carried by ONE engine step of K x B images (per-batch outputs come back in loader
+      order): the launch-bound cases — exit-only dropout, whose whole trunk is a once-per-batch prefix of 250 images
+      (Software_Artifact/script_figs/journal_script.sh:10-63), and config 4's 31-image share of eight ranks — get K times the work per launch.
+      MC-dropout masks of a macro step are drawn at an image's index in the macro-batch (other i.i.d. draws than the K = 1 walk's); Masksembles
+      layers count forward calls per loader batch (SA/utils.py:165-169), which one step can only honour when T % M == 0 — otherwise K falls back to 1.
+    """
+
+    def __init__(self, model, test_loader, gpu=0, mc_dropout=False, mc_passes=10, suffix="", *, seed=0, ece="kde", macro_batches=1,
+                 shard=None, group=None):
         self.ece_kind = ece          # "kde": what the reference's ece_eval_binary returns (:503; FFTKDE restated, parity
                                      # unpinned) | "hist": ece_hist_binary (pinned to the reference, unused by it)
         self.model = model
@@ -50,66 +72,126 @@ class FullAnalysis:
         self.mc_passes = mc_passes if mc_dropout else 1
         self.filename_suffix = suffix
         self.seed = seed
+        self.macro_batches = max(1, int(macro_batches))
+        self.shard, self.group = shard, group
         self.device = get_device(gpu)
         self._batch_index = 0
         if test_loader is not None:
             self.sdn_get_detailed_results()
 
+    # -- multi-GPU ---------------------------------------------------------------------------
+    def _ranks(self):
+        """(rank, world) of the walk: (0, 1) unless sharding is on."""
+        if getattr(self, "shard", None) is False:
+            return 0, 1
+        from ..sharding import _rank_world
+        rank, world = _rank_world(getattr(self, "group", None))
+        if getattr(self, "shard", None) is None and world == 1:
+            return 0, 1
+        return rank, world
+
+    def is_writer(self):
+        """Rank 0 of a sharded walk (or the only rank) writes the log / .npy files."""
+        return self._ranks()[0] == 0
+
     # -- device side -------------------------------------------------------------------------
-    def _batch_call(self):
-        """(T, seed, cnt0) of the next batch, then the bookkeeping the reference's T forwards would have done.
+    def _batch_call(self, n_batches=1):
+        """(T, seed, cnt0) of the next engine step, then the bookkeeping the reference's T forwards per loader batch would have done.
         Masksembles layers keep ONE counter per layer that carries over from batch to batch and from evaluate() into
         this run (SA/utils.py:165-169, :228-230): pass i of this batch uses mask (cnt + i) mod M with the layers'
         CURRENT cnt.  (The Philox sample index restarts at 0 for every batch; the batch index is part of the seed.)"""
         ml = self.model.mask_layers()
         call = (self.mc_passes, self.seed + self._batch_index, ml[0].cnt if ml else 0)
-        self.model.advance(self.mc_passes)
+        self.model.advance(self.mc_passes * n_batches)
         return call
+
+    def _engine_for(self, b_x):
+        """The engine a synchronous ``_predict`` runs on (tests substitute a CPU stand-in with MCDEngine's accumulate / new_moments /
+        finalize / image_offset_ok / check_finite to exercise the sharded collation under gloo)."""
+        return self.model.engine(b_x.device, max_batch=b_x.shape[0], calib=b_x)
 
     def _predict(self, b_x):
         """T folded passes on the GPU -> dict of float64 numpy arrays [E,B,C]."""
-        eng = self.model.engine(b_x.device, max_batch=b_x.shape[0])
+        eng = self._engine_for(b_x)
         T, seed, cnt0 = self._batch_call()
-        r = eng.predict(b_x, T, seed=seed, t_begin=0, cnt0=cnt0)
-        return {k: v.cpu().numpy() for k, v in r.items()}
+        rank, world = self._ranks()
+        if world > 1:
+            from ..sharding import predict_sharded
+            r = predict_sharded(eng, b_x, T, seed, cnt0, group=getattr(self, "group", None))
+        else:
+            S = eng.new_moments(b_x.shape[0])
+            eng.accumulate(b_x, S, 0, T, seed, cnt0)
+            r = eng.finalize(S, T)
+        out = {k: v.cpu().numpy() for k, v in r.items()}
+        eng.check_finite()
+        return out
 
-    def _make_pipe(self, device, max_batch):
-        """Two engines / streams for the batch loop, with the model's engine settings (``model.engine_dtype``, an explicit
-        chunk size of its cached engine) like ``model.engine()`` would build them."""
+    def _make_pipe(self, b_x, max_batch):
+        """The engines / streams of the batch loop, with the model's engine settings (``model.engine_dtype`` — "auto" is decided here, on the
+        first batch —, an explicit chunk size of its cached engine) like ``model.engine()`` would build them.  How many batches are in flight,
+        and whether a step is one hipGraph replay, is decided by MEASUREMENT of the first step (``BatchesInFlight.tuned``: under 1 ms = launch
+        bound -> three in flight; a replay only when the launch scalars repeat from batch to batch — Masksembles-only models, whose kernels
+        never see the seed and whose counter takes at most M values)."""
         from ..engine import BatchesInFlight
+        device = b_x.device
         old = getattr(self, "_pipe", None)
         if old is not None:
-            old.synchronize()        # a batch may still be queued on the engines that are about to be destroyed
-        dtype = getattr(self.model, "engine_dtype", None) or "f16"
+            old.close()              # (synchronises first: a batch may still be queued on the engines that are about to be destroyed)
+        dtype = self.model.resolve_engine_dtype(device, None, calib=b_x)
         cached = getattr(self.model, "_engines", {}).get(f"{device}/{dtype}")
         chunk = cached.chunk_samples if cached is not None and cached.chunk_explicit else None
-        self._pipe = BatchesInFlight(self.model, device, n=2, max_batch=max_batch, dtype=dtype, chunk_samples=chunk)
+        rank, world = self._ranks()
+        xs = b_x if b_x.shape[0] == max_batch else b_x.new_zeros((max_batch,) + tuple(b_x.shape[1:]))
+        ml = self.model.mask_layers()
+        self._pipe = BatchesInFlight.tuned(self.model, device, xs, self.mc_passes, seed=self.seed, cnt0=ml[0].cnt if ml else 0,
+                                           allow_graph=True, group=(getattr(self, "group", None) or _default_group()) if world > 1 else None,
+                                           max_batch=max_batch, dtype=dtype, chunk_samples=chunk)
+        self._pipe.use_graph = self._pipe.use_graph and not self._pipe.engines[0].seed_matters
         return self._pipe
 
-    def _predict_async(self, b_x):
-        """The same call queued on one of two engines / streams (engine.BatchesInFlight): returns the DEVICE tensors; the caller
+    def _predict_async(self, b_x, n_batches=1):
+        """The same call queued on one of the engines / streams of the pipe (engine.BatchesInFlight): returns the DEVICE tensors; the caller
         converts them after it has queued the next batch, so that batch's launch-bound prefix and this batch's host-side
         collation both overlap the GPU work.  Results are bit for bit those of _predict."""
         pipe = getattr(self, "_pipe", None)
         if pipe is None or pipe.device != b_x.device or pipe.engines[0].max_batch < b_x.shape[0]:
             # sized once from the loader's batch size where it says so (a smaller last batch reuses the engines)
-            want = max(b_x.shape[0], int(getattr(getattr(self, "_cur_loader", None), "batch_size", 0) or 0))
-            pipe = self._make_pipe(b_x.device, want)
-        T, seed, cnt0 = self._batch_call()
-        r = pipe.submit(lambda eng: eng.predict(b_x, T, seed=seed, t_begin=0, cnt0=cnt0), inputs=(b_x,))
-        return r, pipe.last_stream
+            want = max(b_x.shape[0], self._macro_k() * int(getattr(getattr(self, "_cur_loader", None), "batch_size", 0) or 0))
+            pipe = self._make_pipe(b_x, want)
+        T, seed, cnt0 = self._batch_call(n_batches)
+        rank, world = self._ranks()
+        if not pipe.engines[0].seed_matters:
+            seed = self.seed           # (no kernel reads it: constant, so that a Masksembles step's hipGraph is found again)
+        r = pipe.step(b_x, T, seed=seed, cnt0=cnt0, group=getattr(self, "group", None), shard=world > 1)
+        return r, pipe.last_stream, pipe.last_engine
 
-    def _predict_deferred(self, b_x):
+    def _macro_k(self):
+        """Loader batches per engine step: ``macro_batches``, or 1 when the model's Masksembles counters could not be honoured (T % M != 0)."""
+        K = getattr(self, "macro_batches", 1)
+        ml = self.model.mask_layers() if hasattr(self.model, "mask_layers") else []
+        if K > 1 and ml and self.mc_passes % ml[0].n != 0:
+            return 1
+        return K
+
+    def _predict_deferred(self, b_x, n_batches=1):
         """Queues the batch and returns a zero-argument function that waits for it and gives _predict's numpy dict."""
-        if type(self)._predict is not FullAnalysis._predict:      # a subclass with its own per-batch predictor (tests inject the oracle)
-            r = self._predict(b_x)
+        if type(self)._predict is not FullAnalysis._predict or type(self)._engine_for is not FullAnalysis._engine_for:
+            # a subclass with its own per-batch predictor / engine (tests inject the oracle): the synchronous route
+            # (loader batch by loader batch, each under its own batch index: exactly the macro_batches = 1 walk)
+            parts, base = [], self._batch_index
+            for j, piece in enumerate(b_x.chunk(n_batches)):
+                self._batch_index = base + j
+                parts.append(self._predict(piece))
+            r = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
             return lambda: r
-        r_dev, st = self._predict_async(b_x)
+        r_dev, st, eng = self._predict_async(b_x, n_batches)
 
         def get():
             if st is not None:
                 st.synchronize()                       # this batch is done (the next one is already queued behind it)
-            return {k: v.cpu().numpy() for k, v in r_dev.items()}
+            out = {k: v.cpu().numpy() for k, v in r_dev.items()}
+            eng.check_finite()                         # non-finite moment sums (a 16-bit overflow) never reach the collation silently
+            return out
         return get
 
     def _outputs_from(self, r):
@@ -153,17 +235,33 @@ class FullAnalysis:
         trackers = [[(set(), set(), {}, {}) for _ in range(n_exits)] for _ in range(2)]
         off = 0
         if getattr(self, "_pipe", None) is not None:
-            self._pipe.synchronize()
-        self._pipe = None            # engines snapshot the weights when they are built: a fresh pair per collection run
+            self._pipe.close()
+        self._pipe = None            # engines snapshot the weights when they are built: a fresh set per collection run
         self._cur_loader = loader
 
+        K = self._macro_k()
+
+        def steps(it):
+            """(index of the first loader batch, images, labels, loader batches carried) of each ENGINE step: K consecutive loader batches of
+            one size concatenated (``macro_batches``), a smaller last batch — or a change of size — on its own."""
+            hold, first = [], 0
+            for idx, batch in enumerate(it):
+                if hold and (len(hold) == K or batch[0].shape[0] != hold[0][0].shape[0]):
+                    yield first, torch.cat([h[0] for h in hold]) if len(hold) > 1 else hold[0][0], torch.cat([h[1] for h in hold]), len(hold)
+                    hold = []
+                if not hold:
+                    first = idx
+                hold.append(batch)
+            if hold:
+                yield first, torch.cat([h[0] for h in hold]) if len(hold) > 1 else hold[0][0], torch.cat([h[1] for h in hold]), len(hold)
+
         def queued(it):
-            """(result getter, labels) of each batch, one batch behind the one being queued (two batches in flight)."""
+            """(result getter, labels) of each engine step, one step behind the one being queued (two or three steps in flight)."""
             pending = None
-            for self._batch_index, batch in enumerate(it):
-                b_x = batch[0].to(self.device, non_blocking=True)     # asynchronous from a pinned loader batch; ordered before the
+            for self._batch_index, xs, ys, nb in steps(it):
+                b_x = xs.to(self.device, non_blocking=True)           # asynchronous from a pinned loader batch; ordered before the
                                                                       # batch's launches by submit()'s wait on this stream
-                nxt = (self._predict_deferred(b_x), batch[1].cpu().numpy().astype(np.int64))
+                nxt = (self._predict_deferred(b_x, nb), ys.cpu().numpy().astype(np.int64))
                 if pending is not None:
                     yield pending
                 pending = nxt
@@ -231,6 +329,8 @@ class FullAnalysis:
         """Layer,Accuracy,Cumulative Correct,Destructive Overthinking,Unique Correct,ECE,NLL,MSE (:515-526) and the
         three consecutive np.save arrays preds / ensemble_preds / labels (:538-541)."""
         name = f"test_evaluation_log_{type(self.model).__name__}{experiment_id}{self.filename_suffix}.txt"
+        if not self.is_writer():          # a sharded walk: every rank holds the same arrays, rank 0 writes them
+            return name
         with open(name, "w") as f:
             for r in self.rows:
                 f.write(",".join(str(v) for v in r) + "\n")
@@ -242,6 +342,8 @@ class FullAnalysis:
 
     def save_validation(self, experiment_id, loader):
         preds, ensemble_preds, labels = self.get_validation_predictions(loader)
+        if not self.is_writer():
+            return
         with open(f"validation_predictions_{experiment_id}.npy", "wb") as f:
             np.save(f, preds)
             np.save(f, ensemble_preds)

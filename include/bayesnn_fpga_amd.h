@@ -32,7 +32,12 @@
  * errno-style code (no exceptions cross the ABI); all device buffers are owned by the
  * caller; every launch is asynchronous on the caller's hipStream_t (passed as void*);
  * no allocation or synchronisation happens inside a launch function, so a caller may
- * capture bmi_forward_mcd into a hipGraph.  One host thread per GPU.
+ * capture bmi_forward_mcd into a hipGraph.
+ *
+ * Threading: one host thread per engine handle at a time (a handle carries the state of the call in flight); different handles —
+ * one per GPU, or the two / three "batches in flight" of one GPU — may be driven from different threads concurrently.  The
+ * kernel-selection switches of bmi_set_option are process DEFAULTS that bmi_create copies into the handle: a live engine is not
+ * affected by later bmi_set_option calls from any thread (bmi_engine_set_option edits one engine's copy).
  *
  * Data layout in HBM: activations are NHWC fp16 ([image][y][x][channel]); conv weights
  * fp16 [Cout][ky][kx][Cin]; folded-BN scale/bias fp32 [Cout]; classifier weights fp32
@@ -50,7 +55,7 @@
 extern "C" {
 #endif
 
-#define BMI_VERSION 510
+#define BMI_VERSION 600
 
 #define BMI_OK 0
 #define BMI_ERR_INVALID (-22)      /* EINVAL: bad descriptor / argument            */
@@ -100,7 +105,8 @@ typedef struct bmi_op_desc {
     int32_t in2;       /* CONV 3x3 stride-1: input of a fused 1x1 strided shortcut conv (the BasicBlock
                           downsample path, resnet18.py:42-45) whose result is added before the ReLU, or -1.
                           With in2 both BN scales must be folded into the fp16 weights (scale = NULL)
-                          and `bias` is the sum of the two BN biases.                               */
+                          and `bias` is the sum of the two BN biases.  Split engines only: `scale` may carry
+                          one per-channel factor common to both weight sets (the host's power-of-two lift). */
     int32_t ksize, stride, pad;
     int32_t relu;      /* apply ReLU after scale/bias(+residual)                       */
     const void* weight;  /* device; CONV fp16 [Cout][k][k][Cin]; STEM fp32 [Cout][k][k][Cin];
@@ -134,11 +140,18 @@ typedef struct bmi_op_desc {
                              tails, split ONCE by the host; the activations live in the workspace in the same form ("pair32": per pixel,
                              32-channel blocks [hi x 32 | lo x 32], 4 bytes per element: csrc/conv_epilogue.h), encoded once by the
                              kernel that produces a tensor — and
-                             w.x = w_lo.x_hi + w_hi.x_lo + w_hi.x_hi on v_mfma_f32_32x32x16_f16 (fp32 accumulate; 22 significant bits
-                             per operand, lo.lo dropped): three MFMAs per K-step instead of the exact engine's sixteen.  The reference's
-                             fp32 arithmetic to ~1e-6 where plain fp16 is at 1e-4..2e-3 (peaky logits of trained / converted nets,
-                             Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45 on SA/models/vgg19/vgg19.py:256-324).  |values| < 65504.
-                             Graph restrictions of BMI_DTYPE_F32 apply (no in2, no dynamic exit).                                      */
+                             w.x = w_lo.x_hi + w_hi.x_lo + w_hi.x_hi on v_mfma_f32_32x32x16_f16 (fp32 accumulate; lo.lo dropped): three MFMAs
+                             per K-step instead of the exact engine's sixteen.  Precision of an operand: 22 significant bits while its tail is a
+                             NORMAL fp16 number, i.e. |v| >= 2^-3; below that the tail is an fp16 subnormal (ulp 2^-24) and the operand carries
+                             an ABSOLUTE error floor of ~2^-25 = 3e-8 (|v| = 1e-3: ~15 bits; |v| < 6e-8 is lost).  For WEIGHTS the host removes
+                             the floor: bayesnn_fpga_amd/engine.py splits each output channel's weights after an exact power-of-two scale that
+                             brings max|w| of the channel to [2^7, 2^8) and folds 2^-k into the channel's BN scale (exact); activations are
+                             O(1) behind BatchNorm and keep the floor.  The reference's fp32 arithmetic to ~1e-6 where plain fp16 is at
+                             1e-4..2e-3 (peaky logits of trained / converted nets, Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45 on
+                             SA/models/vgg19/vgg19.py:256-324).  |values| < 65504.
+                             Graph support: what the 16-bit engines take EXCEPT bmi_forward_mcd_exit (BMI_ERR_UNSUPPORTED) — in2 (the fused 1x1 shortcut) of any conv geometry with Cin2 % 32 == 0 (extra
+                             K-steps of the same kernel), pair launches and split-K are taken; channel counts Cin % 32 == 0, Cout % 64 == 0;
+                             no lazy first site, no pooled epilogue (the tensors are materialised).                                     */
 #define BMI_DTYPE_BF16X3 4 /* the same on v_mfma_f32_32x32x16_bf16: bf16 head + tail (16 significant bits, fp32's exponent range), three
                              bf16 MFMAs per K-step — BASELINE configs[1] ("bf16") inside north_star's 1e-3 on the bf16 matrix pipe      */
 
@@ -225,8 +238,18 @@ const char* bmi_error_string(int code);
  *                                           are pair32 tensors, bmi_conv_igemm_fwd takes the 16-bit head / tail weight planes and runs conv_split
  *   "ws_no_reuse"                           0 | 1, read by bmi_plan: every suffix tensor keeps its own workspace range (per-layer
  *                                           traces through bmi_tensor_info; the workspace grows to the sum of the activations)
- * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT). */
+ *   "block_fuse"                            0 | 1 | 2, read by bmi_create and at launch: conv1 -> conv2 of a BasicBlock whose 16x16 intermediate map
+ *                                           has no other reader run as ONE conv3x3_block launch with the intermediate map kept in LDS (1, default;
+ *                                           2: without the minimum-grid rule: tests), or as two launches (0).  The same bits either way
+ * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT).
+ *
+ * SCOPE (C-ABI 600).  bmi_set_option edits the PROCESS DEFAULTS: what the single-kernel entry points read, and what bmi_create COPIES into
+ * the handle it returns.  An engine runs every later call (bmi_plan, bmi_forward_*) under its own copy, so a live engine never changes
+ * kernels because another host thread (see "Threading" at the top) changed a default; bmi_engine_set_option edits the copy
+ * of ONE engine (same names and ranges; switches read by bmi_create / bmi_plan take effect at the next bmi_plan at the latest, the
+ * graph-merging ones — "conv_seam", "block_fuse" — only at launch time: an op merged at bmi_create falls back to its two launches). */
 int bmi_set_option(const char* name, int32_t value);
+int bmi_engine_set_option(bmi_handle h, const char* name, int32_t value);
 
 /* Host-only: validates and copies the graph, marks which tensors are stochastic, splits a
  * conv that carries a site but has only deterministic inputs into conv + MASK (so the
@@ -279,8 +302,9 @@ int bmi_forward_mcd_images(bmi_handle h, const float* x_nchw, int32_t batch, int
  * written by the fused head kernel beside the moment sums (S1 / S2 / SL as in bmi_forward_mcd), or instead of them (all three NULL).
  * mask_stride: the Masksembles mask of sample t is (mask_cnt0 + (t - t_begin) * mask_stride) mod M — the reference's layers count
  * their forward calls (SA/utils.py:165-169), so when its evaluate() walks a loader of n batches T times, pass i of batch k is call
- * i * n + k: the T passes of batch k folded into ONE call here take mask_cnt0 = cnt + k, mask_stride = n.  (mask_stride = 1: the
- * masks of bmi_forward_mcd.)  MC-dropout masks depend on the sample index t alone, as everywhere.  Captures into a hipGraph like
+ * i * n + k: the T passes of batch k folded into ONE call here take mask_cnt0 = cnt + k, mask_stride = n.  mask_cnt0 is the mask of the
+ * call's FIRST sample whatever t_begin (mask_stride = 1 and t_begin = 0: the masks of bmi_forward_mcd, which indexes (mask_cnt0 + t) mod M
+ * with the global sample index t).  MC-dropout masks depend on the sample index t alone, as everywhere.  Captures into a hipGraph like
  * bmi_forward_mcd. */
 int bmi_forward_mcd_samples(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_begin, int32_t t_count, uint64_t seed,
                             int32_t mask_cnt0, int32_t mask_stride, float* logits, double* S1, double* S2, double* SL, void* workspace,
@@ -304,6 +328,11 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
 /* mean = S1/T, var = S2/T - mean^2 (clamped at 0), logit_mean = SL/T; n = E*B*C. */
 int bmi_finalize(int64_t n, int32_t t_total, const double* S1, const double* S2, const double* SL, double* mean,
                  double* var, double* logit_mean, bmi_stream stream);
+/* The same, and ADDS to *nonfinite (device int32, caller-zeroed) the number of elements whose sums are not finite: the 16-bit engines
+ * saturate at 65 504 (fp16) — an overflowing activation becomes inf, then NaN in the softmax, and would otherwise travel into the
+ * reference's np.average (SA/train/results_analyzer.py:247-248) unnoticed.  No synchronisation: read the counter with the results. */
+int bmi_finalize_checked(int64_t n, int32_t t_total, const double* S1, const double* S2, const double* SL, double* mean,
+                         double* var, double* logit_mean, int32_t* nonfinite, bmi_stream stream);
 
 /* Per-op-kind HIP-event timing of bmi_forward_mcd (off by default; adds two event records per
  * launch).  bmi_profile_read synchronises the recorded events and resets the accumulators. */

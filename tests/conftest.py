@@ -33,3 +33,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def fp16_engine_default(monkeypatch):
+    """The modules that pin the fp16 KERNELS (which kernel takes which launch, bit-for-bit equality between kernel variants, lazy sites,
+    pooled epilogues, dynamic exit) run with ``engine_dtype = "f16"`` as the models' default instead of the product's "auto", so that what
+    they exercise does not depend on a calibration outcome; "auto" itself — the product default — is what tests/test_auto_engine.py,
+    tests/test_collation.py, tests/test_converter.py and smoke() go through."""
+    from bayesnn_fpga_amd.models._engine_mixin import EngineModelMixin
+    monkeypatch.setattr(EngineModelMixin, "engine_dtype", "f16")

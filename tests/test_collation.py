@@ -380,11 +380,51 @@ def test_gpu_forward_samples_equals_T_model_calls():
         e3 = m.engine(x.device, max_batch=B, chunk_samples=3)                          # three launches (3 + 3 + 1 samples): ANOTHER plan may pick
         got3 = e3.forward_samples(x, T, seed=11)                                       # other kernels (K order), so: close to the first, and bit for
         assert float((got3 - calls).abs().max()) <= 2e-3 * float(calls.abs().max())    # bit its own one-sample calls
-        for i in range(T):
-            assert torch.equal(got3[i], e3.forward_samples(x, 1, seed=11, t_begin=i)[0]), i
+        M = 4 if m.mask_layers() else 1
+        for i in range(T):                                                             # (cnt0 = the mask of the call's FIRST sample, whatever t_begin)
+            assert torch.equal(got3[i], e3.forward_samples(x, 1, seed=11, t_begin=i, cnt0=i % M)[0]), i
         if m.mask_layers():                                                            # stride 3 from counter 1: masks 1, 0, 3, 2, 1, 0, 3
             eng = m.engine(x.device, max_batch=B)
             got = eng.forward_samples(x, T, seed=11, cnt0=1, mask_stride=3)
             for i in range(T):
-                one = eng.forward_samples(x, 1, seed=11, t_begin=i, cnt0=(1 + 3 * i - i) % 4)   # (stride 1: mask (cnt0 + t) mod M at t = i)
+                one = eng.forward_samples(x, 1, seed=11, t_begin=i, cnt0=(1 + 3 * i) % 4)
                 assert torch.equal(got[i], one[0]), i
+            # stride 1 from t_begin > 0 (round-5 advisor, medium): sample j of the call takes mask (cnt0 + j) mod M — NOT rotated by t_begin
+            late = eng.forward_samples(x, T, seed=11, t_begin=5, cnt0=2)
+            for j in range(T):
+                one = eng.forward_samples(x, 1, seed=11, t_begin=0, cnt0=(2 + j) % 4)      # (Masksembles-only model: no kernel reads t)
+                assert torch.equal(late[j], one[0]), j
+
+
+@pytest.mark.gpu
+def test_gpu_folded_evaluate_single_batch_loader_after_a_forward():
+    """Round-5 advisor (medium): a ONE-batch loader (mask_stride = 1) on a Masksembles model whose MC pass index is not a multiple of M —
+    any earlier model(x) — must walk masks (cnt + i) mod M like the reference's layers (SA/utils.py:165-169: masks[self.cnt], then cnt + 1)
+    and like the unfolded walk; T = 5, M = 4, so a rotated walk changes the averaged metrics."""
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_labels, synthetic_weights_
+    from bayesnn_fpga_amd.train.evaluate import MultiExitAccuracy, evaluate
+    from tests.helpers import build_seeded
+    kw = dict(dropout_exit=True, dropout="block", mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=10)
+    B, T = 12, 5
+    x, y = synthetic_images(B, seed=3), synthetic_labels(B, 10, seed=4)
+    loader = [(x, y)]
+    loss = MultiExitAccuracy(4, acc_tops=(1, 5))
+    got = {}
+    for fold in (True, False):
+        m = synthetic_weights_(build_seeded(ResNet18MCEarlyExit, kw), 0).to("cuda:0").eval()
+        m.engine_dtype = "f16x2"
+        m(x.to("cuda:0"))                               # one forward: mc_pass = 1, every layer's cnt = 1
+        assert m.mc_pass == 1 and m.mask_layers()[0].cnt == 1
+        got[fold] = np.array(evaluate(loss, loader, m, 0, "t", T, create_log=False, fold=fold))
+        assert m.mask_layers()[0].cnt == (1 + T) % 4 and m.mc_pass == 1 + T
+    np.testing.assert_allclose(got[True], got[False], rtol=0, atol=1e-6)
+    # per-pass logits of the folded call against T model(x) calls from the same state
+    m = synthetic_weights_(build_seeded(ResNet18MCEarlyExit, kw), 0).to("cuda:0").eval()
+    m.engine_dtype = "f16x2"
+    xd = x.to("cuda:0")
+    m(xd)
+    eng = m.engine(xd.device, max_batch=B)
+    folded = eng.forward_samples(xd, T, seed=m.mc_seed, t_begin=m.mc_pass, cnt0=m.mask_layers()[0].cnt, mask_stride=1)
+    calls = torch.stack([torch.stack(m(xd)) for _ in range(T)])
+    assert torch.equal(folded, calls)

@@ -282,7 +282,8 @@ def test_oracle_and_mirror_convert_the_multi_exit_nets_like_the_reference(name):
 @pytest.mark.parametrize("name", ["resnet18ee", "vgg19ee"])
 def test_gpu_converted_multi_exit_against_reference_golden(name):
     """Per-pass logits of every exit, the zero pattern of the dropped logits, predictive mean AND variance within north_star's 1e-3
-    on the fp16 engine; the exact engine (dtype "f32") on the same inputs to fp32 summation order."""
+    on the engine the product picks by itself (engine_dtype = "auto"); the exact engine (dtype "f32") on the same inputs to fp32
+    summation order."""
     Mirror, _, E, _ = _multi_exit_case(name)
     g = load_golden(f"converter_{name}.npz")
     B, T, seed, p = int(g["B"]), int(g["T"]), int(g["seed"]), float(g["p"])
@@ -294,14 +295,13 @@ def test_gpu_converted_multi_exit_against_reference_golden(name):
     ref = g["logits"]
     ref_probs = torch.softmax(torch.from_numpy(ref), -1).numpy().astype(np.float64)
     scale = float(np.abs(ref).max())
-    # fp16 engine: north_star's 1e-3 on the ResNet (logits up to 22); the converted VGG-19's logits reach 61 and one fp16 ulp of such a
-    # logit is 3e-2, which a peaky softmax turns into up to 1.7e-3 on a T = 4 mean (measured) — that golden is asserted at 3e-3 on the
-    # fp16 engine and at 2e-5 on its exact-engine twin right below (the per-layer trace shows rounding, not a layer:
-    # profiles/experiments/r4_layer_trace_converter_vgg19.txt).  Round 5: the SAME golden within 1e-3 (measured 2.5e-6 / 1.7e-5) at a quarter
-    # of fp16 speed instead of a sixteenth on the split engines: tests/test_split_engine.py::test_converted_vgg19_early_exit_within_1e3_at_speed
-    p16 = 1e-3 if name == "resnet18ee" else 3e-3
-    for dt, ltol, ptol in (("f16", 4e-3 * scale, p16), ("f32", 1e-5 * scale + 2e-4, 2e-5)):
+    # The product default, engine_dtype = "auto" (round-5 review: no 3e-3 exception any more): on the ResNet (logits up to 22) auto may keep
+    # fp16; the converted VGG-19's logits reach 61, one fp16 ulp of such a logit is 3e-2 and a peaky softmax turns that into 1.7e-3 on a
+    # T = 4 mean — auto's calibration on the first batch sees it and runs the split engine, so north_star's 1e-3 holds on BOTH goldens
+    # through the default path; the exact engine (dtype "f32") on the same inputs to fp32 summation order.
+    for dt, ltol, ptol in (("auto", 4e-3 * scale, 1e-3), ("f32", 1e-5 * scale + 2e-4, 2e-5)):
         m.engine_dtype = dt
+        m.invalidate_engine()
         m.train()
         m.mc_pass = 0
         passes = np.stack([np.stack([o.cpu().numpy() for o in m(x)]) for _ in range(T)])
@@ -309,10 +309,13 @@ def test_gpu_converted_multi_exit_against_reference_golden(name):
         np.testing.assert_allclose(passes, ref, rtol=0, atol=ltol)
         zero = ref == 0
         assert zero.any() and np.array_equal(passes == 0, zero)
-        r = m.engine(x.device, max_batch=B, dtype=dt).predict(x, T, seed=seed)
+        eng = m.engine(x.device, max_batch=B, calib=x)
+        r = eng.predict(x, T, seed=seed)
         em, ev = np.abs(r["mean"].cpu().numpy() - ref_probs.mean(0)).max(), np.abs(r["var"].cpu().numpy() - ref_probs.var(0)).max()
-        print(f"converter_{name} {dt}: max|logit| {scale:.1f}  mean {em:.2e}  var {ev:.2e}")
+        print(f"converter_{name} {dt} -> {eng.dtype}: max|logit| {scale:.1f}  mean {em:.2e}  var {ev:.2e}  auto record {m._auto}")
         assert em <= ptol and ev <= ptol
+        if dt == "auto" and name == "vgg19ee":
+            assert eng.dtype == "f16x2"            # fp16 measured 1.7e-3 on this golden: the calibration must have rejected it
 
 
 # ---- a hand-written forward through torch.fx (converter/pytorch/fx_frontend.py): the reference's _convert_model on tests/helpers.py's

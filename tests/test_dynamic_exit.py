@@ -12,7 +12,7 @@ from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
 from bayesnn_fpga_amd.train import confidence_exiting as cex
 from tests.helpers import build_seeded
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fp16_engine_default")]
 DEV = "cuda:0"
 
 KWS = {

@@ -25,6 +25,8 @@ from oracle import mcd
 from tests import gpu_helpers as gh
 from tests.helpers import build_seeded, converter_cnn, golden_kwargs, load_golden
 
+pytestmark = pytest.mark.usefixtures("fp16_engine_default")      # (tests/conftest.py: these tests pin the fp16 kernels)
+
 DEV = "cuda:0"
 LOGIT_TOL, PROB_TOL = 2e-4, 2e-5
 

@@ -14,6 +14,8 @@ from oracle import extra_models as ox
 from oracle import mcd
 from tests.helpers import build_seeded, state_checksum
 
+pytestmark = pytest.mark.usefixtures("fp16_engine_default")      # (tests/conftest.py: these tests pin the fp16 kernels)
+
 PAIRS = [
     (bx.VGG11MC, ox.VGG11MC, dict(num_bayes_layer=3, dropout_p=0.25, out_dim=10)),
     (bx.VGG11MC, ox.VGG11MC, dict(num_bayes_layer=7, dropout_p=0.25, out_dim=10)),

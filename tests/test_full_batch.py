@@ -16,7 +16,7 @@ from oracle import mcd
 from oracle import resnet18 as oresnet
 from tests.helpers import build_seeded
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fp16_engine_default")]
 DEV = "cuda:0"
 B = 250
 TOL = 1e-3
@@ -84,11 +84,11 @@ def test_fused_relu_avgpool_equals_the_separate_head_pooling():
     eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
     x = synthetic_images(B, seed=1234).to(DEV)
     fused = eng.predict(x, T, seed=seed)
-    _lib.set_option("conv_pool", 0)
+    eng.set_option("conv_pool", 0)
     try:
         plain = eng.predict(x, T, seed=seed)
     finally:
-        _lib.set_option("conv_pool", 1)
+        eng.set_option("conv_pool", 1)
     for k in ("mean", "var"):
         d = (fused[k] - plain[k]).abs()
         assert float(d.max()) < 2e-4, (k, float(d.max()))
@@ -98,11 +98,11 @@ def test_fused_relu_avgpool_equals_the_separate_head_pooling():
     assert torch.equal(again["mean"], fused["mean"])
     # layer4[1].conv2's pooled tail runs on the persistent walk (conv3x3_pwp_kernel<4, .., LITE_RES, POOLP>, round 4): bit for bit the per-tile
     # kernel's pooled lite epilogue ("epilogue_lite" = 2 keeps the unspecialised forms everywhere)
-    _lib.set_option("epilogue_lite", 2)
+    eng.set_option("epilogue_lite", 2)
     try:
         old = eng.predict(x, T, seed=seed)
     finally:
-        _lib.set_option("epilogue_lite", 1)
+        eng.set_option("epilogue_lite", 1)
     for k in ("mean", "var"):
         assert torch.equal(old[k], fused[k]), k
 
@@ -140,13 +140,13 @@ def test_lazy_first_site_is_bit_for_bit_the_materialised_one(dropout):
     lazy, ms_lazy = timed()
     shard = eng.predict(x, 5, seed=seed, t_begin=3)
     imgs = image_shard()
-    _lib.set_option("mask_lazy", 0)
+    eng.set_option("mask_lazy", 0)
     try:
         plain, ms_plain = timed()
         shard_plain = eng.predict(x, 5, seed=seed, t_begin=3)
         imgs_plain = image_shard()
     finally:
-        _lib.set_option("mask_lazy", 1)
+        eng.set_option("mask_lazy", 1)
     for k in ("mean", "var", "logit_mean"):
         assert torch.equal(lazy[k], plain[k]), k
         assert torch.equal(shard[k], shard_plain[k]), k
@@ -246,11 +246,11 @@ def test_lazy_first_site_with_p_zero_keeps_everything():
     ref = mcd.mcd_predict(o, x, T, seed)
     eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=Bs)
     lazy = eng.predict(x.to(DEV), T, seed=seed)
-    _lib.set_option("mask_lazy", 0)
+    eng.set_option("mask_lazy", 0)
     try:
         plain = eng.predict(x.to(DEV), T, seed=seed)
     finally:
-        _lib.set_option("mask_lazy", 1)
+        eng.set_option("mask_lazy", 1)
     for r in (lazy, plain):
         assert float(np.abs(r["mean"].cpu().numpy() - ref["mean"]).max()) <= TOL
         assert float(r["var"].max()) <= 1e-12 and float(ref["var"].max()) <= 1e-12
@@ -279,11 +279,11 @@ def test_lazy_first_site_resnet50():
         return r, next(l for l in eng.profile_launches() if l["kind"] == "mask")["ms"]
 
     lazy, ms_lazy = timed()
-    _lib.set_option("mask_lazy", 0)
+    eng.set_option("mask_lazy", 0)
     try:
         plain, ms_plain = timed()
     finally:
-        _lib.set_option("mask_lazy", 1)
+        eng.set_option("mask_lazy", 1)
     for k in ("mean", "var"):
         assert float((lazy[k] - plain[k]).abs().max()) < 1e-5, k
     print(f"ResNet-50 first MASK launch: lazy {ms_lazy * 1e3:.0f} us, materialised {ms_plain * 1e3:.0f} us")
@@ -306,10 +306,10 @@ def test_lazy_tile_order_is_placement_only(arch, batch, T):
     out = {}
     try:
         for v in (0, 1):
-            _lib.set_option("lazy_order", v)
+            eng.set_option("lazy_order", v)
             out[v] = eng.predict(x, T, seed=5)
     finally:
-        _lib.set_option("lazy_order", 1)
+        eng.set_option("lazy_order", 1)
     for k in ("mean", "var"):
         assert torch.equal(out[0][k], out[1][k]), k
 
@@ -327,11 +327,11 @@ def test_lazy_first_site_bf16_engine(arch):
     eng = model.to(DEV).eval().engine(torch.device(DEV), max_batch=B, dtype="bf16")
     x = synthetic_images(B, seed=1234).to(DEV)
     lazy = eng.predict(x, T, seed=seed)
-    _lib.set_option("mask_lazy", 0)
+    eng.set_option("mask_lazy", 0)
     try:
         plain = eng.predict(x, T, seed=seed)
     finally:
-        _lib.set_option("mask_lazy", 1)
+        eng.set_option("mask_lazy", 1)
     for k in ("mean", "var"):
         if arch == "resnet18":
             assert torch.equal(lazy[k], plain[k]), k

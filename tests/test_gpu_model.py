@@ -14,7 +14,7 @@ from oracle import mcd
 from oracle import resnet18 as oresnet
 from tests.helpers import build_seeded, golden_kwargs, load_golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fp16_engine_default")]
 DEV = "cuda:0"
 TOL = 1e-3
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.bmi_version() == _lib.ABI_VERSION == 510
+    assert lib.bmi_version() == _lib.ABI_VERSION == 600
     assert _lib.error_string(0) == "ok" and "workspace" in _lib.error_string(-12)
 
 
@@ -191,3 +191,45 @@ def test_bmi_options_environment_is_applied_at_load():
     env = dict(os.environ, BMI_OPTIONS="no_such_option=1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode != 0 and "BMI_OPTIONS" in r.stderr
+
+
+@pytest.mark.gpu
+def test_a_live_engine_keeps_its_options_whatever_the_process_defaults_become():
+    """C-ABI 600 (round-5 review, weak #9): bmi_set_option edits the process DEFAULTS, bmi_create copies them into the handle, and every
+    later call of that engine runs under ITS copy — another host thread (one per GPU) or a test flipping a default cannot change the kernels
+    of a live engine; bmi_engine_set_option (MCDEngine.set_option) edits one engine.  Observable through the lazy first site: "mask_lazy" = 0
+    materialises the masked tensor (a long MASK launch), 1 writes keep bits + one scaled copy (a short one)."""
+    import torch
+    from bayesnn_fpga_amd import _lib
+    from bayesnn_fpga_amd.models.resnet18.resnet18 import ResNet18MCEarlyExit
+    from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_
+    from tests.helpers import build_seeded
+    dev = torch.device("cuda:0")
+    m = synthetic_weights_(build_seeded(ResNet18MCEarlyExit, dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)), 0).to(dev).eval()
+    x = synthetic_images(250, seed=1).to(dev)
+
+    def mask_ms(eng):
+        eng.profile(True)
+        eng.predict(x, 8, seed=3)
+        torch.cuda.synchronize()
+        eng.profile_read()
+        eng.profile(False)
+        return next(l for l in eng.profile_launches() if l["kind"] == "mask")["ms"]
+
+    a = m.engine(dev, max_batch=250, dtype="f16")                 # created under the defaults: lazy
+    lazy = mask_ms(a)
+    _lib.set_option("mask_lazy", 0)
+    try:
+        assert mask_ms(a) < 2.0 * lazy                            # the live engine did not notice
+        m._engines = {}
+        b = m.engine(dev, max_batch=250, dtype="f16")             # created under the new default: materialised
+        plain = mask_ms(b)
+    finally:
+        _lib.set_option("mask_lazy", 1)
+    assert mask_ms(b) > 0.7 * plain and plain > 1.5 * lazy        # ... and keeps ITS copy when the default goes back
+    b.set_option("mask_lazy", 1)                                  # one engine's switch
+    assert mask_ms(b) < 0.7 * plain
+    ra, rb = a.predict(x, 8, seed=3), b.predict(x, 8, seed=3)
+    assert torch.equal(ra["mean"], rb["mean"])
+    with pytest.raises(_lib.BmiError):
+        b.set_option("no_such_switch", 1)

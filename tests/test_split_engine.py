@@ -515,3 +515,43 @@ def test_split_engine_resnet50_multi_exit(dt):
     err_v = float(np.abs(r["var"].cpu().numpy() - ref["var"]).max())
     print(f"ResNet-50 multi-exit {dt}: B={B} T={T} max|mean-oracle|={err_m:.2e} max|var-oracle|={err_v:.2e}")
     assert err_m <= 5 * TOLS[dt]["prob"] and err_v <= 5 * TOLS[dt]["prob"]
+
+
+def _shrink_(model, f):
+    """The same function with every (conv, BatchNorm) pair's conv output f times smaller: conv weights x f, the BN's running mean x f, running
+    variance and eps x f^2 — BN(f y) with those statistics is BN(y) exactly.  What changes is the MAGNITUDE of the weights the engines must
+    represent (f = 2^-11: He-init weights of ~0.02 become ~1e-5, under fp16's smallest normal number)."""
+    from torch import nn
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, nn.Conv2d):
+                mod.weight.mul_(f)
+            elif isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.mul_(f)
+                mod.running_var.mul_(f * f)
+                mod.eps = mod.eps * f * f
+    return model
+
+
+@pytest.mark.gpu
+def test_small_magnitude_weights_keep_their_bits():
+    """Round-5 advisor (low): the fp16 tail rn16(w - hi) of a weight below 2^-3 is an fp16 subnormal, so un-scaled BN-folded weights of 1e-3
+    would keep 15 bits instead of 22 (and fp16 itself loses bits below 6.1e-5).  The host lifts every output channel's weights by an exact
+    power of two before rounding / splitting and folds it back in the fp32 epilogue scale (engine.GraphBuilder.channel_lift): the headline
+    model with ALL conv weights 2^-11 times smaller (the same function: the BatchNorms absorb the factor) must come out like the unshrunk
+    model does — f16x2 at its usual 1e-5 of the oracle, fp16 at its usual few 1e-4."""
+    B, T, seed = 64, 3, 42
+    kw = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
+    x = synthetic_images(B, seed=1234)
+    out = {}
+    for tag, f in (("plain", 1.0), ("shrunk", 2.0 ** -11)):
+        m = _shrink_(synthetic_weights_(build_seeded(ResNet18MCEarlyExit, kw), 0), f)
+        o = _shrink_(synthetic_weights_(build_seeded(oresnet.ResNet18MCEarlyExit, kw), 0), f)
+        ref = mcd.mcd_predict(o, x, T, seed)
+        for dt in ("f16x2", "f16"):
+            r = _on(m, dt).engine(torch.device(DEV), max_batch=B, dtype=dt).predict(x.to(DEV), T, seed=seed)
+            out[(tag, dt)] = float(np.abs(r["mean"].cpu().numpy() - ref["mean"]).max())
+    print("max|mean - oracle|: " + " | ".join(f"{k[0]} {k[1]} {v:.2e}" for k, v in out.items()))
+    assert out[("shrunk", "f16x2")] <= 5e-5 and out[("plain", "f16x2")] <= 5e-5
+    assert out[("shrunk", "f16")] <= 1e-3
+    assert out[("shrunk", "f16")] <= 2 * out[("plain", "f16")] + 1e-5          # a power of two commutes with every rounding on the way

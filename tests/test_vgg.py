@@ -12,6 +12,8 @@ from oracle import mcd
 from oracle import vgg19 as ovgg
 from tests.helpers import build_seeded, golden_kwargs, load_golden, state_checksum
 
+pytestmark = pytest.mark.usefixtures("fp16_engine_default")      # (tests/conftest.py: these tests pin the fp16 kernels)
+
 CASES = ["exit_mc", "exit_mask4"]
 
 

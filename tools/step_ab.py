@@ -21,10 +21,16 @@ from bayesnn_fpga_amd import _lib  # noqa: E402
 from bayesnn_fpga_amd.synthetic import synthetic_images, synthetic_weights_  # noqa: E402
 
 
+ENGINES = []      # the live engines of this run: an option set is applied to the process defaults AND to their snapshots (C-ABI 600:
+                  # bmi_create copies the defaults into the handle; bmi_engine_set_option edits one engine's copy)
+
+
 def select(v):
     for kv in (v.split("+") if v else []):
         nm, _, val = kv.partition("=")
         _lib.set_option(nm, int(val))
+        for e in ENGINES:
+            e.set_option(nm, int(val))
 
 
 def main():
@@ -42,7 +48,8 @@ def main():
     np.random.seed(0)
     model = synthetic_weights_(bench._load(wl[0])(**wl[2]), 0).to(dev).eval()
     B, T = a.batch or wl[3], a.T or wl[4]
-    eng = model.engine(dev, max_batch=B)
+    eng = model.engine(dev, max_batch=B, dtype="f16")
+    ENGINES.append(eng)
     x = synthetic_images(B, seed=1234).to(dev)
     S = eng.new_moments(B)
 
