@@ -33,7 +33,8 @@
 //              kind, residual (a pair32 tensor too), ReLU (epilogue_quad_f32v: arithmetic and order of every other conv kernel) — and
 //              the result ENCODED into the pair32 output: whole contiguous rows to and from HBM
 // Two wave groups in ping-pong (below).  The fp16-engine launch forms that exist for speed only (fused shortcut, pair, pooling, lazy
-// sites, split-K, dynamic-exit row tables) are not built for this dtype (bmi_create keeps them out, as for the exact engine).
+// sites) are not built for this dtype (bmi_create keeps them out, as for the exact engine); the fused shortcut, pair launches, split-K and the
+// dynamic-exit row tables (IMAP) are.
 #include <type_traits>
 
 #include "conv_epilogue.h"
@@ -100,7 +101,9 @@ static __device__ unsigned int g_split_zero[64];   // zeros: what an out-of-imag
 // p + p / Wo + 1; written once at kernel start, never by the DMA, whose eight-pixel pieces never straddle a row), so a shifted read at an edge lands
 // on padding by itself.  (SHX = 1 clears 16 registers per 16-deep sub-step behind the fragment reads, in the LOAD part the other wave group's MFMA
 // part has to cover: measured +0.8 % instead of the probe's 17 %.)
-template <bool BF, int TI, int SHX>
+// IMAP (dynamic early exit, bmi_forward_mcd_exit): the launch covers the still-active images only — compact image n of the launch is row
+// a.imap[n] of every tensor and of the Philox index space (ConvArgs::imap; a kernel template parameter like everywhere else: see map_image)
+template <bool BF, int TI, int SHX, bool IMAP = false>
 __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
     constexpr bool PADX = SHX == 2;
     constexpr int CT = 64 * TI;
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
         const int m = pix0 + row;
         const bool vm = m < a.M;
         const int mm = vm ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int nc = mm / HoWo, rem = mm - nc * HoWo;
+        const int n = map_image<IMAP>(a, nc);               // (IMAP: the tensors' row of compact image nc)
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         iy0[i] = vm ? oy * a.stride - a.pad : -0x10000;      // a row beyond M never passes the bounds test
         ix0[i] = ox * a.stride - a.pad;
@@ -489,7 +493,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvArgs a) {
             const int x_ = pl & 31 & (CHUNKS - 1);
             const f32x4_s r0 = *(const f32x4_s*)(smem + pl * ROWB + (((c8l >> 2) ^ x_) << 4));
             const f32x4_s r1 = *(const f32x4_s*)(smem + pl * ROWB + ((((c8l >> 2) + 1) ^ x_) << 4));
-            const int n = m_o / HoWo, rem = m_o - n * HoWo;
+            const int nc = m_o / HoWo, rem = m_o - nc * HoWo;
+            const int n = map_image<IMAP>(a, nc);
             PixelCtx p;
             p.out_off = ((size_t)n * HoWo + rem) * a.Cout;
             p.resp = nullptr;
@@ -577,14 +582,19 @@ static int launch_split_t(const ConvArgs& a, hipStream_t s) {
     // (a tile must start and end on a map row boundary, so that a pixel's horizontal neighbours are in its own tile: 256 % Wo == 0)
     const bool shx = opt_split_shx() && !SP_TAP_MAJOR && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.partial && SP_PT % a.Wo == 0;
     const bool padx = shx && a.Wo % 8 == 0 && opt_split_shx() != 2;      // ("split_shx" = 2: the clearing form everywhere: A/B, tests)
+#define SP_LAUNCH_I(TI_, IM_)                                                                                    \
+    {                                                                                                            \
+        if (padx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 2, IM_>), grid, block, 0, s, a);                \
+        else if (shx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 1, IM_>), grid, block, 0, s, a);            \
+        else hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 0, IM_>), grid, block, 0, s, a);                     \
+    }
 #define SP_LAUNCH(TI_)                                                                                           \
     {                                                                                                            \
-        if (padx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 2>), grid, block, 0, s, a);                     \
-        else if (shx) hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 1>), grid, block, 0, s, a);                 \
-        else hipLaunchKernelGGL((conv_split_kernel<BF, TI_, 0>), grid, block, 0, s, a);                          \
+        if (a.imap) SP_LAUNCH_I(TI_, true) else SP_LAUNCH_I(TI_, false)                                          \
     }
     if (ct == 256) SP_LAUNCH(4) else if (ct == 128) SP_LAUNCH(2) else SP_LAUNCH(1)
 #undef SP_LAUNCH
+#undef SP_LAUNCH_I
     BMI_CHECK_LAUNCH();
     if (a.partial) {
         const long total = (long)a.M * (a.Cout >> 3);
@@ -601,7 +611,7 @@ bool conv_takes_split_kernel(int cin, int cout) { return cin % 32 == 0 && cout %
 // a.in / a.res / a.out: pair32 tensors (conv_epilogue.h); a.wgt: 16-bit [2][Cout][k*k*Cin] head / tail planes
 int launch_conv_split(const ConvArgs& a, int bf16, hipStream_t s) {
     if (!conv_takes_split_kernel(a.Cin, a.Cout)) return BMI_ERR_UNSUPPORTED;
-    if (a.in_bits || a.in2_bits || a.pool || a.pool_b || a.imap) return BMI_ERR_UNSUPPORTED;
+    if (a.in_bits || a.in2_bits || a.pool || a.pool_b || (a.imap && a.partial)) return BMI_ERR_UNSUPPORTED;
     // fused 1x1 shortcut: in2 a pair32 tensor of Cin2 channels read at stride2 (no padding), wgt2 the planes [2][Cout][Cin2]
     if (a.in2 && (!a.wgt2 || a.wgt_b || a.Cin2 % 32 != 0 || a.Cin2 <= 0 || a.stride2 < 1 || a.in2_mod <= 0 || (a.Ho - 1) * a.stride2 >= a.H2 ||
                   (a.Wo - 1) * a.stride2 >= a.W2))

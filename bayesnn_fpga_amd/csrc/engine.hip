@@ -93,7 +93,7 @@ struct bmi_engine_s {
     size_t ws_bytes = 0, exit_off = 0;   // exit_off: 2 active-image lists + a counter (dynamic early exit)
     size_t splitk_off = 0;               // fp32 partial sums of the split-K prefix convs
     int image_offset = 0;                // batch index of the current call's image 0 (bmi_forward_mcd_images), else 0
-    size_t head_off = 0;                 // float64 partial sums of a head launch's 32-sample groups (joined in group order)
+    size_t head_off = 0, head_part_bytes = 0;   // float64 partial sums of a head launch's 32-sample groups (joined in group order), one region per exit
     // bmi_forward_mcd_samples: per-sample logits out, Masksembles masks walked with a stride
     float* logits_out = nullptr;         // (run time) [t_count][E][batch][C] of the current call, or null
     bool no_moments = false;             // (run time) the heads write per-sample logits only
@@ -222,7 +222,7 @@ static int set_named_option(BmiOptions& o, const char* name, int32_t value) {
         {"dense_exact", &BmiOptions::dense_exact, 0, 1},
         {"lazy_order", &BmiOptions::lazy_order, 0, 1},
         {"epilogue_lite", &BmiOptions::epilogue_lite, 0, 2},
-        {"block_fuse", &BmiOptions::block_fuse, 0, 2},                    // read by bmi_create (which ops merge) and at launch
+        {"head_batch", &BmiOptions::head_batch, 0, 1},
     };
     for (const Row& r : rows)
         if (std::strcmp(name, r.name) == 0) {
@@ -734,7 +734,8 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
     }
     off += sk_bytes;
     h->head_off = off;
-    off += align_up((size_t)((chunk_samples + 31) / 32) * 3 * max_batch * h->out_dim * sizeof(double), 256);
+    h->head_part_bytes = align_up((size_t)((chunk_samples + 31) / 32) * 3 * max_batch * h->out_dim * sizeof(double), 256);
+    off += h->head_part_bytes * (size_t)h->n_exits;      // one region per exit: the heads of a batched launch (launch_head_fused_multi) run concurrently
     h->perm.clear();
     for (const std::vector<OpInfo>* ops : {&h->prefix, &h->suffix})
         for (const OpInfo& op : *ops) {
@@ -821,6 +822,49 @@ struct ProfScope {
     }
 };
 
+// The arguments of one exit head's launch (head_fused.hip).
+HeadArgs make_head_args(bmi_engine_s* e, const OpInfo& op, char* ws, int N, int B, int t0, uint64_t seed, int cnt0, double* S1, double* S2, double* SL,
+                        const int* imap, int Bc) {
+    const bmi_op_desc& d = op.d;
+    const TensorInfo& tin = e->tensors[d.in];
+    const int b0 = e->image_offset;
+    const int n_rows = imap ? (N / Bc) * B : N;
+    HeadArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = ws + tin.offset;
+    a.in_kind = (e->split && !tin.dense_out) ? 2 + e->split        // the split engines' pair32 tensors
+                : (tin.f32 || tin.pooled_now) ? 1 : (e->bf16 ? 2 : 0);      // pooled_now: fp32 means [row][K] written by the conv
+    a.in_mod = tin.stoch ? n_rows : B;
+    a.imap = imap; a.Bc = Bc;
+    a.HW = tin.pooled_now ? 1 : tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = imap ? N / Bc : N / B;
+    a.w = (const float*)d.weight; a.bias = d.bias; a.C = e->out_dim;
+    const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
+    const uint64_t soff = (uint64_t)b0 * (uint64_t)tin.c;          // (site_off of run_op: [B, K] features, elementwise and per-channel draws alike)
+    SiteArgs sf = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0, soff);
+    SiteArgs sl = resolve_site(on_logits ? &d.site : nullptr, seed, cnt0);
+    for (SiteArgs* sa : {&sf, &sl})                                 // Masksembles tables walked with a stride (bmi_forward_mcd_samples): see run_op
+        if (sa->kind == BMI_SITE_MASKSEMBLE && e->mask_permuted)
+            for (const auto& pr : e->perm)
+                if (pr.first == sa->masks) {
+                    sa->masks = (const float*)(ws + pr.second);
+                    sa->cnt0 = (sa->num_masks - e->mask_t_begin % sa->num_masks) % sa->num_masks;
+                    break;
+                }
+    a.site = sf;
+    a.site_logits = sl;
+    a.b0 = b0;
+    const size_t eo = (size_t)d.out * B * e->out_dim;
+    a.S1 = S1 + eo; a.S2 = S2 + eo; a.SL = SL + eo;
+    if (e->no_moments) a.S1 = a.S2 = a.SL = nullptr;
+    a.part = (double*)(ws + e->head_off + (size_t)d.out * e->head_part_bytes);     // this exit's own region
+    if (e->logits_out) {            // per-sample logits of this exit: [t - t_begin][E][batch][C]
+        const size_t plane = (size_t)e->logits_batch * e->out_dim;
+        a.logits = e->logits_out + ((size_t)(t0 - e->logits_t_begin) * e->n_exits + d.out) * plane;
+        a.logits_tstride = (size_t)e->n_exits * plane;
+    }
+    return a;
+}
+
 // imap / rows / Bc: dynamic early exit: N = samples * Bc compact images of the B-image batch; imap = the Bc active images
 // (heads), rows = the N-entry row table (ConvArgs::imap); null = all images
 int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, int B, int t0, uint64_t seed, int cnt0,
@@ -849,7 +893,7 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         return sa;
     };
     if (imap && d.kind != BMI_OP_CONV && d.kind != BMI_OP_HEAD) return BMI_ERR_UNSUPPORTED;
-    if (imap && e->f32) return BMI_ERR_UNSUPPORTED;
+    if (imap && e->f32 && !e->split) return BMI_ERR_UNSUPPORTED;      // (the exact engine: parity only)
     // a lazy site's tensor (see bmi_create) is written now if this op cannot apply the mask itself
     auto pending = [&](int id) { return id >= 0 && e->tensors[id].lazy_pending; };
     auto materialise = [&](int id) -> int {
@@ -1116,34 +1160,44 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
             return launch_dense_f32(ws + tin.offset, (e->split && !tin.dense_out) ? 2 + e->split : (tin.f32 ? 1 : (e->bf16 ? 2 : 0)), (const float*)d.weight, d.bias,
                                     (float*)(ws + e->tensors[d.out].offset), N, tin.stoch ? N : B, tin.c, op.cout, d.relu,
                                     resolve_site(&d.site, seed, cnt0, site_off(d.site, (size_t)op.cout, (size_t)op.cout)), B, t0, s);
-        case BMI_OP_HEAD: {
+        case BMI_OP_HEAD:
             // pool + site + Linear + softmax + the chunk's moment sums in one launch (head_fused.hip)
-            HeadArgs a;
-            std::memset(&a, 0, sizeof(a));
-            a.in = ws + tin.offset;
-            a.in_kind = (e->split && !tin.dense_out) ? 2 + e->split        // the split engines' pair32 tensors
-                        : (tin.f32 || tin.pooled_now) ? 1 : (e->bf16 ? 2 : 0);      // pooled_now: fp32 means [row][K] written by the conv
-            a.in_mod = tin.stoch ? n_rows : B;
-            a.imap = imap; a.Bc = Bc;
-            a.HW = tin.pooled_now ? 1 : tin.h * tin.w; a.K = tin.c; a.B = B; a.t0 = t0; a.tc = imap ? N / Bc : N / B;
-            a.w = (const float*)d.weight; a.bias = d.bias; a.C = e->out_dim;
-            const bool on_logits = d.site_pos == BMI_SITE_POS_INNER;
-            a.site = resolve_site(on_logits ? nullptr : &d.site, seed, cnt0, site_off(d.site, (size_t)tin.c, (size_t)tin.c));
-            a.site_logits = resolve_site(on_logits ? &d.site : nullptr, seed, cnt0);
-            a.b0 = b0;
-            const size_t eo = (size_t)d.out * B * e->out_dim;
-            a.S1 = S1 + eo; a.S2 = S2 + eo; a.SL = SL + eo;
-            if (e->no_moments) a.S1 = a.S2 = a.SL = nullptr;
-            a.part = (double*)(ws + e->head_off);
-            if (e->logits_out) {            // per-sample logits of this exit: [t - t_begin][E][batch][C]
-                const size_t plane = (size_t)e->logits_batch * e->out_dim;
-                a.logits = e->logits_out + ((size_t)(t0 - e->logits_t_begin) * e->n_exits + d.out) * plane;
-                a.logits_tstride = (size_t)e->n_exits * plane;
-            }
-            return launch_head_fused(a, s);
-        }
+            return launch_head_fused(make_head_args(e, op, ws, N, B, t0, seed, cnt0, S1, S2, SL, imap, Bc), s);
     }
     return BMI_ERR_INVALID;
+}
+
+// One chunk of the suffix.  Consecutive exit heads run as ONE launch ("head_batch"; launch_head_fused_multi): with exit-only dropout — what
+// every run of the paper uses, Software_Artifact/script_figs/journal_script.sh:10-63 — the suffix is nothing but the heads, each a launch of
+// mostly fixed latency; the same arithmetic per head, the same bits.
+int run_suffix(bmi_engine_s* e, const float* x, char* ws, int N, int B, int t0, uint64_t seed, int cnt0, double* S1, double* S2, double* SL,
+               hipStream_t s) {
+    const std::vector<OpInfo>& ops = e->suffix;
+    for (size_t i = 0; i < ops.size();) {
+        size_t j = i;
+        if (opt_head_batch())
+            while (j < ops.size() && j - i < BMI_HEAD_PACK_MAX && ops[j].d.kind == BMI_OP_HEAD && !e->tensors[ops[j].d.in].lazy_pending) ++j;
+        if (j - i >= 2) {
+            HeadArgs list[BMI_HEAD_PACK_MAX];
+            for (size_t k = i; k < j; ++k) list[k - i] = make_head_args(e, ops[k], ws, N, B, t0, seed, cnt0, S1, S2, SL, nullptr, 0);
+            int rc;
+            {
+                ProfScope prof(e, BMI_OP_HEAD, s);
+                prof.r.out = ops[i].d.out; prof.r.images = N;
+                rc = launch_head_fused_multi(list, (int)(j - i), s);
+            }
+            if (rc == BMI_OK) { i = j; continue; }
+            if (rc != BMI_ERR_UNSUPPORTED) return rc;
+            if (e->profiling && !e->recs.empty()) {          // not taken: drop the empty record, the heads follow one by one
+                e->pool.push_back(e->recs.back().a); e->pool.push_back(e->recs.back().b);
+                e->recs.pop_back();
+            }
+        }
+        const int rc = run_op(e, ops[i], x, ws, N, B, t0, seed, cnt0, S1, S2, SL, s);
+        if (rc != BMI_OK) return rc;
+        ++i;
+    }
+    return BMI_OK;
 }
 
 }  // namespace
@@ -1197,10 +1251,8 @@ int bmi_forward_mcd(bmi_handle h, const float* x_nchw, int32_t batch, int32_t t_
     for (int t0 = t_begin; t0 < t_begin + t_count; t0 += h->chunk) {
         const int tc = std::min(h->chunk, t_begin + t_count - t0);
         const int N = tc * batch;
-        for (const OpInfo& op : h->suffix) {
-            const int rc = run_op(h, op, x_nchw, ws, N, batch, t0, seed, mask_cnt0, S1, S2, SL, s);
-            if (rc != BMI_OK) return rc;
-        }
+        const int rc = run_suffix(h, x_nchw, ws, N, batch, t0, seed, mask_cnt0, S1, S2, SL, s);
+        if (rc != BMI_OK) return rc;
     }
     return BMI_OK;
 }
@@ -1253,7 +1305,7 @@ int bmi_forward_mcd_exit(bmi_handle h, const float* x_nchw, int32_t batch, int32
     BmiOptionScope opt_scope(&h->opts);
     if (batch < 1 || t_count < 1 || mask_cnt0 < 0 || first_exit < 0) return BMI_ERR_INVALID;
     if (h->max_batch == 0 || batch > h->max_batch) return BMI_ERR_INVALID;
-    if (t_count > h->chunk || h->f32) return BMI_ERR_UNSUPPORTED;     // an exit's decision needs ALL samples of the stage in the workspace
+    if (t_count > h->chunk || (h->f32 && !h->split)) return BMI_ERR_UNSUPPORTED;     // an exit's decision needs ALL samples of the stage in the workspace
     if (workspace_bytes < h->ws_bytes) return BMI_ERR_NOMEM;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;

@@ -41,8 +41,9 @@ typedef _Float16 half8_h __attribute__((ext_vector_type(8)));
 // Here a wave keeps 16 accumulators, nothing is exchanged (the logits tile goes straight to the [class][sample] array the
 // softmax reads), the feature chunk is 256 deep (32 KB) and a wave stages its [32 classes][32 k] weight blocks in 4.5 KB of
 // its own (8 lanes per 128-byte row segment instead of one 2 KB row per lane): 66 KB of LDS, two workgroups per CU.
-template <int RT, int KIND, bool CSPLIT = false>
-__global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArgs a) {
+// The kernel body, shared by the one-head launch and the batched one (head_fused_multi_kernel: blockIdx.z = which head of the pack).
+template <int RT, int KIND, bool CSPLIT>
+__device__ __forceinline__ void head_body(const HeadArgs& a) {
     static_assert(!CSPLIT || (RT >= 3 && RT <= 4), "class split: one wave per class tile");
     constexpr int KC = CSPLIT ? 256 : HEAD_KC;                 // K chunk held in LDS (floats per sample)
     constexpr int FEAT_BYTES = 32 * KC * 4;
@@ -349,6 +350,22 @@ __global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArg
     }
 }
 
+template <int RT, int KIND, bool CSPLIT = false>
+__global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_kernel(HeadArgs a) {
+    head_body<RT, KIND, CSPLIT>(a);
+}
+
+// Several exit heads in ONE launch (round 6): with exit-only dropout — the configuration every run of the paper uses,
+// Software_Artifact/script_figs/journal_script.sh:10-63 — the whole network is the once-per-batch prefix and the sample-folded suffix is
+// NOTHING BUT the four (VGG-19: five) heads, each a ~60 us launch of mostly fixed latency at T = 10: grid.z walks the pack, every workgroup
+// runs the one-head body on its head's arguments (same arithmetic, same bits; tests/test_full_batch.py).  The heads of a pack agree in
+// everything the template parameters and the grid depend on (class tiles, input kind, images, samples); launch_head_fused_multi checks.
+struct HeadArgsPack { HeadArgs a[BMI_HEAD_PACK_MAX]; };
+template <int RT, int KIND, bool CSPLIT = false>
+__global__ __launch_bounds__(256, CSPLIT ? 2 : 1) void head_fused_multi_kernel(HeadArgsPack p) {
+    head_body<RT, KIND, CSPLIT>(p.a[blockIdx.z]);
+}
+
 // Joins the per-group partial sums of an image in GROUP ORDER into the caller's accumulators: with hardware float64 atomics the
 // groups met in whatever order the workgroups finished, and the last bit of the sums of more than 64 samples changed from run to
 // run (round-2 verdict); an ordered "last arriver adds all" reduction inside the head kernel needed agent-scope fences that doubled
@@ -367,6 +384,43 @@ __global__ __launch_bounds__(256) void head_join_kernel(const double* __restrict
         s1 += pp[0]; s2 += pp[plane]; sl += pp[2 * plane];
     }
     S1[o] += s1; S2[o] += s2; SL[o] += sl;
+}
+
+struct HeadJoinPack { const double* part[BMI_HEAD_PACK_MAX]; double *S1[BMI_HEAD_PACK_MAX], *S2[BMI_HEAD_PACK_MAX], *SL[BMI_HEAD_PACK_MAX]; };
+__global__ __launch_bounds__(256) void head_join_multi_kernel(HeadJoinPack p, int groups, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int z = blockIdx.y;
+    const size_t o = (size_t)i, plane = (size_t)B * C;
+    double s1 = 0.0, s2 = 0.0, sl = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        const double* pp = p.part[z] + (size_t)g * 3 * plane + o;
+        s1 += pp[0]; s2 += pp[plane]; sl += pp[2 * plane];
+    }
+    p.S1[z][o] += s1; p.S2[z][o] += s2; p.SL[z][o] += sl;
+}
+
+template <int RT>
+static void launch_rt_multi(const HeadArgsPack& p, int n, hipStream_t s) {
+    const HeadArgs& a = p.a[0];
+    const dim3 grid((unsigned)a.B, (unsigned)((a.tc + 31) / 32), (unsigned)n), block(256);
+#define HEAD_LAUNCH_M(CS)                                                                                                 \
+    switch (a.in_kind) {                                                                                                  \
+        case 1: hipLaunchKernelGGL((head_fused_multi_kernel<RT, 1, CS>), grid, block, 0, s, p); break;                    \
+        case 2: hipLaunchKernelGGL((head_fused_multi_kernel<RT, 2, CS>), grid, block, 0, s, p); break;                    \
+        case 3: hipLaunchKernelGGL((head_fused_multi_kernel<RT, 3, CS>), grid, block, 0, s, p); break;                    \
+        case 4: hipLaunchKernelGGL((head_fused_multi_kernel<RT, 4, CS>), grid, block, 0, s, p); break;                    \
+        default: hipLaunchKernelGGL((head_fused_multi_kernel<RT, 0, CS>), grid, block, 0, s, p); break;                   \
+    }
+    if constexpr (RT >= 3) {
+        static const int csplit = [] { const char* v = std::getenv("BMI_HEAD_CSPLIT"); return v ? std::atoi(v) : 1; }();
+        if (csplit) {
+            HEAD_LAUNCH_M(true)
+            return;
+        }
+    }
+    HEAD_LAUNCH_M(false)
+#undef HEAD_LAUNCH_M
 }
 
 template <int RT>
@@ -391,8 +445,7 @@ static void launch_rt(const HeadArgs& a, hipStream_t s) {
 #undef HEAD_LAUNCH
 }
 
-int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
-    HeadArgs a = a_in;
+static int head_prepare(HeadArgs& a) {
     const int groups = (a.tc + 31) / 32;
     if (groups <= 1) a.part = nullptr;             // one group per image: the workgroup adds into S1 / S2 / SL itself
     if (!a.in || !a.w || !a.bias) return BMI_ERR_INVALID;
@@ -402,6 +455,14 @@ int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
     if (a.imap && (a.Bc <= 0 || a.Bc > a.B)) return BMI_ERR_INVALID;
     if (a.K % 32 != 0 || a.C > 128) return BMI_ERR_UNSUPPORTED;
     if (a.site_logits.kind != BMI_SITE_NONE && a.site_logits.kind != BMI_SITE_ELEMENTWISE) return BMI_ERR_UNSUPPORTED;
+    return BMI_OK;
+}
+
+int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
+    HeadArgs a = a_in;
+    const int groups = (a.tc + 31) / 32;
+    const int rcp = head_prepare(a);
+    if (rcp != BMI_OK) return rcp;
     switch ((a.C + 31) / 32) {
         case 1: launch_rt<1>(a, s); break;
         case 2: launch_rt<2>(a, s); break;
@@ -413,6 +474,45 @@ int launch_head_fused(const HeadArgs& a_in, hipStream_t s) {
         const int n = (a.imap ? a.Bc : a.B) * a.C;
         hipLaunchKernelGGL(head_join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, groups, a.B, a.C, a.imap, a.Bc, a.S1,
                            a.S2, a.SL);
+        BMI_CHECK_LAUNCH();
+    }
+    return BMI_OK;
+}
+
+// n heads in one launch (n <= BMI_HEAD_PACK_MAX); BMI_ERR_UNSUPPORTED when the pack is not uniform (the caller launches them one by one).
+// Every head needs its OWN partial-sum scratch (`part`): they run concurrently.
+int launch_head_fused_multi(const HeadArgs* list, int n, hipStream_t s) {
+    if (!list || n < 1 || n > BMI_HEAD_PACK_MAX) return BMI_ERR_INVALID;
+    if (n == 1) return launch_head_fused(list[0], s);
+    HeadArgsPack p;
+    for (int i = 0; i < n; ++i) {
+        p.a[i] = list[i];
+        const int rcp = head_prepare(p.a[i]);
+        if (rcp != BMI_OK) return rcp;
+        const HeadArgs &x = p.a[i], &y = p.a[0];
+        if (x.imap || x.C != y.C || x.in_kind != y.in_kind || x.B != y.B || x.tc != y.tc || (x.part != nullptr) != (y.part != nullptr) ||
+            (x.S1 != nullptr) != (y.S1 != nullptr))
+            return BMI_ERR_UNSUPPORTED;
+        for (int j = 0; j < i; ++j)
+            if (x.part && x.part == p.a[j].part) return BMI_ERR_INVALID;
+    }
+    for (int i = n; i < BMI_HEAD_PACK_MAX; ++i) p.a[i] = p.a[0];
+    const HeadArgs& a = p.a[0];
+    switch ((a.C + 31) / 32) {
+        case 1: launch_rt_multi<1>(p, n, s); break;
+        case 2: launch_rt_multi<2>(p, n, s); break;
+        case 3: launch_rt_multi<3>(p, n, s); break;
+        default: launch_rt_multi<4>(p, n, s); break;
+    }
+    BMI_CHECK_LAUNCH();
+    if (a.part) {
+        HeadJoinPack j;
+        for (int i = 0; i < BMI_HEAD_PACK_MAX; ++i) {
+            const HeadArgs& x = p.a[i < n ? i : 0];
+            j.part[i] = x.part; j.S1[i] = x.S1; j.S2[i] = x.S2; j.SL[i] = x.SL;
+        }
+        const int groups = (a.tc + 31) / 32, m = a.B * a.C;
+        hipLaunchKernelGGL(head_join_multi_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)n), dim3(256), 0, s, j, groups, a.B, a.C);
         BMI_CHECK_LAUNCH();
     }
     return BMI_OK;

@@ -118,6 +118,8 @@ struct HeadArgs {   // fused exit head (head_fused.hip)
                           // null (hardware atomics then: the single-kernel entry point)
 };
 int launch_head_fused(const HeadArgs& a, hipStream_t s);
+#define BMI_HEAD_PACK_MAX 8
+int launch_head_fused_multi(const HeadArgs* list, int n, hipStream_t s);   // n uniform heads in one launch (grid.z); BMI_ERR_UNSUPPORTED -> one by one
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int launch_conv_igemm_wide(const ConvArgs& a, hipStream_t s);  // 256x256 tiles; BMI_ERR_UNSUPPORTED -> conv_igemm
@@ -185,7 +187,7 @@ struct BmiOptions {
     int pw_persist = 1;          // 1: plain-epilogue launches of conv3x3_pw run in its persistent form (conv3x3_pwp_kernel), 0: never
     int lazy_planar = 1;         // 1: lazy sites whose readers are all stride-2 consumers store their scaled copy + bits in the planar layout
     int ws_no_reuse = 0;         // bmi_plan: every suffix tensor keeps its own workspace range (per-layer traces)
-    int block_fuse = 1;          // 1: conv1 -> conv2 of a BasicBlock on 16x16 maps run as one conv3x3_block launch (2 = without its minimum-grid rule: tests), 0: two launches
+    int head_batch = 1;          // 1: consecutive exit heads of the suffix (exit-only dropout: the suffix is nothing but the heads) run as ONE launch, 0: one launch per head
 };
 BmiOptions& bmi_default_options();                 // the process defaults (engine.hip)
 extern thread_local const BmiOptions* bmi_tl_options;   // the snapshot of the engine whose entry point is running on this thread, else null
@@ -201,7 +203,7 @@ struct BmiOptionScope {
 BMI_OPT(mfma_shape_patch) BMI_OPT(mfma_shape_wide) BMI_OPT(unit_dtype) BMI_OPT(wide_persist_min) BMI_OPT(conv_pw) BMI_OPT(conv_wide)
 BMI_OPT(mask_lazy) BMI_OPT(conv_pool) BMI_OPT(conv_s2) BMI_OPT(split_shx) BMI_OPT(split_tile) BMI_OPT(conv_seam) BMI_OPT(conv_stream)
 BMI_OPT(splitk) BMI_OPT(dense_exact) BMI_OPT(lazy_order) BMI_OPT(epilogue_lite) BMI_OPT(xcd_split) BMI_OPT(pw_persist) BMI_OPT(lazy_planar)
-BMI_OPT(ws_no_reuse) BMI_OPT(block_fuse)
+BMI_OPT(ws_no_reuse) BMI_OPT(head_batch)
 #undef BMI_OPT
 int xcd_split_for(int n_ctiles, size_t weight_bytes);
 

@@ -71,7 +71,7 @@ class GraphBuilder:
         rounded / split — exact — and the caller folds 1 / lift[c] into the channel's epilogue scale."""
         w32 = w.detach().float()
         if lift is not None:
-            w32 = w32 * lift.reshape((-1,) + (1,) * (w32.dim() - 1))
+            w32 = w32 * lift.to(w32.device).reshape((-1,) + (1,) * (w32.dim() - 1))
         if self.dtype not in ("f16x2", "bf16x3"):
             return self.dev(w32, self.act_dtype)
         hi = w32.to(self.act_dtype)
@@ -138,12 +138,12 @@ class GraphBuilder:
             lift = self.channel_lift(wk, w2) if self.dtype in ("f16x2", "bf16x3") else None
             w2dev = self.conv_weight(w2, lift)                                         # (split engines: head / tail planes)
             bias = bias + s_bias
-            scale = None if lift is None else 1.0 / lift
+            scale = None if lift is None else (1.0 / lift).to(bias.device)
             in2 = x2
         else:
             lift = None if stem else self.channel_lift(wk)
             if lift is not None:
-                scale = scale / lift
+                scale = scale / lift.to(scale.device)
         wdev = self.dev(wk, torch.float32) if stem else self.conv_weight(wk, lift)
         self.ops.append(dict(kind=_lib.OP_STEM if stem else _lib.OP_CONV, in_=x, out=out, residual=residual, ksize=k,
                              stride=s, pad=p, relu=int(relu), weight=wdev, in2=in2, weight2=w2dev,

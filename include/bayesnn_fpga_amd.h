@@ -149,7 +149,7 @@ typedef struct bmi_op_desc {
                              O(1) behind BatchNorm and keep the floor.  The reference's fp32 arithmetic to ~1e-6 where plain fp16 is at
                              1e-4..2e-3 (peaky logits of trained / converted nets, Hardware_Artifact/converter/pytorch/nn2bnn.py:32-45 on
                              SA/models/vgg19/vgg19.py:256-324).  |values| < 65504.
-                             Graph support: what the 16-bit engines take EXCEPT bmi_forward_mcd_exit (BMI_ERR_UNSUPPORTED) — in2 (the fused 1x1 shortcut) of any conv geometry with Cin2 % 32 == 0 (extra
+                             Graph support: what the 16-bit engines take, bmi_forward_mcd_exit included (row tables in conv_split) — in2 (the fused 1x1 shortcut) of any conv geometry with Cin2 % 32 == 0 (extra
                              K-steps of the same kernel), pair launches and split-K are taken; channel counts Cin % 32 == 0, Cout % 64 == 0;
                              no lazy first site, no pooled epilogue (the tensors are materialised).                                     */
 #define BMI_DTYPE_BF16X3 4 /* the same on v_mfma_f32_32x32x16_bf16: bf16 head + tail (16 significant bits, fp32's exponent range), three
@@ -238,16 +238,16 @@ const char* bmi_error_string(int code);
  *                                           are pair32 tensors, bmi_conv_igemm_fwd takes the 16-bit head / tail weight planes and runs conv_split
  *   "ws_no_reuse"                           0 | 1, read by bmi_plan: every suffix tensor keeps its own workspace range (per-layer
  *                                           traces through bmi_tensor_info; the workspace grows to the sum of the activations)
- *   "block_fuse"                            0 | 1 | 2, read by bmi_create and at launch: conv1 -> conv2 of a BasicBlock whose 16x16 intermediate map
- *                                           has no other reader run as ONE conv3x3_block launch with the intermediate map kept in LDS (1, default;
- *                                           2: without the minimum-grid rule: tests), or as two launches (0).  The same bits either way
+ *   "head_batch"                            0 | 1: consecutive exit heads of the sample-folded suffix run as ONE launch (1, default) — with exit-only
+ *                                           dropout, the configuration of every run of the paper (journal_script.sh:10-63), the suffix is nothing but
+ *                                           the four / five heads — or one launch per head (0).  The same bits either way
  * Initial values come from the environment (BMI_MFMA_SHAPE, BMI_MFMA_SHAPE_WIDE, BMI_XCD_SPLIT).
  *
  * SCOPE (C-ABI 600).  bmi_set_option edits the PROCESS DEFAULTS: what the single-kernel entry points read, and what bmi_create COPIES into
  * the handle it returns.  An engine runs every later call (bmi_plan, bmi_forward_*) under its own copy, so a live engine never changes
  * kernels because another host thread (see "Threading" at the top) changed a default; bmi_engine_set_option edits the copy
  * of ONE engine (same names and ranges; switches read by bmi_create / bmi_plan take effect at the next bmi_plan at the latest, the
- * graph-merging ones — "conv_seam", "block_fuse" — only at launch time: an op merged at bmi_create falls back to its two launches). */
+ * graph-merging one — "conv_seam" — only at launch time: an op merged at bmi_create falls back to its two launches). */
 int bmi_set_option(const char* name, int32_t value);
 int bmi_engine_set_option(bmi_handle h, const char* name, int32_t value);
 

@@ -184,12 +184,13 @@ def test_headline_size_parity_b250_t100_and_error_versus_T():
 @pytest.mark.gpu
 def test_non_finite_moment_sums_are_an_error_not_a_number():
     """An fp16 activation past 65 504 becomes inf, then NaN in the softmax; ``bmi_finalize_checked`` counts the non-finite sums on the
-    device and the mirrors raise where they read results (FullAnalysis) — on every engine.  Provoked by a stem whose output is 1e6 times
-    too large."""
+    device and the mirrors raise where they read results (FullAnalysis) — on every engine.  Provoked here at the last step of that chain
+    (a NaN in one classifier's bias: every logit sum and softmax of that exit is non-finite), which does not depend on how an overflow
+    happens to travel through ReLUs (``fmaxf(NaN, 0)`` is 0) and masks on the way."""
     from bayesnn_fpga_amd.train.results_analyzer import FullAnalysis
     m = synthetic_weights_(build_seeded(ResNet18MCEarlyExit, KW), 0)
     with torch.no_grad():
-        m.bn1.weight.mul_(1e6)
+        m.ex2linear.bias[3] = float("nan")
     m = m.to(DEV).eval()
     x = synthetic_images(8, seed=5).to(DEV)
     for dt in ("f16", "f16x2"):

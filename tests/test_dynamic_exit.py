@@ -22,12 +22,15 @@ KWS = {
 }
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f16x2", "bf16x3"])
 @pytest.mark.parametrize("name", sorted(KWS))
-def test_device_exit_equals_posthoc_rule_on_the_full_run(name):
+def test_device_exit_equals_posthoc_rule_on_the_full_run(name, dt):
+    """Every engine that runs the path at speed — the 16-bit ones and, round 6, the split engines (conv_split's IMAP instantiations: the
+    engine ``engine_dtype="auto"`` falls back to must not lose the feature) — against the reference's post-hoc rule on ITS OWN full run."""
     B, T, seed = 45, 6, 11
     m = build_seeded(ResNet18MCEarlyExit, KWS[name])
     synthetic_weights_(m, 0)
-    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=B, dtype=dt)
     x = synthetic_images(B, seed=21).to(DEV)
     full = eng.predict(x, T, seed=seed)
     p_full = full["mean"].cpu().numpy()
@@ -93,6 +96,16 @@ def test_device_exit_on_small_batches(B, chunk):
         np.testing.assert_array_equal(r["exit_layer"].cpu().numpy(), want)
         np.testing.assert_allclose(r["best_preds"].cpu().numpy(), p_full[want, np.arange(B)], rtol=0, atol=1e-13)
     assert (cex.exit_layer(p_full.copy(), float(conf[1:3].max()) + 1e-6) == 3).all()     # the first threshold sent nobody out early
+
+
+def test_dynamic_exit_is_refused_by_the_exact_engine_only():
+    """dtype "f32" (the exact engine: parity only) has no row-table form: BMI_ERR_UNSUPPORTED, as include/bayesnn_fpga_amd.h says."""
+    from bayesnn_fpga_amd import _lib
+    m = build_seeded(ResNet18MCEarlyExit, KWS["mc_block_exit"])
+    synthetic_weights_(m, 0)
+    eng = m.to(DEV).eval().engine(torch.device(DEV), max_batch=4, dtype="f32")
+    with pytest.raises(_lib.BmiError):
+        eng.predict_with_exit(synthetic_images(4, seed=1).to(DEV), 3, 0.5)
 
 
 def test_dynamic_exit_needs_all_samples_in_one_chunk():

@@ -338,3 +338,41 @@ def test_lazy_first_site_bf16_engine(arch):
         else:
             assert float((lazy[k] - plain[k]).abs().max()) < 1e-4, k
     assert float(lazy["var"].max()) > 0
+
+
+@pytest.mark.parametrize("arch,T,dt", [("resnet18", 10, "f16"), ("resnet18", 40, "f16"), ("vgg19", 40, "f16"), ("resnet18", 10, "f16x2"), ("resnet18_mask", 8, "f16")])
+def test_batched_exit_heads_are_bit_for_bit_the_single_launches(arch, T, dt):
+    """Exit-only dropout — every run of the paper (Software_Artifact/script_figs/journal_script.sh:10-63; C = 100, T = 10, batch 250) — makes the
+    whole network the once-per-batch prefix and the suffix NOTHING BUT the four (VGG-19: five) heads: they run as ONE launch (grid.z = the
+    head, "head_batch"; csrc/head_fused.hip: head_fused_multi_kernel) instead of four launches of mostly fixed latency.  Same arithmetic per
+    head: moments (one group per image at T = 10; several groups joined in group order at T = 40), per-sample logits and the Masksembles walk
+    equal the one-launch-per-head engine bit for bit; the profile shows ONE head launch."""
+    from bayesnn_fpga_amd.models.vgg19.vgg19 import VGG19MCEarlyExit
+    kw = dict(dropout_exit=True, dropout=None, dropout_p=0.25, out_dim=100)
+    if arch == "resnet18_mask":
+        kw = dict(dropout_exit=True, dropout=None, mask_type="mask", num_masks=4, mask_scale=4.0, out_dim=100)
+    cls = VGG19MCEarlyExit if arch == "vgg19" else ResNet18MCEarlyExit
+    model = synthetic_weights_(build_seeded(cls, kw), 0).to(DEV).eval()
+    x = synthetic_images(B, seed=1234).to(DEV)
+    eng = model.engine(torch.device(DEV), max_batch=B, dtype=dt)
+    n_heads = eng.n_exits
+
+    def run():
+        S = eng.accumulate(x, eng.new_moments(B), 3, T, seed=7, cnt0=1).clone()
+        lg = eng.forward_samples(x, T, seed=7, t_begin=2, cnt0=1, mask_stride=3).clone()
+        eng.profile(True)
+        eng.accumulate(x, eng.new_moments(B), 3, T, seed=7, cnt0=1)
+        torch.cuda.synchronize()
+        eng.profile_read()
+        eng.profile(False)
+        return S, lg, sum(1 for l in eng.profile_launches() if l["kind"] == "head")
+
+    S1, L1, heads1 = run()
+    eng.set_option("head_batch", 0)
+    try:
+        S0, L0, heads0 = run()
+    finally:
+        eng.set_option("head_batch", 1)
+    assert heads1 == 1 and heads0 == n_heads
+    assert torch.equal(S1, S0) and torch.equal(L1, L0)
+    assert float(S1[1].max()) > 0 and bool(torch.isfinite(L1).all())

@@ -116,5 +116,5 @@ def test_macro_batches_carry_k_loader_batches_per_engine_step():
     np.testing.assert_array_equal(f.preds, g.preds)                    # deterministic given (seed, K)
     assert f.preds.shape == e.preds.shape and np.allclose(f.preds.sum(-1), 1.0, atol=1e-6)
     assert not np.array_equal(f.preds[:, :2 * B], e.preds[:, :2 * B])  # other draws ...
-    assert float(np.abs(f.preds - e.preds).max()) < 0.25               # ... of the same distribution
+    assert float(np.abs(f.preds - e.preds).mean()) < 0.05              # ... of the same distribution (T = 6 samples: noisy per element)
     np.testing.assert_array_equal(f.labels, e.labels)

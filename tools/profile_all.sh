@@ -11,7 +11,7 @@ for W in $WL; do
   cp gpurun_out/${TAG}_${W}_kernel_stats.csv gpurun_out/$TAG/${TAG}_${W}_kernel_stats.csv
   # the bench line quotes profiles/hbm_traffic_<W>.json when its launch count matches: refresh it first
   cp gpurun_out/hbm_traffic_$W.json profiles/hbm_traffic_$W.json
-  EXTRA="--no-cpu-baseline"; [ "$W" = resnet18_me ] && EXTRA=""
+  EXTRA="--no-cpu-baseline --no-parity-leg --no-rccl-probe"; [ "$W" = resnet18_me ] && EXTRA=""
   python3 bench.py --workload $W --steps 10 --warmup 3 $EXTRA 2> /dev/null | grep '^{' > gpurun_out/$TAG/${TAG}_${W}_bench_line.json
   rm -rf gpurun_out/${TAG}_${W}_stats gpurun_out/${TAG}_${W}_fetch gpurun_out/${TAG}_${W}_write gpurun_out/${TAG}_${W}_sq
 done

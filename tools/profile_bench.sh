@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd /tmp
 # one batch at a time under the profiler: with two batches in flight (bench.py's default) the kernels of neighbouring batches share
 # the GPU, and a kernel's trace duration / PMC window would include its neighbour's work
-ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-rccl-probe --no-graph --in-flight 1 $BENCH_EXTRA"
+ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-rccl-probe --no-parity-leg --no-graph --in-flight 1 $BENCH_EXTRA"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_write.log 2>&1
