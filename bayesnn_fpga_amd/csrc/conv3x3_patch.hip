@@ -63,9 +63,9 @@ __device__ unsigned int g_zero_page[64];  // 256 B of zeros: DMA source for padd
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),       \
                                      (__attribute__((address_space(3))) void*)(LDSPTR), 16, 0, 0)
 
-template <int TH, int TW, int IMGS, int TJ>
+template <int TH, int TW, int IMGS, int TJ, int BCT = 128>
 struct PatchGeom {
-    static constexpr int BC = 128;
+    static constexpr int BC = BCT;
     static constexpr int BP = IMGS * TH * TW;
     static_assert(BP == 64 * TJ, "pixel tile must be 2 waves x TJ x 32");
     static constexpr int PH = TH + 2, PW = TW + 2;
@@ -85,12 +85,20 @@ struct PatchGeom {
 // 16 x 32 fragment), same LDS layout and swizzle (the 16 lanes of a read group are 16 consecutive rows either way).
 // Which one is faster is a clock question, not a cycle question (MI355X_MICROARCH.md, DVFS give-back item 7): both are
 // built and launch_conv3x3_patch picks by measured wall time (BMI_MFMA_SHAPE overrides).
-template <int TH, int TW, int IMGS, int TJ, int EPI, int MS, bool BF, bool IMAP = false>
+// BCT = 64 (round 6; 16x16x32 MFMAs only): the 64-channel tile for the 64 -> 64 convs on 32x32 maps — the stem's BasicBlocks: once per batch in every
+// ResNet-18 / VGG configuration (four of the 27 launches of the paper's exit-only step), and per SAMPLE behind a "layer" site, where the per-tap
+// conv_igemm took 4.2 + 6.5 ms of a 34 ms step at 447 / 289 TFLOP/s.  All four waves sit on the pixel axis (wave tile 64 channels x 16*TJ pixels),
+// the 8 KB weight stage is read by every wave, and the launch finishes in the per-quad epilogue (conv_epilogue.h: epilogue_quad — every site kind,
+// residual, ReLU; no LDS): same K order per accumulator as the 128-channel tile.  No fused shortcut (a 64-channel block has no downsample path).
+template <int TH, int TW, int IMGS, int TJ, int EPI, int MS, bool BF, bool IMAP = false, int BCT = 128>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
-    using G = PatchGeom<TH, TW, IMGS, TJ>;
+    using G = PatchGeom<TH, TW, IMGS, TJ, BCT>;
+    static_assert(BCT == 128 || (BCT == 64 && MS == 16), "64-channel tiles: the 16x16x32 form");
     constexpr int BC = G::BC, PH = G::PH, PW = G::PW, PWP = G::PWP, KA = G::KA;
+    constexpr int NWP = BCT == 128 ? 2 : 4;       // waves on the pixel axis (x 4 / NWP on the channel axis)
+    constexpr int PPW = G::BP / NWP;              // pixels per wave: 32 TJ | 16 TJ
     constexpr int TI = MS == 32 ? 2 : 4;          // channel tiles per wave
-    constexpr int TP = MS == 32 ? TJ : 2 * TJ;    // pixel tiles per wave
+    constexpr int TP = PPW / MS;                  // pixel tiles per wave
     constexpr int RW = MS;                        // rows (channels / pixels) per MFMA tile
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     char* const patch = smem;
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     const int kq = lane / RW;                     // which 8-element k group of the MFMA's K the lane holds (0..64/RW-1)
     constexpr int KSUB = MS == 32 ? 4 : 2;        // MFMA k-substeps per 64-deep K-step
     constexpr int KQ = 64 / RW;                   // 16-byte chunks of a 128-byte row consumed per substep
-    const int wc = wave >> 1, wp = wave & 1;
+    const int wc = wave / NWP, wp = wave % NWP;
 
     // ---- tile coordinates (channel tile fastest) ------------------------------------------------
     const int n_ctiles = a.Cout / BC;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     }
 #define LOAD_W(KOFF, BUF)                                                                         \
     {                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+        _Pragma("unroll") for (int i = 0; i < BC / 32; ++i)                                       \
             GLDS16(wsrc + (size_t)(32 * i) * Ktot + (KOFF),                                       \
                    wbuf + (BUF) * G::WTILE + (i * 256 + wave * 64) * 16);                         \
     }
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     int bcell[TP], bkey[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-        const int p = wp * (32 * TJ) + RW * j + r;
+        const int p = wp * PPW + RW * j + r;
         const int img = p / (TH * TW), rem = p - img * (TH * TW);
         const int oy = rem / TW, ox = rem - oy * TW;
         bcell[j] = (img * PH + oy) * PWP + ox;   // tap (0,0)
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     // ---- fused 1x1 strided shortcut: extra K-steps on a halo-free "patch" of the block input -----
     // (the downsample conv of BasicBlock: as its own launch it is a K = 64..256 GEMM that costs 10 % of
     // the conv time for 1.2 % of the FLOPs; here it is Cin2/64 more K-steps and no residual traffic)
-    if (a.in2) {
+    if (BCT == 128 && a.in2) {
         const int nch2 = a.Cin2 / 64;
         for (int c2 = 0; c2 < nch2; ++c2) {
             lds_barrier();   // every wave is done with the patch and the weight buffers
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 for (int i = 0; i < TI; ++i) af[i] = *(const half8*)(wbuf + a_off + i * RW * 128 + ((ch ^ a_sw) << 4));
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
-                    const int p = wp * (32 * TJ) + RW * j + r;
+                    const int p = wp * PPW + RW * j + r;
                     const int rem = p % (TH * TW);
                     const int sw = PSW((rem % TW) + KA * (rem / TW));
                     bf[j] = *(const half8*)(patch + p * 128 + ((ch ^ sw) << 4));
@@ -324,7 +332,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         off = ((size_t)n * (a.Ho * a.Wo) + rem) * a.Cout;
         return ok;
     };
-    epilogue_coalesced<TJ, EPI, MS, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
+    if constexpr (BCT == 64) {
+        // per-quad epilogue: lane = pixel (lane & 15) of pixel tile j, its register quad of channel tile i = channels 16 i + 4 (lane >> 4) ..
+        // Arithmetic and order of epilogue_quad.  The common stochastic launch — an elementwise site drawn at 2 bits per element (p = 0.25) —
+        // shares its Philox calls: ONE call masks the 64 channels of a pixel (the whole tile row), lane (pixel, q4) computes the call of
+        // pixel tile j = q4 and the four lanes of a pixel fetch its words with __shfl (epilogue_lite's scheme) instead of sixteen calls per pixel.
+        (void)offmap;
+        static_assert(TP <= 4, "one shared Philox call per lane");
+        const int l16 = lane & 15, q4 = lane >> 4;
+        const bool fast_site = a.site.kind == BMI_SITE_ELEMENTWISE && a.site.log2_bits == 1 && !a.site.drop_all && !a.site_inner;   // launch-uniform
+        philox4 mine = {{0u, 0u, 0u, 0u}};
+        if (fast_site) {
+            int n, rem;
+            pixmap(wp * PPW + 16 * q4 + l16, n, rem);
+            const int tl = n / a.B;
+            mine = philox_site_call(a.site, (uint64_t)((n - tl * a.B) * (a.Ho * a.Wo) + rem) * a.Cout + ch0, (uint32_t)(a.t0 + tl));
+        }
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (fast_site) {
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) w[wd] = (uint32_t)__shfl((int)mine.w[wd], l16 + 16 * j, 64);
+            }
+            int n, rem;
+            if (!pixmap(wp * PPW + 16 * j + l16, n, rem)) continue;
+            const PixelCtx px = make_pixel_ctx(a, n, rem);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const int c4 = ch0 + 16 * i + 4 * q4;
+                if (!fast_site) { epilogue_quad<BF>(a, px, v, c4); continue; }
+                if (a.scale) {
+                    const float4 s4 = *(const float4*)(a.scale + c4);
+                    v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
+                } else if (a.out_mul != 1.f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
+                }
+                if (a.bias) {
+                    const float4 b4 = *(const float4*)(a.bias + c4);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (px.resp) {
+                    const half4 r4 = *(const half4*)(px.resp + c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += a16_to_f32<BF>(r4[e]);
+                }
+                const uint32_t fields = w[i] >> (8 * q4);      // the four 2-bit fields of channels 16 i + 4 q4 ..
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = a.relu ? fmaxf(v[e], 0.f) : v[e];
+                    x = ((fields >> (2 * e)) & 3u) >= a.site.thresh ? x * a.site.scale : 0.f;
+                    o[e] = a16_from_f32<BF>(x);
+                }
+                *(half4*)(a.out + px.out_off + c4) = o;
+            }
+        }
+    } else {
+        epilogue_coalesced<TJ, EPI, MS, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
+    }
     STAMP(3);
 }
 
@@ -383,6 +451,20 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     return BMI_OK;
 }
 
+// 64-channel tiles (Cout % 128 == 64 on 32-wide maps): one instantiation per element type, the per-quad epilogue takes every launch form.
+static int launch_patch64(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    a.xcd_split = 1;
+    const long tiles = (long)a.N * (a.Ho / 8) * (a.Cout / 64);
+    if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
+    if (a.imap || a.in2 || a.in2_bits || a.pool || a.partial) return BMI_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)tiles), block(256);
+    if (a.bf16) hipLaunchKernelGGL((conv3x3_patch_kernel<8, 32, 1, 4, BMI_EPI_GENERAL, 16, true, false, 64>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<8, 32, 1, 4, BMI_EPI_GENERAL, 16, false, false, 64>), grid, block, 0, s, a);
+    BMI_CHECK_LAUNCH();
+    return BMI_OK;
+}
+
 // Shapes the patch kernel takes (kept in sync with launch_conv3x3_patch; the engine uses it to decide
 // which consumers of a site can read keep bits instead of a materialised masked tensor).
 bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, int ho, int wo) {
@@ -394,9 +476,13 @@ bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, 
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s) {
     if (a.in_bits) return BMI_ERR_UNSUPPORTED;   // the patch is filled by DMA: no place to apply keep bits
     if (a.in2 && (!a.wgt2 || a.Cin2 % 64 != 0 || a.in2_mod <= 0 || a.stride2 < 1)) return BMI_ERR_INVALID;
-    if (a.ksize != 3 || a.pad != 1 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % 128 != 0) return BMI_ERR_UNSUPPORTED;
+    if (a.ksize != 3 || a.pad != 1 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % 64 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;
     if ((size_t)a.in_mod * a.H * a.W * a.Cin >= 0x7fffffffull) return BMI_ERR_UNSUPPORTED;   // 31-bit DMA source offsets
+    if (a.Cout % 128 != 0) {      // 64-channel tiles: the 32-wide maps only ("conv_patch64" = 0: conv_igemm as before; A/B, tests)
+        if (!opt_conv_patch64() || a.Ho % 8 != 0 || a.Wo != 32) return BMI_ERR_UNSUPPORTED;
+        return launch_patch64(a, s);
+    }
     if (a.Ho == 16 && a.Wo == 16) return launch_patch<16, 16, 1, 4>(a, s);
     if (a.Ho == 8 && a.Wo == 8) return launch_patch<8, 8, 2, 2>(a, s);
     if (a.Ho == 4 && a.Wo == 4) return launch_patch<4, 4, 8, 2>(a, s);

@@ -223,6 +223,8 @@ static int set_named_option(BmiOptions& o, const char* name, int32_t value) {
         {"lazy_order", &BmiOptions::lazy_order, 0, 1},
         {"epilogue_lite", &BmiOptions::epilogue_lite, 0, 2},
         {"head_batch", &BmiOptions::head_batch, 0, 1},
+        {"conv_patch64", &BmiOptions::conv_patch64, 0, 1},
+        {"splitk_tiles", &BmiOptions::splitk_tiles, 0, 1024},            // read by bmi_plan
     };
     for (const Row& r : rows)
         if (std::strcmp(name, r.name) == 0) {
@@ -727,7 +729,7 @@ int bmi_plan(bmi_handle h, int32_t max_batch, int32_t chunk_samples, size_t* wor
             continue;
         }
         const size_t tiles = (M + 127) / 128 * (op.cout / 128);
-        if (ti.c % 64 != 0 || ti.c < 256 || tiles > 64) continue;      // stride 1 or 2 (VGG-19's 256 -> 512 exit convs: 37 -> 22 us); at
+        if (ti.c % 64 != 0 || ti.c < 256 || tiles > (size_t)opt_splitk_tiles()) continue;      // stride 1 or 2 (VGG-19's 256 -> 512 exit convs: 37 -> 22 us); at
                                                                        // Cin = 128 (18 K-steps) the split measured slower: 23 -> 28 us
         op.nsplit = 9;
         sk_bytes = std::max(sk_bytes, align_up((size_t)op.nsplit * M * op.cout * sizeof(float), 256));

@@ -646,7 +646,7 @@ class BatchesInFlight:
         self.engines = []
 
     @classmethod
-    def tuned(cls, model, device, x, T, seed=0, cnt0=0, threshold_ms=1.0, allow_graph=True, group=None, **engine_kwargs):
+    def tuned(cls, model, device, x, T, seed=0, cnt0=0, threshold_ms=1.5, allow_graph=True, group=None, **engine_kwargs):
         """The pipe a model should run with, decided by MEASUREMENT on its first batch: one engine is built, a batch step (x, T) is
         warmed up and timed with HIP events; a step under ``threshold_ms`` is launch-bound (VGG-11 at batch 250 x T = 30: ~20 launches of
         20-50 us on a ~20 us launch floor, 0.26 ms per step) and gets THREE batches in flight, each step ONE hipGraph replay

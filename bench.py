@@ -45,6 +45,8 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16, MI355X_MICROARCH.md §Chip-level parameters
 HBM_PEAK_GBS = 8000.0           # HBM3E, same table
+LAUNCH_BOUND_MS = 1.5           # a rank's step under this is launch-bound: three batches in flight + one hipGraph replay per step (round 6: measured on the
+                                # exit-only ResNet-18 — probe 1.1 ms, +5.5 % — and VGG-19 — 1.2 ms, +4 % —; neutral at the Masksembles config's 2.2 ms)
 MODEL_KW = dict(dropout_exit=True, dropout="block", dropout_p=0.25, out_dim=10)
 
 # name -> (package class, oracle class, kwargs, batch, T, description).  The default is the configuration BASELINE.json's
@@ -95,8 +97,10 @@ def parse():
     ap.add_argument("--T", type=int, default=0, help="MC samples per image (0 = the workload's)")
     ap.add_argument("--chunk", type=int, default=0, help="MC samples folded per suffix launch (0 = engine default)")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--dtype", choices=("f16", "bf16", "f16x2", "bf16x3"), default="f16",
-                    help="f16 / bf16: 16-bit activations and conv weights (f16 meets the 1e-3 bar and is the default; bf16 is reported next to it); "
+    ap.add_argument("--dtype", choices=("auto", "f16", "bf16", "f16x2", "bf16x3"), default="auto",
+                    help="auto (default): the PRODUCT's choice — engine_dtype='auto' calibrates fp16 against f16x2 on the bench batch and keeps fp16 only under "
+                         "5e-4 (models/_engine_mixin.py); on the synthetic bench weights that is f16, and the line says so (config.engine_dtype).  "
+                         "f16 / bf16: 16-bit activations and conv weights (bf16 is reported next to f16); "
                          "f16x2 / bf16x3: the split engines (fp32 activations, 16-bit head + tail operands, three MFMAs per K-step: csrc/conv_split.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true",
@@ -112,7 +116,7 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: consecutive steps alternate between this many engines / streams (engine.BatchesInFlight), so "
                          "the once-per-batch prefix of step k+1 runs beside the suffix of step k; 1 = one stream; 0 (default) = decided by "
-                         "measurement: a rank's step is timed once before the warm-up — under 1 ms it is launch-bound and gets 3 in flight + "
+                         "measurement: a rank's step is timed once before the warm-up — under 1.5 ms it is launch-bound and gets 3 in flight + "
                          "one hipGraph replay per step (VGG-11, one Masksembles mask per GPU), else 2 eager (the ResNets at T = 100)")
     ap.add_argument("--no-graph", action="store_true", help="never replay a step as a hipGraph (overrides the measured choice)")
     ap.add_argument("--macro", type=int, default=1,
@@ -191,6 +195,25 @@ def rocprof_family(workload, family, launches_per_step):
     if not calls or calls % max(launches_per_step, 1):
         return None
     return max(by_name, key=by_name.get), tot / calls * 1e-6, calls, os.path.relpath(files[-1], ROOT)
+
+
+def rocprof_top_symbol(workload):
+    """The single kernel SYMBOL (template arguments included) with the most device time in the committed rocprofv3 summary of this command —
+    the family view of `roofline` can hide it (round-5 review: by family the headline's dominant kernel is conv3x3_pwp, by symbol the 16x16
+    instantiation of conv3x3_patch).  {name, calls, avg_ms, share_of_kernel_time} or None."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = [(re.sub(r"^void ", "", r["Name"]).split("(")[0], int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(files[-1]))]
+    total = sum(r[2] for r in rows) or 1.0
+    conv = [r for r in rows if r[0].startswith("conv")]
+    if not conv:
+        return None
+    nm, calls, ns = max(conv, key=lambda r: r[2])
+    return {"name": nm, "calls": calls, "avg_ms": round(ns / calls * 1e-6, 4), "share_of_kernel_time": round(ns / total, 4), "source": os.path.relpath(files[-1], ROOT)}
 
 
 def physical_cores():
@@ -350,7 +373,7 @@ def cpu_baseline_multiproc(a, batch, T, procs, threads=16):
 HEAD_NAMES = ("ex1linear", "ex2linear", "ex3linear", "linear")
 
 
-def tolerance_leg(model, dev, x, B, T, seed, steps, gain=24.0):
+def tolerance_leg(model, dev, x, B, T, seed, steps, gain=24.0, rec=None):
     """The rate AT north_star's tolerance (round-5 review, weak #1 / next #1d): what engine_dtype="auto" — the product default — decides on
     the bench model and on its TRAINED-LIKE twin (every classifier x 24: max prob >= 0.99 on most images, where fp16 measures 5e-3 against
     the oracle, tests/test_auto_engine.py), and the whole-step rate of the engine it picks for the twin, timed like the headline (two
@@ -360,7 +383,8 @@ def tolerance_leg(model, dev, x, B, T, seed, steps, gain=24.0):
     import warnings
     from bayesnn_fpga_amd.engine import BatchesInFlight
     out = {}
-    rec = model.calibrate_engine_dtype(dev, x)
+    if rec is None:
+        rec = model.calibrate_engine_dtype(dev, x)
     out["auto_on_bench_model"] = {k: rec[k] for k in ("dtype", "dmean", "dvar", "tol", "images", "samples")}
     if not all(hasattr(model, n) for n in HEAD_NAMES):
         return out
@@ -568,9 +592,16 @@ def main():
     from bayesnn_fpga_amd.sharding import accumulate_share
     if a.in_flight < 0:
         raise SystemExit("--in-flight >= 0")
+    x = synthetic_images(B, seed=1234).to(dev)
+    auto_rec = None
+    if a.dtype == "auto":            # the product default: decided on this batch, outside the timed region, the same on every rank (deterministic)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            auto_rec = model.calibrate_engine_dtype(dev, x)
+        a.dtype = auto_rec["dtype"]
     pipe = BatchesInFlight(model, dev, n=1, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
     eng = pipe.engines[0]
-    x = synthetic_images(B, seed=1234).to(dev)
     pkind = None if a.partition == "auto" else a.partition
     # batches in flight / hipGraph replay: by measurement of THIS rank's share of a step (before the warm-up, outside the timed region);
     # every rank takes the slowest rank's figure, so the group decides together
@@ -596,7 +627,7 @@ def main():
         tprobe = torch.tensor([probe_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tprobe, op=dist.ReduceOp.MAX)
         probe_ms = float(tprobe.item())
-    launch_bound = probe_ms < 1.0
+    launch_bound = probe_ms < LAUNCH_BOUND_MS
     a.in_flight = a.in_flight or (3 if launch_bound else 2)
     a.graph = bool(a.graph or (launch_bound and not a.no_graph))
     pipe.grow(a.in_flight)
@@ -699,11 +730,13 @@ def main():
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": wl[5],
+                       "engine_dtype": (f"auto -> {a.dtype} (fp16 vs f16x2 on the bench batch: mean {auto_rec['dmean']:.1e} / variance {auto_rec['dvar']:.1e}, kept under "
+                                        f"{auto_rec['tol']:.0e})" if auto_rec else a.dtype),
                        "batch": B, "T": T, "chunk_samples": eng.chunk_samples,
                        "workspace_gb": round(eng.workspace_bytes / 2**30, 2), "batches_in_flight": a.in_flight, "hipgraph": bool(a.graph),
                        "macro_batches": a.macro, "rank_step_probe_ms": round(probe_ms, 4), "partition_probe_ms": partition_probe,
-                       "pipe": "3 in flight + one hipGraph replay per step (launch-bound: the probed step is under 1 ms)" if launch_bound
-                               else "2 eager batches in flight (the probed step is over 1 ms)",
+                       "pipe": f"3 in flight + one hipGraph replay per step (launch-bound: the probed step is under {LAUNCH_BOUND_MS} ms)" if launch_bound
+                               else f"2 eager batches in flight (the probed step is over {LAUNCH_BOUND_MS} ms)",
                        "sharding": (f"T over {world} rank(s)" if share[0] == "samples" else f"images over {world} ranks (T <= ranks)") +
                                    ", one float64 all-reduce per batch"},
             "ece_hist_final_exit": round(ece_hist_binary(mean[-1], onehot), 6),
@@ -746,6 +779,7 @@ def main():
                 "avg_launch_ms_rocprof": None if rp is None else round(rp[1], 4), "rocprof_source": None if rp is None else rp[3],
                 "dominant_by": "hip_event_ms (the conv family with the most device time in the profiled step; "
                                                                    "quote whole_step.frac when comparing rounds)",
+                "rocprof_top_symbol": rocprof_top_symbol(a.workload) if rp else None,
                 "achieved": d["hbm_gbs_algorithmic"] if hbm_bound else d["achieved"],
                 "peak": HBM_PEAK_GBS if hbm_bound else d["peak_algorithmic_tflops"], "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": d["hbm_frac"] if hbm_bound else d["frac"],
@@ -790,7 +824,7 @@ def main():
                 f"max_abs_mean_diff_gpu_{other}_vs_cpu": float(np.abs(gpu_other - cpu_mean).max()),
             }
         if world == 1 and not a.no_parity_leg and a.dtype == "f16":
-            line["parity"] = tolerance_leg(model, dev, x, B, T, a.seed, max(3, a.steps // 2))
+            line["parity"] = tolerance_leg(model, dev, x, B, T, a.seed, max(3, a.steps // 2), rec=auto_rec)
             line["parity_engine"] = line["parity"].get("parity_engine")
             line["value_at_tolerance"] = line["parity"].get("value_at_tolerance")
         if world == 1 and not a.no_rccl_probe:       # after everything timed: RCCL executed once on this GPU (SURVEY 8.5, round-4 review item 5)

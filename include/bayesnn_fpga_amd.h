@@ -238,6 +238,11 @@ const char* bmi_error_string(int code);
  *                                           are pair32 tensors, bmi_conv_igemm_fwd takes the 16-bit head / tail weight planes and runs conv_split
  *   "ws_no_reuse"                           0 | 1, read by bmi_plan: every suffix tensor keeps its own workspace range (per-layer
  *                                           traces through bmi_tensor_info; the workspace grows to the sum of the activations)
+ *   "conv_patch64"                          0 | 1: 3x3 stride-1 convs with Cout % 128 == 64 on 32-wide maps (the 64 -> 64 BasicBlocks behind the stem) run in
+ *                                           conv3x3_patch's 64-channel tile (1, default) or in the per-tap conv_igemm (0); another K order (64- vs
+ *                                           32-channel chunks): equal to rounding
+ *   "splitk_tiles"                          0..1024, read by bmi_plan: the largest grid (128 x 128 tiles at the planned batch) of a deterministic 3x3 conv
+ *                                           with Cin >= 256 that still runs split-K (default 64: a quarter of the CUs)
  *   "head_batch"                            0 | 1: consecutive exit heads of the sample-folded suffix run as ONE launch (1, default) — with exit-only
  *                                           dropout, the configuration of every run of the paper (journal_script.sh:10-63), the suffix is nothing but
  *                                           the four / five heads — or one launch per head (0).  The same bits either way

@@ -947,3 +947,46 @@ def test_conv3x3_pw4_equals_conv3x3_pw(cin, cout, H, n, use_res, use_site):
     if site is not None:
         ref = ref * gh.folded_site_mask(site, n, cout, H, H, 1, 1, 3)
     torch.testing.assert_close(outs[4].float().cpu().permute(0, 3, 1, 2), ref, rtol=2e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("kind", ["none", "elementwise", "elementwise_p02", "channel", "masksemble"])
+@pytest.mark.parametrize("bf16", [False, True], ids=["f16", "bf16"])
+def test_patch_kernel_64_channel_tile(kind, bf16):
+    """conv3x3_patch's 64-channel tile (round 6; BCT = 64: the 64 -> 64 BasicBlocks behind the stem on 32x32 maps — per sample behind a "layer"
+    site, once per batch everywhere else) against a torch fp32 reference on the same 16-bit operands: every site kind bit-exact on the mask
+    (the 2-bit elementwise site takes the shared-Philox form: one call per pixel for the tile's 64 channels; p = 0.2 draws 16 bits per element and
+    takes epilogue_quad), residual, broadcast input (n % in_mod), a ragged batch; and close to the per-tap conv_igemm ("conv_patch64" = 0), which
+    sums K in 32-channel chunks."""
+    cin, cout, H, k, s, p = SHAPES["S1"]
+    B, tc, t0, seed, cnt0 = 3, 3, 5, (7 << 32) + 42, 2
+    t16 = torch.bfloat16 if bf16 else torch.float16
+    x, w, scale, bias, g = _conv_inputs(cin, cout, H, k, B, 21, False)
+    res = torch.randn(B * tc, H, H, cout, generator=g)
+    if bf16:
+        x, w = x.float().to(t16), w.float().to(t16)
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    res = res.to(t16).to(DEV)
+    site = None
+    if kind.startswith("elementwise"):
+        site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=4, p=0.2 if kind.endswith("p02") else 0.25)
+    elif kind == "channel":
+        site = dict(kind=_lib.SITE_CHANNEL, site_id=2, p=0.5)
+    elif kind == "masksemble":
+        site = dict(kind=_lib.SITE_MASKSEMBLE, site_id=1, masks=(np.random.RandomState(0).rand(4, cout) < 0.4).astype(np.float32))
+    try:
+        out = {}
+        for arm in (1, 0):
+            _lib.set_option("conv_patch64", arm)
+            out[arm] = gh.run_conv(x, w, scale, bias, res, True, s, p, B * tc, B, B * tc, site=site, batch=B, t0=t0, seed=seed, cnt0=cnt0,
+                                   out_dtype=t16).float().cpu().permute(0, 3, 1, 2)
+    finally:
+        _lib.set_option("conv_patch64", 1)
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+    ref = gh.conv_ref(x, w, scale, bias, res, True, s, p, B * tc, B, B * tc)
+    mult = gh.folded_site_mask(site, B, cout, H, H, tc, t0, seed, cnt0) if site is not None else torch.ones_like(ref)
+    tol = 2e-2 if bf16 else 2e-3
+    assert torch.isfinite(out[1]).all()
+    torch.testing.assert_close(out[1], ref * mult, rtol=tol, atol=tol)
+    torch.testing.assert_close(out[1], out[0], rtol=tol, atol=tol)
+    if site is not None:
+        assert torch.equal(out[1][mult == 0], torch.zeros_like(out[1][mult == 0])) and (mult == 0).any() and (mult != 0).any()

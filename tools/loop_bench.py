@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--evaluate", type=int, default=0,
                     help="N > 0: time the reference's MCD use #1 instead — train.evaluate (SA/train/evaluate.py:8-22): N OUTER passes over the "
                          "loader, every model(X) ONE stochastic pass, the multi-exit accuracy vector per batch")
+    ap.add_argument("--macro", type=int, default=1, help="FullAnalysis(macro_batches=K): K loader batches per engine step")
     a = ap.parse_args()
     wl = bench.WORKLOADS[a.workload]
     dev = torch.device("cuda", 0)
@@ -83,7 +84,7 @@ def main():
                                          pin_memory=bool(a.pin))
     if a.evaluate > 0:
         return evaluate_route(a, wl, model, loader)
-    fa = FullAnalysis(model, None, gpu=0, mc_dropout=True, mc_passes=T, seed=42)
+    fa = FullAnalysis(model, None, gpu=0, mc_dropout=True, mc_passes=T, seed=42, macro_batches=a.macro)
     fa.loader = loader
     fa.sdn_get_detailed_results()                                                # warm-up: engines built, kernels loaded
     torch.cuda.synchronize()
@@ -112,7 +113,8 @@ def main():
     tl, td = sorted(loop)[len(loop) // 2], sorted(devonly)[len(devonly) // 2]
     print(json.dumps({
         "what": "FullAnalysis loader walk (host loader -> H2D -> T passes -> host collation) vs the same batches device-resident",
-        "workload": wl[5], "images": a.images, "batch": a.batch, "T": T, "pinned_host_batches": bool(a.pin),
+        "workload": wl[5], "images": a.images, "batch": a.batch, "T": T, "pinned_host_batches": bool(a.pin), "macro_batches": a.macro,
+        "pipe": {"in_flight": len(fa._pipe.engines), "hipgraph": bool(fa._pipe.use_graph), "engine_dtype": fa._pipe.engines[0].dtype},
         "loop_s": round(tl, 4), "loop_mcd_samples_per_s": round(n / tl, 1),
         "device_only_s": round(td, 4), "device_only_mcd_samples_per_s": round(n / td, 1),
         "loop_overhead_pct": round(100.0 * (tl - td) / td, 2),
