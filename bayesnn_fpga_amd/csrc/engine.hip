@@ -225,6 +225,7 @@ static int set_named_option(BmiOptions& o, const char* name, int32_t value) {
         {"head_batch", &BmiOptions::head_batch, 0, 1},
         {"conv_patch64", &BmiOptions::conv_patch64, 0, 1},
         {"splitk_tiles", &BmiOptions::splitk_tiles, 0, 1024},            // read by bmi_plan
+        {"pair_prefix", &BmiOptions::pair_prefix, 0, 1},                  // read by bmi_create
     };
     for (const Row& r : rows)
         if (std::strcmp(name, r.name) == 0) {
@@ -504,25 +505,31 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
             return c.d.kind == BMI_OP_CONV && !c.has_pair && c.d.residual < 0 && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE &&
                    c.bits_tensor < 0 && c.out_mul == 1.f && c.d.scale && c.d.bias;
         };
-        for (size_t i = 0; enable && i < e->suffix.size(); ++i) {
-            if (!plain(e->suffix[i])) continue;
-            const OpInfo A = e->suffix[i];
-            const TensorInfo& ti = e->tensors[A.d.in];
-            if (conv_takes_patch_kernel(A.d.ksize, A.d.stride, A.d.pad, ti.c, A.cout, A.ho, A.wo)) continue;
-            for (size_t j = i + 1; j < e->suffix.size(); ++j) {
-                const OpInfo& Bo = e->suffix[j];
-                if (!plain(Bo) || Bo.d.in != A.d.in || Bo.d.ksize != A.d.ksize || Bo.d.stride != A.d.stride ||
-                    Bo.d.pad != A.d.pad || Bo.d.relu != A.d.relu)
-                    continue;
-                if (A.cout % 128 != 0 || !conv_takes_wide_kernel(ti.c, A.cout + Bo.cout)) continue;
-                if (e->split && Bo.cout % 128 != 0) continue;
-                e->suffix[i].has_pair = true;
-                e->suffix[i].pair_d = Bo.d;
-                e->suffix[i].pair_cout = Bo.cout;
-                e->suffix.erase(e->suffix.begin() + (long)j);
-                break;
+        auto merge = [&](std::vector<OpInfo>& ops) {
+            for (size_t i = 0; i < ops.size(); ++i) {
+                if (!plain(ops[i])) continue;
+                const OpInfo A = ops[i];
+                const TensorInfo& ti = e->tensors[A.d.in];
+                if (conv_takes_patch_kernel(A.d.ksize, A.d.stride, A.d.pad, ti.c, A.cout, A.ho, A.wo)) continue;
+                for (size_t j = i + 1; j < ops.size(); ++j) {
+                    const OpInfo& Bo = ops[j];
+                    if (!plain(Bo) || Bo.d.in != A.d.in || Bo.d.ksize != A.d.ksize || Bo.d.stride != A.d.stride ||
+                        Bo.d.pad != A.d.pad || Bo.d.relu != A.d.relu)
+                        continue;
+                    if (A.cout % 128 != 0 || !conv_takes_wide_kernel(ti.c, A.cout + Bo.cout)) continue;
+                    if (e->split && Bo.cout % 128 != 0) continue;
+                    ops[i].has_pair = true;
+                    ops[i].pair_d = Bo.d;
+                    ops[i].pair_cout = Bo.cout;
+                    ops.erase(ops.begin() + (long)j);
+                    break;
+                }
             }
-        }
+        };
+        if (enable) merge(e->suffix);
+        // "pair_prefix" (round 6, default 0): the same for the once-per-batch prefix — with exit-only dropout the whole network is prefix and the
+        // pairs are there.  Measured on 250-image launches before it was made a default (profiles/experiments/r6_exit_only_variants.txt).
+        if (enable && opt_pair_prefix() && !e->f32) merge(e->prefix);
     }
     // Seam fusion (Bottleneck nets): conv3 + BN + residual + ReLU of block k followed at once by conv1 + BN + ReLU of block k+1 on its output:
     // one conv1x1_seam launch produces both tensors and the wide one is not read back (conv1x1_seam.hip).  Decided per launch in run_op.

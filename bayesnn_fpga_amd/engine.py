@@ -662,13 +662,13 @@ class BatchesInFlight:
             # a rank's SHARE of the step is what it will run; the group takes the slowest rank's figure so that every rank builds the same pipe
             import torch.distributed as dist
             S = pipe.engines[0].new_moments(x.shape[0])
-            ms = pipe.measure_ms(lambda e: accumulate_share(e, x, S.zero_(), T, seed, cnt0, rank, world))
+            ms = pipe.measure_ms(lambda e: accumulate_share(e, x, S.zero_(), T, seed, cnt0, rank, world), warm=1, reps=2)
             on_dev = dist.get_backend(group) == "nccl"
             t = torch.tensor([ms], dtype=torch.float64, device=pipe.device if on_dev else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             ms = float(t.item())
         else:
-            ms = pipe.measure_ms(lambda e: e.predict(x, T, seed, cnt0=cnt0))
+            ms = pipe.measure_ms(lambda e: e.predict(x, T, seed, cnt0=cnt0), warm=1, reps=2)
         pipe.step_ms_measured = ms
         launch_bound = ms < threshold_ms
         pipe.grow(3 if launch_bound else 2)

@@ -10,7 +10,9 @@ from ..utils import Masksembles1D, Masksembles2D
 # tests/test_split_engine.py) to AUTO_TOL on the calibration batch.  north_star asks for 1e-3 on mean and variance; half of it is left for
 # what one batch x AUTO_SAMPLES samples cannot see (other batches of the loader: measured spread in tests/test_auto_engine.py).
 AUTO_TOL = 5e-4
-AUTO_SAMPLES = 4          # Monte-Carlo samples of the calibration pass (the error FALLS slowly with T: conservative for T = 10 .. 100)
+AUTO_SAMPLES = 8          # Monte-Carlo samples of the calibration pass: close to the reference's T = 10 (mc_dropout_passes) — fp16's error against the oracle
+                          # at B = 250 is 3.1e-4 / 2.4e-4 / 1.7e-4 at T = 4 / 10 / 100 on near-uniform predictions and 3.9e-3 / 1.9e-3 / 5.6e-4 on peaky
+                          # ones (profiles/r06_parity_b250_t100.log): at 8 samples both sit a factor of two or more away from AUTO_TOL
 AUTO_IMAGES = 256         # at most this many images of the first batch
 AUTO_CANDIDATES = ("f16", "f16x2")      # (fast, safe); a model may set ``auto_candidates = ("bf16", "bf16x3")`` for the bf16 pipe
 
@@ -23,7 +25,7 @@ class EngineModelMixin:
     def _init_engine_state(self):
         self.mc_seed = 0      # Philox key of the Monte-Carlo stream (csrc/philox.h)
         self.mc_pass = 0      # global sample index t of the next forward
-        self._engines, self._eval_pipes, self._auto = {}, {}, {}
+        self._engines, self._eval_pipes, self._auto, self._fa_pipes = {}, {}, {}, {}
 
     def _drop_engines(self):
         """Compiled weights are stale (or must not be pickled): close what holds device memory, forget the auto choice."""
@@ -33,12 +35,12 @@ class EngineModelMixin:
                 eng.workspace = None
             except Exception:       # noqa: BLE001
                 pass
-        for pipe in list(getattr(self, "_eval_pipes", {}).values()):
+        for pipe in list(getattr(self, "_eval_pipes", {}).values()) + list(getattr(self, "_fa_pipes", {}).values()):
             try:
                 pipe.close()
             except Exception:       # noqa: BLE001
                 pass
-        self._engines, self._eval_pipes, self._auto = {}, {}, {}
+        self._engines, self._eval_pipes, self._auto, self._fa_pipes = {}, {}, {}, {}
 
     def _apply(self, fn, *a, **k):
         self._drop_engines()          # parameters moved / cast: compiled weights are stale
@@ -61,6 +63,7 @@ class EngineModelMixin:
         state["_engines"] = {}
         state["_eval_pipes"] = {}          # (train/evaluate.py: the folded evaluation's two engines in flight)
         state["_auto"] = {}
+        state["_fa_pipes"] = {}            # (train/results_analyzer.py: FullAnalysis' engines in flight)
         return state
 
     # ---- engine_dtype = "auto" -----------------------------------------------------------------------------------------------

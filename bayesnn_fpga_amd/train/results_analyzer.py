@@ -129,25 +129,35 @@ class FullAnalysis:
     def _make_pipe(self, b_x, max_batch):
         """The engines / streams of the batch loop, with the model's engine settings (``model.engine_dtype`` — "auto" is decided here, on the
         first batch —, an explicit chunk size of its cached engine) like ``model.engine()`` would build them.  How many batches are in flight,
-        and whether a step is one hipGraph replay, is decided by MEASUREMENT of the first step (``BatchesInFlight.tuned``: under 1 ms = launch
+        and whether a step is one hipGraph replay, is decided by MEASUREMENT of the first step (``BatchesInFlight.tuned``: under 1.5 ms = launch
         bound -> three in flight; a replay only when the launch scalars repeat from batch to batch — Masksembles-only models, whose kernels
-        never see the seed and whose counter takes at most M values)."""
+        never see the seed and whose counter takes at most M values).
+        The pipe lives ON THE MODEL (``model._fa_pipes``, like its compiled engines): the walks of one analysis — test loader, validation
+        loader (SA/main.py:95-98) — and of later analyses of the same weights share it instead of paying engine builds, workspace
+        allocations and the timing probe again (round 6: 0.15-0.2 s per walk, six times the GPU time of an exit-only walk);
+        ``model.invalidate_engine()`` / ``.to()`` / ``load_state_dict`` drop it — after in-place weight updates call ``invalidate_engine()``."""
         from ..engine import BatchesInFlight
         device = b_x.device
-        old = getattr(self, "_pipe", None)
-        if old is not None:
-            old.close()              # (synchronises first: a batch may still be queued on the engines that are about to be destroyed)
         dtype = self.model.resolve_engine_dtype(device, None, calib=b_x)
+        rank, world = self._ranks()
+        pipes = self.model.__dict__.setdefault("_fa_pipes", {})
+        key = (str(device), dtype, rank, world, self.mc_passes)
+        pipe = pipes.get(key)
+        if pipe is not None and pipe.engines and pipe.engines[0].max_batch == max_batch:
+            self._pipe = pipe
+            return pipe
+        if pipe is not None:
+            pipe.close()             # (synchronises first: a batch may still be queued on the engines that are about to be destroyed)
         cached = getattr(self.model, "_engines", {}).get(f"{device}/{dtype}")
         chunk = cached.chunk_samples if cached is not None and cached.chunk_explicit else None
-        rank, world = self._ranks()
         xs = b_x if b_x.shape[0] == max_batch else b_x.new_zeros((max_batch,) + tuple(b_x.shape[1:]))
         ml = self.model.mask_layers()
-        self._pipe = BatchesInFlight.tuned(self.model, device, xs, self.mc_passes, seed=self.seed, cnt0=ml[0].cnt if ml else 0,
-                                           allow_graph=True, group=(getattr(self, "group", None) or _default_group()) if world > 1 else None,
-                                           max_batch=max_batch, dtype=dtype, chunk_samples=chunk)
-        self._pipe.use_graph = self._pipe.use_graph and not self._pipe.engines[0].seed_matters
-        return self._pipe
+        pipe = BatchesInFlight.tuned(self.model, device, xs, self.mc_passes, seed=self.seed, cnt0=ml[0].cnt if ml else 0,
+                                     allow_graph=True, group=(getattr(self, "group", None) or _default_group()) if world > 1 else None,
+                                     max_batch=max_batch, dtype=dtype, chunk_samples=chunk)
+        pipe.use_graph = pipe.use_graph and not pipe.engines[0].seed_matters
+        pipes[key] = self._pipe = pipe
+        return pipe
 
     def _predict_async(self, b_x, n_batches=1):
         """The same call queued on one of the engines / streams of the pipe (engine.BatchesInFlight): returns the DEVICE tensors; the caller
@@ -242,8 +252,8 @@ class FullAnalysis:
         y_all = np.empty(n, dtype=np.int64)
         off = 0
         if getattr(self, "_pipe", None) is not None:
-            self._pipe.close()
-        self._pipe = None            # engines snapshot the weights when they are built: a fresh set per collection run
+            self._pipe.synchronize()
+        self._pipe = None            # (found again — or rebuilt — by _make_pipe on the first batch: the pipe belongs to the model)
         self._cur_loader = loader
 
         K = self._macro_k()

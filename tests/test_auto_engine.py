@@ -53,7 +53,7 @@ def test_auto_is_the_default_everywhere():
 
 @pytest.mark.gpu
 def test_auto_keeps_fp16_on_the_synthetic_model_and_rejects_it_on_the_peaky_one():
-    """The calibration (first batch, 4 samples, fp16 vs f16x2 on the same masks) keeps fp16 where it agrees with the split engine to AUTO_TOL
+    """The calibration (first batch, 8 samples, fp16 vs f16x2 on the same masks) keeps fp16 where it agrees with the split engine to AUTO_TOL
     and switches — saying so once — where it does not: the stress model of tests/test_split_engine.py (fp16 5.0e-3 against the oracle)."""
     from oracle import mcd
     from oracle import resnet18 as oresnet
