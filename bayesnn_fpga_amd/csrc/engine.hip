@@ -505,11 +505,14 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
             return c.d.kind == BMI_OP_CONV && !c.has_pair && c.d.residual < 0 && c.d.in2 < 0 && c.d.site.kind == BMI_SITE_NONE &&
                    c.bits_tensor < 0 && c.out_mul == 1.f && c.d.scale && c.d.bias;
         };
-        auto merge = [&](std::vector<OpInfo>& ops) {
+        auto merge = [&](std::vector<OpInfo>& ops, bool prefix) {
             for (size_t i = 0; i < ops.size(); ++i) {
                 if (!plain(ops[i])) continue;
                 const OpInfo A = ops[i];
                 const TensorInfo& ti = e->tensors[A.d.in];
+                // (prefix: a conv with 256+ input channels may get a split-K launch from bmi_plan on a small batch — VGG's exit convs, 37 -> 22 us —
+                //  which a pair launch does not have: those stay single.  Measured: VGG-11 on f16x2 15.0 -> 14.4 M with every prefix pair merged)
+                if (prefix && ti.c >= 256) continue;
                 if (conv_takes_patch_kernel(A.d.ksize, A.d.stride, A.d.pad, ti.c, A.cout, A.ho, A.wo)) continue;
                 for (size_t j = i + 1; j < ops.size(); ++j) {
                     const OpInfo& Bo = ops[j];
@@ -526,10 +529,10 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
                 }
             }
         };
-        if (enable) merge(e->suffix);
-        // "pair_prefix" (round 6, default 0): the same for the once-per-batch prefix — with exit-only dropout the whole network is prefix and the
-        // pairs are there.  Measured on 250-image launches before it was made a default (profiles/experiments/r6_exit_only_variants.txt).
-        if (enable && opt_pair_prefix() && !e->f32) merge(e->prefix);
+        if (enable) merge(e->suffix, false);
+        // "pair_prefix" (round 6): the same for the once-per-batch prefix — with exit-only dropout the whole network is prefix and the pairs are
+        // there: the paper's configuration 3.60-3.63 M -> 3.70-3.77 M MCD-samples/s, same box (profiles/experiments/r6_exit_only_variants.txt).
+        if (enable && opt_pair_prefix() && !e->f32) merge(e->prefix, true);
     }
     // Seam fusion (Bottleneck nets): conv3 + BN + residual + ReLU of block k followed at once by conv1 + BN + ReLU of block k+1 on its output:
     // one conv1x1_seam launch produces both tensors and the wide one is not read back (conv1x1_seam.hip).  Decided per launch in run_op.

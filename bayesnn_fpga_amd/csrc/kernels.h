@@ -189,7 +189,7 @@ struct BmiOptions {
     int ws_no_reuse = 0;         // bmi_plan: every suffix tensor keeps its own workspace range (per-layer traces)
     int conv_patch64 = 1;        // 1: 64 -> 64-class 3x3 stride-1 convs on 32-wide maps run in conv3x3_patch's 64-channel tile, 0: conv_igemm
     int splitk_tiles = 64;       // bmi_plan: a deterministic 3x3 conv (Cin >= 256, no residual / shortcut / site) of at most this many 128 x 128 tiles runs split-K
-    int pair_prefix = 0;         // bmi_create: pair fusion (two plain convs on one input in one launch) in the once-per-batch prefix too
+    int pair_prefix = 1;         // bmi_create: pair fusion (two plain convs on one input in one launch) in the once-per-batch prefix too (0: suffix only)
     int head_batch = 1;          // 1: consecutive exit heads of the suffix (exit-only dropout: the suffix is nothing but the heads) run as ONE launch, 0: one launch per head
 };
 BmiOptions& bmi_default_options();                 // the process defaults (engine.hip)

@@ -236,7 +236,10 @@ class FullAnalysis:
         confidence.update(zip(ids.tolist(), conf.tolist()))
 
     def _collect(self, loader):
-        n_exits, C = self.model.n_exits if self.model.n_exits > 1 else len(self._probe_exits()), self.model.out_dim
+        # exits = what the model's forward RETURNS (engine.model_exits), not its ``n_exits`` attribute: a VGG19MCEarlyExit built with the
+        # constructor's default n_exits = 4 still returns five logits tensors (the reference sizes by the attribute, :133-137, and silently
+        # drops the fifth; its own entry point passes n_exits = 5 for VGG, SA/train/hyperparameters.py:94-98)
+        n_exits, C = len(self._probe_exits()), self.model.out_dim
         # rows = what the loader actually yields: a SubsetRandomSampler validation loader (SA/datasets/dataset_loader.py:
         # 156-164) walks a subset of its dataset; the reference sizes by len(val_loader.sampler.indices) (:179-215)
         if getattr(loader, "sampler", None) is not None and hasattr(loader.sampler, "__len__"):
@@ -259,18 +262,18 @@ class FullAnalysis:
         K = self._macro_k()
 
         def steps(it):
-            """(index of the first loader batch, images, labels, loader batches carried) of each ENGINE step: K consecutive loader batches of
-            one size concatenated (``macro_batches``), a smaller last batch — or a change of size — on its own."""
+            """(index of the first loader batch, [images per loader batch], labels, loader batches carried) of each ENGINE step: K consecutive
+            loader batches of one size (``macro_batches``), a smaller last batch — or a change of size — on its own."""
             hold, first = [], 0
             for idx, batch in enumerate(it):
                 if hold and (len(hold) == K or batch[0].shape[0] != hold[0][0].shape[0]):
-                    yield first, torch.cat([h[0] for h in hold]) if len(hold) > 1 else hold[0][0], torch.cat([h[1] for h in hold]), len(hold)
+                    yield first, [h[0] for h in hold], torch.cat([h[1] for h in hold]), len(hold)
                     hold = []
                 if not hold:
                     first = idx
                 hold.append(batch)
             if hold:
-                yield first, torch.cat([h[0] for h in hold]) if len(hold) > 1 else hold[0][0], torch.cat([h[1] for h in hold]), len(hold)
+                yield first, [h[0] for h in hold], torch.cat([h[1] for h in hold]), len(hold)
 
         def queued(it):
             """(result getter, labels) of each engine step, as many steps behind the one being queued as the pipe has OTHER engines (two in
@@ -278,8 +281,10 @@ class FullAnalysis:
             from collections import deque
             pending = deque()
             for self._batch_index, xs, ys, nb in steps(it):
-                b_x = xs.to(self.device, non_blocking=True)           # asynchronous from a pinned loader batch; ordered before the
-                                                                      # batch's launches by submit()'s wait on this stream
+                # host -> device per LOADER batch (asynchronous from a pinned one; ordered before the step's launches by submit()'s wait on this
+                # stream), a macro group joined ON THE DEVICE: a host-side torch.cat of K batches page-faults a fresh 3 K MB buffer per step
+                # (12 ms per 1000-image group on the GPU box's host: the walk ran slower with K = 4 than with K = 1)
+                b_x = (torch.cat([x.to(self.device, non_blocking=True) for x in xs]) if len(xs) > 1 else xs[0].to(self.device, non_blocking=True))
                 pending.append((self._predict_deferred(b_x, nb), ys.cpu().numpy().astype(np.int64)))
                 pipe = getattr(self, "_pipe", None)
                 depth = max(1, len(pipe.engines) - 1) if pipe is not None and pipe.engines else 1

@@ -244,7 +244,7 @@ const char* bmi_error_string(int code);
  *   "splitk_tiles"                          0..1024, read by bmi_plan: the largest grid (128 x 128 tiles at the planned batch) of a deterministic 3x3 conv
  *                                           with Cin >= 256 that still runs split-K (default 64: a quarter of the CUs)
  *   "pair_prefix"                           0 | 1, read by bmi_create: pair fusion (two plain convs on one input as one launch) also in the once-per-batch
- *                                           prefix (default 0: on 250-image launches the halved grids measured no faster)
+ *                                           prefix (1, default: the exit-only step +3 %, profiles/experiments/r6_exit_only_variants.txt) or in the suffix only (0)
  *   "head_batch"                            0 | 1: consecutive exit heads of the sample-folded suffix run as ONE launch (1, default) — with exit-only
  *                                           dropout, the configuration of every run of the paper (journal_script.sh:10-63), the suffix is nothing but
  *                                           the four / five heads — or one launch per head (0).  The same bits either way

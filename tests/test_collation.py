@@ -428,3 +428,51 @@ def test_gpu_folded_evaluate_single_batch_loader_after_a_forward():
     folded = eng.forward_samples(xd, T, seed=m.mc_seed, t_begin=m.mc_pass, cnt0=m.mask_layers()[0].cnt, mask_stride=1)
     calls = torch.stack([torch.stack(m(xd)) for _ in range(T)])
     assert torch.equal(folded, calls)
+
+
+def test_macro_batches_group_loader_batches_and_keep_loader_order():
+    """``FullAnalysis(..., macro_batches=K)`` on the HOST side (no GPU: the per-batch predictor is injected, so the walk takes the synchronous
+    route, which serves a macro group loader batch by loader batch under each batch's own index): K consecutive loader batches of one size
+    form an engine step, a smaller last batch — or a change of size — goes alone, the outputs come back in loader order and the trackers
+    built once at the end of the walk hold the entries the per-batch walk would have inserted, in the same order."""
+    rng = np.random.RandomState(3)
+    E, C, sizes = 4, 10, [4, 4, 4, 4, 4, 3]
+    xs = [torch.full((b, 3, 32, 32), float(i)) for i, b in enumerate(sizes)]
+    ys = [torch.from_numpy(rng.randint(0, C, size=b)) for b in sizes]
+    loader = list(zip(xs, ys))
+    seen = []
+
+    class FA(FullAnalysis):
+        def _predict(self, b_x):
+            k = int(b_x[0, 0, 0, 0])                       # which loader batch this is
+            seen.append((k, self._batch_index, int(b_x.shape[0])))
+            r = np.random.RandomState(100 + k)
+            p = r.dirichlet(np.ones(C), size=(E, b_x.shape[0]))
+            return dict(mean=p, var=p * 0.01, logit_mean=np.log(p))
+
+    class M(_M):
+        def eval(self):
+            return self
+
+        def mask_layers(self):
+            return []
+    out = {}
+    for K in (1, 3):
+        seen.clear()
+        fa = FA(M(), loader, gpu=-1, mc_dropout=True, mc_passes=5, macro_batches=K)
+        assert [s[0] for s in seen] == list(range(len(sizes))) and [s[1] for s in seen] == list(range(len(sizes)))    # each batch under its own index
+        assert [s[2] for s in seen] == sizes
+        out[K] = fa
+    a, b = out[1], out[3]
+    np.testing.assert_array_equal(a.preds, b.preds)
+    np.testing.assert_array_equal(a.labels, b.labels)
+    assert a.layer_correct == b.layer_correct and a.ensemble_layer_wrong == b.ensemble_layer_wrong
+    assert list(a.layer_predictions[2].items()) == list(b.layer_predictions[2].items())      # dict insertion order = instance order
+    assert list(a.layer_predictions[0].keys()) == list(range(sum(sizes)))
+    # the step grouping itself
+    fa = FA(M(), None, gpu=-1, mc_dropout=True, mc_passes=5, macro_batches=3)
+    assert fa._macro_k() == 3
+    masked = M()
+    masked.mask_layers = lambda: [type("L", (), {"n": 4, "cnt": 0})()]
+    assert FA(masked, None, gpu=-1, mc_dropout=True, mc_passes=5, macro_batches=3)._macro_k() == 1      # T % M != 0: one loader batch per step
+    assert FA(masked, None, gpu=-1, mc_dropout=True, mc_passes=8, macro_batches=3)._macro_k() == 3

@@ -100,3 +100,20 @@ def test_gpu_vgg_single_exit():
     x = synthetic_images(int(g["B"]), seed=1234).to("cuda:0")
     passes = np.stack([np.stack([o.cpu().numpy() for o in m(x)]) for _ in range(int(g["T"]))])
     np.testing.assert_allclose(passes, g["logits"], rtol=0, atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_gpu_full_analysis_collates_every_exit_the_vgg_returns():
+    """``VGG19MCEarlyExit`` built with the constructor's default ``n_exits`` (4) still returns FIVE logits tensors (SA/models/vgg19/vgg19.py:327-382; the
+    reference's entry point passes n_exits = 5 for VGG, SA/train/hyperparameters.py:94-98): the FullAnalysis mirror sizes by what the forward returns
+    — round 6: `tools/loop_bench.py --workload vgg19_me` crashed on a [4, ...] array for five exits."""
+    from bayesnn_fpga_amd.synthetic import synthetic_labels
+    from bayesnn_fpga_amd.train.results_analyzer import FullAnalysis
+    m = synthetic_weights_(build_seeded(bvgg.VGG19MCEarlyExit, dict(dropout_exit=True, dropout=None, dropout_p=0.25, out_dim=10)), 0).to("cuda:0").eval()
+    x, y = synthetic_images(24, seed=3), synthetic_labels(24, 10, seed=4)
+    loader = [(x[:12], y[:12]), (x[12:], y[12:])]
+    fa = FullAnalysis(m, loader, gpu=0, mc_dropout=True, mc_passes=4, ece="hist")
+    assert fa.preds.shape == (5, 24, 10) and fa.ensemble_preds.shape == (5, 24, 10)
+    assert np.allclose(fa.preds.sum(-1), 1.0, atol=1e-6) and sorted(fa.layer_correct) == [0, 1, 2, 3, 4]
+    rows = fa.all_experiments("v", write=False)
+    assert [r[0] for r in rows] == ["0", "1", "2", "3", "4"] + [f"Ensemble{i}" for i in range(5)]
