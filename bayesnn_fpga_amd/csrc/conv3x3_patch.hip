@@ -341,6 +341,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         static_assert(TP <= 4, "one shared Philox call per lane");
         const int l16 = lane & 15, q4 = lane >> 4;
         const bool fast_site = a.site.kind == BMI_SITE_ELEMENTWISE && a.site.log2_bits == 1 && !a.site.drop_all && !a.site_inner;   // launch-uniform
+        // launch-uniform: the register form below (BN vectors loaded once per lane, ALL residual quads of the lane requested before the first
+        // is used — 16 eight-byte loads in flight instead of one exposed round trip per quad —, then arithmetic and stores) takes the launches
+        // without a site and with the 2-bit elementwise site; every other site kind goes quad by quad through epilogue_quad.
+        const bool regs_form = !a.site_inner && (a.site.kind == BMI_SITE_NONE || fast_site);
         philox4 mine = {{0u, 0u, 0u, 0u}};
         if (fast_site) {
             int n, rem;
@@ -348,46 +352,69 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
             const int tl = n / a.B;
             mine = philox_site_call(a.site, (uint64_t)((n - tl * a.B) * (a.Ho * a.Wo) + rem) * a.Cout + ch0, (uint32_t)(a.t0 + tl));
         }
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (fast_site) {
-#pragma unroll
-                for (int wd = 0; wd < 4; ++wd) w[wd] = (uint32_t)__shfl((int)mine.w[wd], l16 + 16 * j, 64);
-            }
-            int n, rem;
-            if (!pixmap(wp * PPW + 16 * j + l16, n, rem)) continue;
-            const PixelCtx px = make_pixel_ctx(a, n, rem);
+        if (regs_form) {
+            f32x4_e sc[TI], bi[TI];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const int c4 = ch0 + 16 * i + 4 * q4;
-                if (!fast_site) { epilogue_quad<BF>(a, px, v, c4); continue; }
-                if (a.scale) {
-                    const float4 s4 = *(const float4*)(a.scale + c4);
-                    v[0] *= s4.x * a.out_mul; v[1] *= s4.y * a.out_mul; v[2] *= s4.z * a.out_mul; v[3] *= s4.w * a.out_mul;
-                } else if (a.out_mul != 1.f) {
+                sc[i] = f32x4_e{1.f, 1.f, 1.f, 1.f};
+                bi[i] = f32x4_e{0.f, 0.f, 0.f, 0.f};
+                if (a.scale) sc[i] = *(const f32x4_e*)(a.scale + c4);
+                if (a.bias) bi[i] = *(const f32x4_e*)(a.bias + c4);
+            }
+            bool okp[TP];
+            size_t ooff[TP];
+            half4 rq[TP][TI];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= a.out_mul;
-                }
-                if (a.bias) {
-                    const float4 b4 = *(const float4*)(a.bias + c4);
-                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                }
-                if (px.resp) {
-                    const half4 r4 = *(const half4*)(px.resp + c4);
+            for (int j = 0; j < TP; ++j) {
+                int n, rem;
+                okp[j] = pixmap(wp * PPW + 16 * j + l16, n, rem);
+                ooff[j] = ((size_t)n * (a.Ho * a.Wo) + rem) * a.Cout;
+                const size_t roff = a.res ? ((size_t)(n % a.res_mod) * (a.Ho * a.Wo) + rem) * a.Cout : 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += a16_to_f32<BF>(r4[e]);
+                for (int i = 0; i < TI; ++i) {
+                    rq[j][i] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    if (a.res && okp[j]) rq[j][i] = *(const half4*)(a.res + roff + ch0 + 16 * i + 4 * q4);
                 }
-                const uint32_t fields = w[i] >> (8 * q4);      // the four 2-bit fields of channels 16 i + 4 q4 ..
-                half4 o;
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = a.relu ? fmaxf(v[e], 0.f) : v[e];
-                    x = ((fields >> (2 * e)) & 3u) >= a.site.thresh ? x * a.site.scale : 0.f;
-                    o[e] = a16_from_f32<BF>(x);
+            for (int j = 0; j < TP; ++j) {
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                if (fast_site) {
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) w[wd] = (uint32_t)__shfl((int)mine.w[wd], l16 + 16 * j, 64);
                 }
-                *(half4*)(a.out + px.out_off + c4) = o;
+                if (!okp[j]) continue;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const uint32_t fields = w[i] >> (8 * q4);      // the four 2-bit fields of channels 16 i + 4 q4 ..
+                    half4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // epilogue_quad's arithmetic and order: (acc * (scale * out_mul)) + bias, + residual, ReLU, site
+                        float x = acc[i][j][e];
+                        if (a.scale) x *= sc[i][e] * a.out_mul;
+                        else if (a.out_mul != 1.f) x *= a.out_mul;
+                        if (a.bias) x += bi[i][e];
+                        if (a.res) x += a16_to_f32<BF>(rq[j][i][e]);
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        if (fast_site) x = ((fields >> (2 * e)) & 3u) >= a.site.thresh ? x * a.site.scale : 0.f;
+                        o[e] = a16_from_f32<BF>(x);
+                    }
+                    *(half4*)(a.out + ooff[j] + ch0 + 16 * i + 4 * q4) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                int n, rem;
+                if (!pixmap(wp * PPW + 16 * j + l16, n, rem)) continue;
+                const PixelCtx px = make_pixel_ctx(a, n, rem);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    epilogue_quad<BF>(a, px, v, ch0 + 16 * i + 4 * q4);
+                }
             }
         }
     } else {

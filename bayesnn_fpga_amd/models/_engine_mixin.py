@@ -13,6 +13,9 @@ AUTO_TOL = 5e-4
 AUTO_SAMPLES = 8          # Monte-Carlo samples of the calibration pass: close to the reference's T = 10 (mc_dropout_passes) — fp16's error against the oracle
                           # at B = 250 is 3.1e-4 / 2.4e-4 / 1.7e-4 at T = 4 / 10 / 100 on near-uniform predictions and 3.9e-3 / 1.9e-3 / 5.6e-4 on peaky
                           # ones (profiles/r06_parity_b250_t100.log): at 8 samples both sit a factor of two or more away from AUTO_TOL
+AUTO_SAMPLES_MAX = 32     # a caller that knows its T (FullAnalysis, evaluate, bench.py) calibrates at min(T, 32) samples: fp16's per-sample rounding noise
+                          # averages out with T, so the decision is taken where the caller will run (VGG-11 at B = 250: 5.1e-4 at 8 samples — rejected by a
+                          # hair — but 3.4e-4 of the oracle at its own T = 30: kept)
 AUTO_IMAGES = 256         # at most this many images of the first batch
 AUTO_CANDIDATES = ("f16", "f16x2")      # (fast, safe); a model may set ``auto_candidates = ("bf16", "bf16x3")`` for the bf16 pipe
 
@@ -67,17 +70,18 @@ class EngineModelMixin:
         return state
 
     # ---- engine_dtype = "auto" -----------------------------------------------------------------------------------------------
-    def resolve_engine_dtype(self, device, dtype=None, calib=None):
+    def resolve_engine_dtype(self, device, dtype=None, calib=None, samples=None):
         """The engine element type a call should run with: ``dtype`` if given, else ``self.engine_dtype``; "auto" is decided ONCE per
         (model weights, device) by ``calibrate_engine_dtype`` on ``calib`` (the caller's first batch) — or, when a caller has no batch
         to give (``model.engine(device)`` from a script), on seeded synthetic N(0, 1) images (CIFAR-normalised inputs have unit-variance
-        channels, SA/datasets/dataset_loader.py:52-57)."""
+        channels, SA/datasets/dataset_loader.py:52-57).  ``samples``: the caller's T when it knows it (capped at AUTO_SAMPLES_MAX); the first decision
+        for a (weights, device) pair sticks until ``invalidate_engine()``."""
         dtype = dtype or getattr(self, "engine_dtype", "auto") or "auto"
         if dtype != "auto":
             return dtype
         rec = self._auto.get(str(device))
         if rec is None:
-            rec = self.calibrate_engine_dtype(device, calib)
+            rec = self.calibrate_engine_dtype(device, calib, samples=min(int(samples), AUTO_SAMPLES_MAX) if samples else AUTO_SAMPLES)
         return rec["dtype"]
 
     def calibrate_engine_dtype(self, device, x=None, samples=AUTO_SAMPLES, tol=None, seed=None):

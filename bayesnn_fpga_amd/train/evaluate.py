@@ -156,7 +156,7 @@ def _evaluate_folded(loss_fn, test_iter, model, dev, T, group=None, shard=None):
         if Tl == 0:
             continue
         if dtype is None:
-            dtype = model.resolve_engine_dtype(dev, None, calib=Xd)              # engine_dtype = "auto": decided on the first batch
+            dtype = model.resolve_engine_dtype(dev, None, calib=Xd, samples=T)   # engine_dtype = "auto": decided on the first batch, at the caller's T
         if pipe is None or pipe.engines[0].max_batch < Bk:
             flush()
             pipe = _eval_pipe(model, dev, dtype, Bk)

@@ -138,7 +138,7 @@ class FullAnalysis:
         ``model.invalidate_engine()`` / ``.to()`` / ``load_state_dict`` drop it — after in-place weight updates call ``invalidate_engine()``."""
         from ..engine import BatchesInFlight
         device = b_x.device
-        dtype = self.model.resolve_engine_dtype(device, None, calib=b_x)
+        dtype = self.model.resolve_engine_dtype(device, None, calib=b_x, samples=self.mc_passes)
         rank, world = self._ranks()
         pipes = self.model.__dict__.setdefault("_fa_pipes", {})
         key = (str(device), dtype, rank, world, self.mc_passes)

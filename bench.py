@@ -384,7 +384,7 @@ def tolerance_leg(model, dev, x, B, T, seed, steps, gain=24.0, rec=None):
     from bayesnn_fpga_amd.engine import BatchesInFlight
     out = {}
     if rec is None:
-        rec = model.calibrate_engine_dtype(dev, x)
+        rec = model.calibrate_engine_dtype(dev, x, samples=min(T, 32))
     out["auto_on_bench_model"] = {k: rec[k] for k in ("dtype", "dmean", "dvar", "tol", "images", "samples")}
     if not all(hasattr(model, n) for n in HEAD_NAMES):
         return out
@@ -395,7 +395,7 @@ def tolerance_leg(model, dev, x, B, T, seed, steps, gain=24.0, rec=None):
     twin.invalidate_engine()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        rec2 = twin.calibrate_engine_dtype(dev, x)
+        rec2 = twin.calibrate_engine_dtype(dev, x, samples=min(T, 32))
     out["auto_on_trained_like_twin"] = {k: rec2[k] for k in ("dtype", "dmean", "dvar", "tol", "images", "samples")}
     out["parity_engine"] = rec2["dtype"]
     pipe = BatchesInFlight(twin, dev, n=2, max_batch=B, dtype=rec2["dtype"])
@@ -598,7 +598,7 @@ def main():
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            auto_rec = model.calibrate_engine_dtype(dev, x)
+            auto_rec = model.calibrate_engine_dtype(dev, x, samples=min(T, 32))      # at the caller's T like FullAnalysis / evaluate (capped at 32)
         a.dtype = auto_rec["dtype"]
     pipe = BatchesInFlight(model, dev, n=1, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
     eng = pipe.engines[0]

@@ -9,7 +9,10 @@ export TMPDIR=/tmp
 cd /tmp
 # one batch at a time under the profiler: with two batches in flight (bench.py's default) the kernels of neighbouring batches share
 # the GPU, and a kernel's trace duration / PMC window would include its neighbour's work
-ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-rccl-probe --no-parity-leg --no-graph --in-flight 1 $BENCH_EXTRA"
+# --dtype f16 unless the caller names one: bench.py's default "auto" calibrates first (8 samples on two engines: small launches of the SAME kernels,
+# which would drag the per-kernel averages of the trace down) and then runs exactly this engine on the synthetic bench weights
+case "$BENCH_EXTRA" in *--dtype*) DT="" ;; *) DT="--dtype f16" ;; esac
+ARGS="--workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-rccl-probe --no-parity-leg --no-graph --in-flight 1 $DT $BENCH_EXTRA"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o run --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_write.log 2>&1
