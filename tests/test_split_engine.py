@@ -51,7 +51,10 @@ def test_split_graph_layout(dt, monkeypatch):
     assert len(fused) == 3 and not any(op.get("in2", -1) >= 0 for op in c32.graph.ops)
     for op in fused:
         cout, cin2 = op["weight"].shape[1], cs.graph.tensors[op["in2"]][2]
-        assert op["weight2"].dtype == TORCH16[dt] and tuple(op["weight2"].shape) == (2, cout, cin2) and op["scale"] is None
+        assert op["weight2"].dtype == TORCH16[dt] and tuple(op["weight2"].shape) == (2, cout, cin2)
+        # (round 6: `scale` carries the inverse of the host's per-channel power-of-two weight lift — the only scale a split-engine conv with in2 takes)
+        k = torch.log2(op["scale"])
+        assert op["scale"] is not None and torch.equal(k, k.round()) and float(op["weight"][0].float().abs().amax()) < 256.0
     assert abs(cs.workspace_bytes - c32.workspace_bytes) <= 0.1 * c32.workspace_bytes   # (no shortcut tensors, but a block's input lives until its conv2)
     assert cs.prefix_macs + 8 * cs.suffix_macs == c16.prefix_macs + 8 * c16.suffix_macs
     monkeypatch.setenv("BMI_FUSE_SHORTCUT", "0")
@@ -63,8 +66,14 @@ def test_split_graph_layout(dt, monkeypatch):
     rel = 2.0 ** -21 if dt == "f16x2" else 2.0 ** -16
     for a, b in convs:
         assert a["weight"].dtype == TORCH16[dt] and tuple(a["weight"].shape) == (2,) + tuple(b["weight"].shape)
-        rec = a["weight"][0].float() + a["weight"][1].float()
+        # head + tail = weight x lift, lift = a power of two per output channel folded back into the epilogue scale (engine.GraphBuilder.channel_lift):
+        # every channel's largest weight sits in [2^7, 2^8), so its tails are normal fp16 numbers
+        lift = b["scale"] / a["scale"]
+        assert torch.equal(torch.log2(lift), torch.log2(lift).round())
+        rec = (a["weight"][0].float() + a["weight"][1].float()) / lift[:, None, None, None]
         assert float((rec - b["weight"]).abs().max()) <= rel * float(b["weight"].abs().max())
+        amax = a["weight"][0].float().abs().reshape(a["weight"].shape[1], -1).amax(dim=1)
+        assert bool(((amax >= 127.9) & (amax <= 256.0)).all())
     assert all(op["weight"].dtype == torch.float32 for op in cs.graph.ops if op["kind"] == _lib.OP_STEM)
 
 
