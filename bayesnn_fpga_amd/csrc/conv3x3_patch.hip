@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     // piece q = tid + 256*i  ->  LDS slot (cell = q >> 3, physical chunk = q & 7)
     // element offset of the piece's source at chunk 0 (relative to a.in), or -1 -> zero page
     int psrc[G::ITER_P];
+    // 64-channel tile, input read through a lazy site (ConvArgs::in_bits; round 6: the first "layer" site feeds 64 -> 64 stride-1 convs): byte offset
+    // of the piece's eight keep bits in the FOLDED tensor's bit image (the piece itself comes from the B scaled images: in_mod = B), or -1
+    long pbit[BCT == 64 ? G::ITER_P : 1];
 #pragma unroll
     for (int i = 0; i < G::ITER_P; ++i) {
         const int q = tid + 256 * i;
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = cell < G::CELLS && px < PW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         psrc[i] = ok ? (int)((((size_t)(map_image<IMAP>(a, n) % a.in_mod) * a.H + iy) * a.W + ix) * a.Cin + c * 8) : -1;
+        if constexpr (BCT == 64) pbit[i] = (ok && a.in_bits) ? (long)(((((size_t)map_image<IMAP>(a, n) * a.H + iy) * a.W + ix) * a.Cin + c * 8) >> 3) : -1L;
     }
     // Weight tile: LDS-DMA one K-step ahead, double buffered, issued as one burst behind the barrier.  Recorded
     // negatives (round 1, same-box A/B on S2/S3/S4): register staging -10 %, hand-pipelined fragment reads -3 %, a third
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     const int nK = 9 * nchunks;
     // K-step s = chunk * 9 + tap uses weight buffer s & 1; the tile of step s+1 is in flight while step s computes
     auto w_koff = [&](int st) { const int c = st / 9, t = st - 9 * c; return t * a.Cin + c * 64; };
+    uint8_t kbp[BCT == 64 ? G::ITER_P : 1];   // (64-channel tile with in_bits: the keep bits of this thread's patch pieces)
     ISSUE_PATCH(0);
     LOAD_W(0, 0);
     int step = 0;
@@ -205,8 +210,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #ifdef BMI_PATCH_STAMPS
             const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
+            if constexpr (BCT == 64) {
+                // keep bits of this chunk's pieces: requested now, used behind the wait (their latency rides with the patch DMA's)
+                if (tap == 0 && a.in_bits) {
+#pragma unroll
+                    for (int i = 0; i < G::ITER_P; ++i) kbp[i] = pbit[i] >= 0 ? a.in_bits[pbit[i] + chunk * 8] : (uint8_t)0xff;
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP_ADD(4, tw0);
+            if constexpr (BCT == 64) {
+                // ... each thread clears the dropped elements of the pieces IT fetched (its own DMA has landed: no barrier needed before), the
+                // barrier below publishes the masked patch — what the fused shortcut's operand does on the 16x16 maps (below)
+                if (tap == 0 && a.in_bits) {
+#pragma unroll
+                    for (int i = 0; i < G::ITER_P; ++i) {
+                        u32x4* const pp = (u32x4*)(patch + (i * 256 + tid) * 16);
+                        u32x4 v = *pp;
+                        const int b = kbp[i];
+#pragma unroll
+                        for (int jq = 0; jq < 4; ++jq) {
+                            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(b, 2 * jq, 1), hi = (unsigned)__builtin_amdgcn_sbfe(b, 2 * jq + 1, 1);
+                            v[jq] &= (lo & 0xffffu) | (hi & 0xffff0000u);
+                        }
+                        *pp = v;
+                    }
+                }
+            }
             __syncthreads();   // patch landed, W[step&1] written; every wave is done with W[(step+1)&1]
             STAMP_ADD(5, tw0);
             if (step == 0) { STAMP(1); }
@@ -365,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
             bool okp[TP];
             size_t ooff[TP];
             half4 rq[TP][TI];
+            uint8_t rkb[TP][TI];
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 int n, rem;
@@ -374,7 +405,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     rq[j][i] = half4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    rkb[j][i] = 0xff;
                     if (a.res && okp[j]) rq[j][i] = *(const half4*)(a.res + roff + ch0 + 16 * i + 4 * q4);
+                    // residual read through a lazy site: its keep bits sit at the element's index in the FOLDED tensor (row n, not n % res_mod)
+                    if (a.res_bits && okp[j]) rkb[j][i] = a.res_bits[(ooff[j] + ch0 + 16 * i + 4 * q4) >> 3];
                 }
             }
 #pragma unroll
@@ -396,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                         if (a.scale) x *= sc[i][e] * a.out_mul;
                         else if (a.out_mul != 1.f) x *= a.out_mul;
                         if (a.bias) x += bi[i][e];
-                        if (a.res) x += a16_to_f32<BF>(rq[j][i][e]);
+                        if (a.res) x += ((rkb[j][i] >> (4 * (q4 & 1) + e)) & 1) ? a16_to_f32<BF>(rq[j][i][e]) : 0.f;
                         if (a.relu) x = fmaxf(x, 0.f);
                         if (fast_site) x = ((fields >> (2 * e)) & 3u) >= a.site.thresh ? x * a.site.scale : 0.f;
                         o[e] = a16_from_f32<BF>(x);
@@ -485,6 +519,10 @@ static int launch_patch64(const ConvArgs& a_in, hipStream_t s) {
     const long tiles = (long)a.N * (a.Ho / 8) * (a.Cout / 64);
     if (tiles <= 0 || tiles > 0x7fffffffL) return BMI_ERR_INVALID;
     if (a.imap || a.in2 || a.in2_bits || a.pool || a.partial) return BMI_ERR_UNSUPPORTED;
+    // operands read through a lazy site: NHWC bit images only; a masked residual needs the register-form epilogue (no site or the 2-bit elementwise one)
+    if ((a.in_bits || a.res_bits) && a.lazy_planar) return BMI_ERR_UNSUPPORTED;
+    if (a.res_bits && (a.site_inner || !(a.site.kind == BMI_SITE_NONE || (a.site.kind == BMI_SITE_ELEMENTWISE && a.site.log2_bits == 1 && !a.site.drop_all))))
+        return BMI_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
     if (a.bf16) hipLaunchKernelGGL((conv3x3_patch_kernel<8, 32, 1, 4, BMI_EPI_GENERAL, 16, true, false, 64>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<8, 32, 1, 4, BMI_EPI_GENERAL, 16, false, false, 64>), grid, block, 0, s, a);
@@ -501,7 +539,7 @@ bool conv_takes_patch_kernel(int ksize, int stride, int pad, int cin, int cout, 
 
 // Returns BMI_ERR_UNSUPPORTED when no patch configuration fits (the caller falls back to conv_igemm).
 int launch_conv3x3_patch(const ConvArgs& a, hipStream_t s) {
-    if (a.in_bits) return BMI_ERR_UNSUPPORTED;   // the patch is filled by DMA: no place to apply keep bits
+    if ((a.in_bits || a.res_bits) && a.Cout % 128 == 0) return BMI_ERR_UNSUPPORTED;   // the 128-channel tiles apply no keep bits to `in` / `res` (the 64-channel tile does)
     if (a.in2 && (!a.wgt2 || a.Cin2 % 64 != 0 || a.in2_mod <= 0 || a.stride2 < 1)) return BMI_ERR_INVALID;
     if (a.ksize != 3 || a.pad != 1 || a.stride != 1 || a.Cin % 64 != 0 || a.Cout % 64 != 0) return BMI_ERR_UNSUPPORTED;
     if (a.N <= 0 || a.in_mod <= 0 || a.B <= 0 || (a.res && a.res_mod <= 0)) return BMI_ERR_INVALID;

@@ -633,6 +633,20 @@ int bmi_create(const bmi_model_desc* desc, bmi_handle* out) {
             if (!reads || &c == &e->suffix[mi]) continue;
             ++readers;
             bool ok = false;
+            // (round 6) conv3x3_patch's 64-channel tile — 3x3 stride-1 convs with Cout % 128 == 64 on 32-wide maps: the BasicBlocks behind the stem, which is
+            // where the first "layer" site sits — clears the dropped elements of its input patch in LDS and of a residual where it is added
+            auto p64 = [&](const OpInfo& q) {
+                const TensorInfo& qi = e->tensors[q.d.in];
+                return opt_conv_patch64() && q.d.kind == BMI_OP_CONV && !q.has_pair && q.d.in2 < 0 && q.d.ksize == 3 && q.d.stride == 1 && q.d.pad == 1 &&
+                       qi.c % 64 == 0 && q.cout % 64 == 0 && q.cout % 128 != 0 && q.wo == 32 && q.ho % 8 == 0 && q.bits_tensor < 0;
+            };
+            if (p64(c) && c.d.in2 != md.out) {
+                // as the input (any epilogue), and / or as the residual (the register-form epilogue: no site or the 2-bit elementwise one, outer)
+                const bool res_ok = c.d.residual != md.out ||
+                                    (c.d.site_pos != BMI_SITE_POS_INNER && (c.d.site.kind == BMI_SITE_NONE ||
+                                                                            (c.d.site.kind == BMI_SITE_ELEMENTWISE && bmi_site_log2_bits(c.d.site.p) == 1 && c.d.site.p < 1.f)));
+                if (res_ok) { all = all && true; all_s2 = false; continue; }
+            }
             if (c.d.kind == BMI_OP_CONV && c.d.residual != md.out && c.bits_tensor < 0) {
                 if (c.d.in2 == md.out) { ok = c.d.in != md.out && c.ho == 16 && c.wo == 16; all_s2 = all_s2 && ti.h == 2 * c.ho && ti.w == 2 * c.wo; }
                 else if (c.d.in2 < 0) {
@@ -913,7 +927,10 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
         e->tensors[id].lazy_pending = false;
         return launch_mask_apply(e->tensors[id].lazy_call, s);
     };
-    if (d.kind != BMI_OP_CONV || pending(d.residual) || (pending(d.in) && pending(d.in2))) {
+    // (a pending RESIDUAL stays pending only for conv3x3_patch's 64-channel tile, which masks it where it is added: tried first in the CONV case below)
+    const bool res_lazy_ok = d.kind == BMI_OP_CONV && pending(d.residual) && !op.has_pair && d.in2 < 0 && d.ksize == 3 && d.stride == 1 && d.pad == 1 &&
+                             op.cout % 64 == 0 && op.cout % 128 != 0 && op.wo == 32 && op.ho % 8 == 0 && opt_conv_patch64() && !imap;
+    if (d.kind != BMI_OP_CONV || (pending(d.residual) && !res_lazy_ok) || (pending(d.in) && pending(d.in2))) {
         int rcm = materialise(d.in);
         if (rcm == BMI_OK && d.kind == BMI_OP_CONV) { rcm = materialise(d.residual); if (rcm == BMI_OK) rcm = materialise(d.in2); }
         if (rcm != BMI_OK) return rcm;
@@ -1071,6 +1088,20 @@ int run_op(bmi_engine_s* e, const OpInfo& op, const float* x, char* ws, int N, i
                 const int rc2 = launch_conv(a, s, &fam);
                 prof.tag(fam, flops, bytes);
                 return rc2 != BMI_OK ? rc2 : launch_conv(q, s);
+            }
+            if (pending(d.residual)) {       // (res_lazy_ok) the residual through its keep bits: conv3x3_patch's 64-channel tile — with the input too when it is the
+                ConvArgs m = a;              //  same pending tensor or another one
+                const TensorInfo& tr = e->tensors[d.residual];
+                m.res = (const _Float16*)(ws + e->tensors[tr.lazy_scaled].offset);
+                m.res_mod = B;
+                m.res_bits = (const uint8_t*)(ws + e->tensors[tr.lazy_bits].offset);
+                m.lazy_planar = tr.lazy_planar_now;
+                if (pending(d.in)) { lazy_in(m); m.lazy_planar = m.lazy_planar || tr.lazy_planar_now; }
+                const int rcl = launch_conv3x3_patch(m, s);
+                prof.tag(BMI_CONV_FAMILY_PATCH, flops, bytes - lazy_saving(d.residual) - (pending(d.in) ? lazy_saving(d.in) : 0.0));
+                if (rcl != BMI_ERR_UNSUPPORTED) return rcl;
+                const int rcm = materialise(d.residual);
+                if (rcm != BMI_OK) return rcm;
             }
             if (pending(d.in)) {             // whichever kernel of the chain applies keep bits: conv1x1_stream, conv3x3_s2, conv_igemm
                 ConvArgs m = a;

@@ -12,6 +12,8 @@ struct ConvArgs {
     const float* scale;   // may be null
     const float* bias;    // may be null
     const _Float16* res;  // may be null
+    const uint8_t* res_bits; // keep bits (as in_bits) for `res`: the residual is a lazy site's tensor — `res` then holds the B scaled images (res_mod = B) and
+                             // the dropped elements are cleared where the residual is added (conv3x3_patch's 64-channel tile), or null
     const uint8_t* in_bits;  // keep bits of an elementwise MC-dropout site on the INPUT (1 bit per element,
                              // byte g = elements 8g..8g+7 of the folded tensor), or null; conv_igemm (zeroes while staging,
                              // 1/(1-p) in out_mul) and conv3x3_s2 on 32x32 maps (clears the elements in LDS; `in` pre-scaled)
