@@ -416,6 +416,9 @@ class MCDEngine(CompiledGraph):
             device = torch.device("cuda", torch.cuda.current_device())
         super().__init__(model, device, max_batch, chunk_samples, dtype)
         self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
+        # the non-finite counter of bmi_finalize_checked: allocated HERE, never lazily — a first finalize() inside a hipGraph capture
+        # (BatchesInFlight.predict_graphed) would otherwise allocate it from the graph's private pool and re-zero it on every replay
+        self._nonfinite = torch.zeros(1, dtype=torch.int32, device=device)
 
     # ---- the path ------------------------------------------------------------------------------
     def _stream(self):
@@ -462,8 +465,6 @@ class MCDEngine(CompiledGraph):
         (bmi_finalize_checked; no synchronisation here): ``check_finite()`` reads it when the results are read."""
         out = torch.empty_like(S)
         n = S[0].numel()
-        if self._nonfinite is None:
-            self._nonfinite = torch.zeros(1, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             rc = self.lib.bmi_finalize_checked(n, int(t_total), S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
                                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._nonfinite.data_ptr(), self._stream())

@@ -201,6 +201,14 @@ def test_non_finite_moment_sums_are_an_error_not_a_number():
         with pytest.raises(FloatingPointError, match="non-finite"):
             eng.check_finite()
         assert eng.nonfinite_count() == 0                     # the check resets the counter
+    # ... behind a hipGraph replay too (the counter is engine-owned device memory allocated at construction, outside any capture: every replay adds to it)
+    from bayesnn_fpga_amd.engine import BatchesInFlight
+    pipe = BatchesInFlight(m, torch.device(DEV), n=1, max_batch=8, dtype="f16")
+    for k in range(3):                                        # capture, replay, replay
+        pipe.predict_graphed(x, 3, seed=1)
+        pipe.last_stream.synchronize()
+        assert pipe.engines[0].nonfinite_count() > 0, k
+    pipe.close()
     good = _mirror()
     eng = good.engine(torch.device(DEV), max_batch=8, dtype="f16")
     eng.predict(x, 3, seed=1)
