@@ -530,16 +530,14 @@ def launch_ranks(n):
     torch.distributed.run, one per GPU, rendezvous on 127.0.0.1 — relay their output (rank 0 prints the JSON line) and exit
     with their code.  Nothing in THIS process has touched the GPU (no torch.cuda call, no HIP call), and it never re-execs
     itself: the children are ordinary subprocesses."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes needs it on this host driver)
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    # --standalone: torchrun's own c10d rendezvous on a port IT binds (a port probed here and released could be taken before the agent
+    # binds it: one flaky 2-rank test in six rounds); --local-addr 127.0.0.1: the container hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           os.path.abspath(__file__), *sys.argv[1:]]
     return subprocess.run(cmd, env=env).returncode
 
 
