@@ -42,6 +42,18 @@ def test_bench_prints_the_contract_line():
         assert rf["traffic"] >= 0.95 * rf["algorithmic_bytes_per_launch"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_mean_diff_gpu_vs_cpu"] < 1e-3
+    # round 6: the same loop as processes x threads over slices of the batch (ATen's convs at batch 250 barely scale inside one process)
+    assert cb["value_multiprocess"] is None or cb["value_multiprocess"] > 0
+    assert "processes" in cb["sample_multiprocess"]
+    # round 6: the timed engine is the PRODUCT's choice (engine_dtype="auto" on the bench batch: fp16 on the synthetic weights), and the line carries
+    # the rate at north_star's tolerance — the engine auto picks on the trained-like twin, timed like the headline
+    assert d["config"]["engine_dtype"].startswith("auto -> f16 ")
+    par = d["parity"]
+    assert par["auto_on_bench_model"]["dtype"] == "f16" and par["auto_on_bench_model"]["dmean"] <= par["auto_on_bench_model"]["tol"] == 5e-4
+    assert par["auto_on_trained_like_twin"]["dtype"] == "f16x2" and par["auto_on_trained_like_twin"]["dmean"] > 5e-4
+    assert d["parity_engine"] == "f16x2" and 0.2 < d["value_at_tolerance"] / d["value"] < 0.45
+    top = rf.get("rocprof_top_symbol")
+    assert top is None or (top["name"].startswith("conv") and 0 < top["share_of_kernel_time"] < 1)
 
 
 @pytest.mark.gpu
