@@ -90,10 +90,18 @@ struct PatchGeom {
 // conv_igemm took 4.2 + 6.5 ms of a 34 ms step at 447 / 289 TFLOP/s.  All four waves sit on the pixel axis (wave tile 64 channels x 16*TJ pixels),
 // the 8 KB weight stage is read by every wave, and the launch finishes in the per-quad epilogue (conv_epilogue.h: epilogue_quad — every site kind,
 // residual, ReLU; no LDS): same K order per accumulator as the 128-channel tile.  No fused shortcut (a 64-channel block has no downsample path).
-template <int TH, int TW, int IMGS, int TJ, int EPI, int MS, bool BF, bool IMAP = false, int BCT = 128>
+// DIRECT (round 6; the 16x16 class, 16x16x32 MFMAs, plain epilogue and the two BasicBlock tails): the epilogue runs on the accumulator registers and
+// stores straight to HBM — what conv3x3_pw's persistent kernel does since round 4 (PWP_DIRECT).  The MFMA rows of a wave's four channel tiles are a
+// PERMUTATION of its 64 channels — LDS weight row 16 i + r holds channel 32 (i >> 1) + 8 (r >> 2) + 4 (i & 1) + (r & 3), applied where the weight DMA picks
+// its source row, so nothing on the LDS side moves — and a lane's sixteen accumulators of a pixel are two runs of 8 consecutive channels (8 q + 0..7 and
+// 32 + 8 q + 0..7, q = lane >> 4): two 16-byte stores per pixel tile (the four lanes of a pixel write 64 contiguous bytes), the residual as two 16-byte loads,
+// no LDS trip, no barrier, no residual DMA.  A row permutation does not touch a row's arithmetic: the same bits as epilogue_plain / epilogue_lite.
+template <int TH, int TW, int IMGS, int TJ, int EPI, int MS, bool BF, bool IMAP = false, int BCT = 128, bool DIRECT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     using G = PatchGeom<TH, TW, IMGS, TJ, BCT>;
     static_assert(BCT == 128 || (BCT == 64 && MS == 16), "64-channel tiles: the 16x16x32 form");
+    static_assert(!DIRECT || (BCT == 128 && MS == 16 && !IMAP && TJ == 4 && (EPI == BMI_EPI_PLAIN || EPI == BMI_EPI_LITE_RES || EPI == BMI_EPI_LITE_RES_MC)),
+                  "the register epilogue: 128-channel tiles, 16x16x32 accumulators, plain / residual / residual + 2-bit site");
     constexpr int BC = G::BC, PH = G::PH, PW = G::PW, PWP = G::PWP, KA = G::KA;
     constexpr int NWP = BCT == 128 ? 2 : 4;       // waves on the pixel axis (x 4 / NWP on the channel axis)
     constexpr int PPW = G::BP / NWP;              // pixels per wave: 32 TJ | 16 TJ
@@ -156,6 +164,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
     const int w_row = tid >> 3;
     const int w_sw = (w_row >> 1) & 7;
     const _Float16* wsrc = a.wgt + (size_t)(ch0 + w_row) * Ktot + ((tid & 7) ^ w_sw) * 8;
+    // DIRECT: LDS weight row rho = w_row + 32 i holds channel sigma(rho) (see the kernel's header); identity otherwise
+    int wch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rho = w_row + 32 * i, t = (rho >> 4) & 3, r16 = rho & 15;
+        wch[i] = DIRECT ? (rho & 64) + 32 * (t >> 1) + 8 * (r16 >> 2) + 4 * (t & 1) + (r16 & 3) : rho;
+    }
 
 #define ISSUE_PATCH(C0)                                                                           \
     {                                                                                             \
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
 #define LOAD_W(KOFF, BUF)                                                                         \
     {                                                                                             \
         _Pragma("unroll") for (int i = 0; i < BC / 32; ++i)                                       \
-            GLDS16(wsrc + (size_t)(32 * i) * Ktot + (KOFF),                                       \
+            GLDS16(wsrc + (size_t)(wch[i] - w_row) * Ktot + (KOFF),                               \
                    wbuf + (BUF) * G::WTILE + (i * 256 + wave * 64) * 16);                         \
     }
 
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                GLDS16(a.wgt2 + (size_t)(ch0 + w_row + 32 * i) * a.Cin2 + c2 * 64 + ((tid & 7) ^ w_sw) * 8,
+                GLDS16(a.wgt2 + (size_t)(ch0 + wch[i]) * a.Cin2 + c2 * 64 + ((tid & 7) ^ w_sw) * 8,
                        wbuf + (i * 256 + wave * 64) * 16);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (MS == 16 && a.in2_bits) {        // each thread clears the dropped elements of the pieces it fetched itself (launcher: 16x16x32 form only)
@@ -451,6 +466,85 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 }
             }
         }
+    } else if constexpr (DIRECT) {
+        // ---- register epilogue (see the kernel's header): lane (l16, q4) holds, per pixel tile j, channels cA .. cA + 7 (tiles 0, 1) and cA + 32 .. (tiles 2, 3)
+        const int l16 = lane & 15, q4 = lane >> 4;
+        const int cA = ch0 + wc * 64 + 8 * q4;
+        constexpr bool HAS_RES = EPI != BMI_EPI_PLAIN, MASKED = EPI == BMI_EPI_LITE_RES_MC;
+        f32x4_e sc[4], bi[4];           // tile i: channels cA + 32 (i >> 1) + 4 (i & 1) ..
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = cA + 32 * (i >> 1) + 4 * (i & 1);
+            sc[i] = f32x4_e{1.f, 1.f, 1.f, 1.f};
+            bi[i] = f32x4_e{0.f, 0.f, 0.f, 0.f};
+            if (a.scale) sc[i] = *(const f32x4_e*)(a.scale + c4);
+            if (a.bias) bi[i] = *(const f32x4_e*)(a.bias + c4);
+            sc[i] *= a.out_mul;
+        }
+        philox4 mine[2] = {{{0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}}};
+        if constexpr (MASKED) {         // one Philox call masks the 64 channels of (pixel, wave channel half): 128 pixels per wave = two calls per lane
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                int n, rem;
+                pixmap(wp * PPW + 16 * (q4 + 4 * r2) + l16, n, rem);
+                const int tl = n / a.B;
+                const uint64_t e0 = (uint64_t)((n - tl * a.B) * (a.Ho * a.Wo) + rem) * a.Cout + ch0 + wc * 64;
+                mine[r2] = philox_site_call(a.site, e0, (uint32_t)(a.t0 + tl));
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < TP; jb += 4) {       // four pixel tiles at a time: eight 16-byte residual loads in flight
+            size_t off[4];
+            bool okp[4];
+            half8_e rA[4], rB[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                okp[jj] = offmap(wp * PPW + 16 * (jb + jj) + l16, off[jj]);
+                if constexpr (HAS_RES) {
+                    if (okp[jj]) {
+                        rA[jj] = *(const half8_e*)(a.res + off[jj] + cA);
+                        rB[jj] = *(const half8_e*)(a.res + off[jj] + cA + 32);
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = jb + jj;
+                uint32_t wA = 0u, wB = 0u;
+                if constexpr (MASKED) {     // (every lane takes part in the exchange, valid pixel or not)
+                    uint32_t w[4];
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) w[wd] = (uint32_t)__shfl((int)mine[j >> 2].w[wd], l16 + 16 * (j & 3), 64);
+                    // channel k of the wave's 64 <-> word k >> 4, bits 2 (k & 15): cA's run = word q4 >> 1 from bit 16 (q4 & 1), cA + 32's = word 2 + (q4 >> 1)
+                    wA = ((q4 & 2) ? w[1] : w[0]) >> (16 * (q4 & 1));
+                    wB = ((q4 & 2) ? w[3] : w[2]) >> (16 * (q4 & 1));
+                }
+                if (!okp[jj]) continue;
+                half8_e oA, oB;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e] * sc[i][e] + bi[i][e];
+                        const int e8 = 4 * (i & 1) + e;
+                        if constexpr (HAS_RES) {
+                            v += a16_to_f32<BF>((i >> 1) ? rB[jj][e8] : rA[jj][e8]);
+                            v = fmaxf(v, 0.f);                       // (the specialised tails: ReLU compiled in)
+                        } else {
+                            if (a.relu) v = fmaxf(v, 0.f);
+                        }
+                        if constexpr (MASKED) {
+                            const uint32_t f = (((i >> 1) ? wB : wA) >> (2 * e8)) & 3u;
+                            v = f >= a.site.thresh ? v * a.site.scale : 0.f;
+                            asm("" : "+v"(v));                       // (epilogue_lite: keep the fp32 product — one rounding, like every other epilogue)
+                        }
+                        if (i >> 1) oB[e8] = a16_from_f32<BF>(v);
+                        else oA[e8] = a16_from_f32<BF>(v);
+                    }
+                *(half8_e*)(a.out + off[jj] + cA) = oA;
+                *(half8_e*)(a.out + off[jj] + cA + 32) = oB;
+            }
+        }
     } else {
         epilogue_coalesced<TJ, EPI, MS, BF>(a, acc, smem, tid, ch0, pixmap, offmap);
     }
@@ -470,6 +564,8 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     const dim3 grid((unsigned)tiles), block(256);
 #define PATCH_LAUNCH(EPI_, MS_, BF_, IMAP_) \
     hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, EPI_, MS_, BF_, IMAP_>), grid, block, 0, s, a)
+#define PATCH_LAUNCH_DIRECT(EPI_, BF_) \
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, IMGS, TJ, EPI_, 16, BF_, false, 128, true>), grid, block, 0, s, a)
 #define PATCH_LAUNCH_EPI16(BF_, IMAP_)                                            \
     {                                                                             \
         if (epi == BMI_EPI_PLAIN) PATCH_LAUNCH(BMI_EPI_PLAIN, 16, BF_, IMAP_);    \
@@ -487,9 +583,13 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
     } else if (ms == 16 && TH == 16 && TW == 16 && epi == BMI_EPI_LITE && conv_epilogue_kind_launch(a, 16) != BMI_EPI_LITE) {
         // the BasicBlock tails of the 16x16 maps: the lite epilogue with its launch-uniform terms compiled in (conv_epilogue.h; same bits)
         if constexpr (TH == 16 && TW == 16) {
+            const bool direct = opt_patch_direct() != 0;      // ("patch_direct" = 0: the lite epilogue through LDS; A/B, tests — the same bits)
             if (conv_epilogue_kind_launch(a, 16) == BMI_EPI_LITE_RES) {
-                if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES, 16, true, false);
+                if (direct) { if (a.bf16) PATCH_LAUNCH_DIRECT(BMI_EPI_LITE_RES, true); else PATCH_LAUNCH_DIRECT(BMI_EPI_LITE_RES, false); }
+                else if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES, 16, true, false);
                 else PATCH_LAUNCH(BMI_EPI_LITE_RES, 16, false, false);
+            } else if (conv_epilogue_kind_launch(a, 16) == BMI_EPI_LITE_RES_MC && direct) {
+                if (a.bf16) PATCH_LAUNCH_DIRECT(BMI_EPI_LITE_RES_MC, true); else PATCH_LAUNCH_DIRECT(BMI_EPI_LITE_RES_MC, false);
             } else if (conv_epilogue_kind_launch(a, 16) == BMI_EPI_LITE_RES_MSK) {
                 if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES_MSK, 16, true, false);
                 else PATCH_LAUNCH(BMI_EPI_LITE_RES_MSK, 16, false, false);
@@ -497,6 +597,10 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
                 if (a.bf16) PATCH_LAUNCH(BMI_EPI_LITE_RES_MC, 16, true, false);
                 else PATCH_LAUNCH(BMI_EPI_LITE_RES_MC, 16, false, false);
             }
+        }
+    } else if (ms == 16 && TH == 16 && TW == 16 && epi == BMI_EPI_PLAIN && opt_patch_direct() == 2) {      // ("patch_direct" = 2: measured +3...5 % on the plain launches in the network: not the default)
+        if constexpr (TH == 16 && TW == 16) {     // the plain launches of the 16x16 class: the register epilogue
+            if (a.bf16) PATCH_LAUNCH_DIRECT(BMI_EPI_PLAIN, true); else PATCH_LAUNCH_DIRECT(BMI_EPI_PLAIN, false);
         }
     } else if (a.bf16) {
         PATCH_LAUNCH_EPI16(true, false)
@@ -507,6 +611,7 @@ static int launch_patch(const ConvArgs& a_in, hipStream_t s) {
         else PATCH_LAUNCH(BMI_EPI_GENERAL, 32, false, false);
     }
 #undef PATCH_LAUNCH_EPI16
+#undef PATCH_LAUNCH_DIRECT
 #undef PATCH_LAUNCH
     BMI_CHECK_LAUNCH();
     return BMI_OK;

@@ -226,6 +226,7 @@ static int set_named_option(BmiOptions& o, const char* name, int32_t value) {
         {"conv_patch64", &BmiOptions::conv_patch64, 0, 1},
         {"splitk_tiles", &BmiOptions::splitk_tiles, 0, 1024},            // read by bmi_plan
         {"pair_prefix", &BmiOptions::pair_prefix, 0, 1},                  // read by bmi_create
+        {"patch_direct", &BmiOptions::patch_direct, 0, 2},
     };
     for (const Row& r : rows)
         if (std::strcmp(name, r.name) == 0) {

@@ -192,6 +192,7 @@ struct BmiOptions {
     int conv_patch64 = 1;        // 1: 64 -> 64-class 3x3 stride-1 convs on 32-wide maps run in conv3x3_patch's 64-channel tile, 0: conv_igemm
     int splitk_tiles = 64;       // bmi_plan: a deterministic 3x3 conv (Cin >= 256, no residual / shortcut / site) of at most this many 128 x 128 tiles runs split-K
     int pair_prefix = 1;         // bmi_create: pair fusion (two plain convs on one input in one launch) in the once-per-batch prefix too (0: suffix only)
+    int patch_direct = 1;        // 1: conv3x3_patch's BasicBlock tails on 16x16 maps (residual, residual + 2-bit site) finish on the accumulator registers (2: the plain launches too), 0: through LDS
     int head_batch = 1;          // 1: consecutive exit heads of the suffix (exit-only dropout: the suffix is nothing but the heads) run as ONE launch, 0: one launch per head
 };
 BmiOptions& bmi_default_options();                 // the process defaults (engine.hip)
@@ -208,7 +209,7 @@ struct BmiOptionScope {
 BMI_OPT(mfma_shape_patch) BMI_OPT(mfma_shape_wide) BMI_OPT(unit_dtype) BMI_OPT(wide_persist_min) BMI_OPT(conv_pw) BMI_OPT(conv_wide)
 BMI_OPT(mask_lazy) BMI_OPT(conv_pool) BMI_OPT(conv_s2) BMI_OPT(split_shx) BMI_OPT(split_tile) BMI_OPT(conv_seam) BMI_OPT(conv_stream)
 BMI_OPT(splitk) BMI_OPT(dense_exact) BMI_OPT(lazy_order) BMI_OPT(epilogue_lite) BMI_OPT(xcd_split) BMI_OPT(pw_persist) BMI_OPT(lazy_planar)
-BMI_OPT(ws_no_reuse) BMI_OPT(head_batch) BMI_OPT(conv_patch64) BMI_OPT(splitk_tiles) BMI_OPT(pair_prefix)
+BMI_OPT(ws_no_reuse) BMI_OPT(head_batch) BMI_OPT(conv_patch64) BMI_OPT(splitk_tiles) BMI_OPT(pair_prefix) BMI_OPT(patch_direct)
 #undef BMI_OPT
 int xcd_split_for(int n_ctiles, size_t weight_bytes);
 

@@ -245,6 +245,9 @@ const char* bmi_error_string(int code);
  *                                           with Cin >= 256 that still runs split-K (default 64: a quarter of the CUs)
  *   "pair_prefix"                           0 | 1, read by bmi_create: pair fusion (two plain convs on one input as one launch) also in the once-per-batch
  *                                           prefix (1, default: the exit-only step +3 %, profiles/experiments/r6_exit_only_variants.txt) or in the suffix only (0)
+ *   "patch_direct"                          0 | 1 | 2: conv3x3_patch's BasicBlock tails on 16x16 maps (residual, residual + 2-bit site) finish on the accumulator
+ *                                           registers and store straight to HBM (1, default; 2: its plain launches too — measured slower in the network) or
+ *                                           take the epilogues through LDS (0).  The same bits every way
  *   "head_batch"                            0 | 1: consecutive exit heads of the sample-folded suffix run as ONE launch (1, default) — with exit-only
  *                                           dropout, the configuration of every run of the paper (journal_script.sh:10-63), the suffix is nothing but
  *                                           the four / five heads — or one launch per head (0).  The same bits either way

@@ -990,3 +990,53 @@ def test_patch_kernel_64_channel_tile(kind, bf16):
     torch.testing.assert_close(out[1], out[0], rtol=tol, atol=tol)
     if site is not None:
         assert torch.equal(out[1][mult == 0], torch.zeros_like(out[1][mult == 0])) and (mult == 0).any() and (mult != 0).any()
+
+
+@pytest.mark.parametrize("form", ["plain", "plain_norelu", "shortcut", "res", "res_site", "res_broadcast"])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_patch_register_epilogue_equals_the_lds_epilogues_bit_for_bit(form, dt):
+    """conv3x3_patch's 16x16 class with "patch_direct" (round 6): the MFMA rows of a wave are a permutation of its 64 channels, so a lane's accumulators of a
+    pixel are two runs of 8 consecutive channels and the launch finishes on the registers — BN, residual, ReLU, the 2-bit elementwise site — with 16-byte
+    stores straight to HBM.  Same arithmetic in the same order as epilogue_plain / epilogue_lite ("patch_direct" = 0): IDENTICAL bits, for the plain launch
+    (with and without ReLU), the fused shortcut (its weight rows follow the same permutation), the residual tails with and without the site, fp16 and bf16;
+    a residual of fewer rows than the output (res_mod < N) is not the specialised tail and takes the LDS epilogue in both arms."""
+    lib = _lib.lib()
+    cin, cout, H, k, s, p = SHAPES["S2"]
+    n, B, t0, seed = 6, 3, 4, (5 << 32) + 7
+    g = _gen(23)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    x = torch.randn(n, H, H, cin, generator=g).to(tdt).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(tdt).to(DEV)
+    scale, bias = (0.5 + torch.rand(cout, generator=g)).to(DEV), (0.2 * torch.randn(cout, generator=g)).to(DEV)
+    res = torch.randn(B if form == "res_broadcast" else n, H, H, cout, generator=g).to(tdt).to(DEV)
+    x2 = torch.randn(n, 2 * H, 2 * H, cin // 2, generator=g).to(tdt).to(DEV)
+    w2 = (torch.randn(cout, cin // 2, generator=g) * (2.0 / cin) ** 0.5).to(tdt).to(DEV)
+    site = dict(kind=_lib.SITE_ELEMENTWISE, site_id=3, p=0.25) if form == "res_site" else None
+    if dt == "bf16":
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_BF16)
+    outs = {}
+    try:
+        for arm in (1, 0):
+            _lib.set_option("patch_direct", 2 * arm)          # 2: the register epilogue for the plain launches too (default 1: the tails only)
+            if form == "shortcut":
+                out = torch.full((n, H, H, cout), float("nan"), dtype=tdt, device=DEV)
+                _lib.check(lib.bmi_conv3x3_shortcut_fwd(gh.ptr(x), gh.ptr(w), gh.ptr(x2), gh.ptr(w2), gh.ptr(bias), gh.ptr(out), n, H, H, cin, cout, cin // 2, 1,
+                                                        gh.stream()), "bmi_conv3x3_shortcut_fwd")
+                torch.cuda.synchronize()
+            else:
+                r = res if form.startswith("res") else None
+                out = gh.run_conv(x, w, scale, bias, r, form != "plain_norelu", s, p, n, n, B if form == "res_broadcast" else n, site=site, batch=B, t0=t0,
+                                  seed=seed, out_dtype=tdt)
+            outs[arm] = out
+    finally:
+        _lib.set_option("patch_direct", 1)
+        _lib.set_option("unit_entry_dtype", _lib.DTYPE_F16)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[1].view(torch.int16), outs[0].view(torch.int16))
+    if form != "shortcut":                      # ... and against the fp32 reference on the same 16-bit operands
+        r = res if form.startswith("res") else None
+        ref = gh.conv_ref(x, w, scale, bias, r, form != "plain_norelu", s, p, n, n, B if form == "res_broadcast" else n)
+        if site is not None:
+            ref = ref * gh.folded_site_mask(site, B, cout, H, H, n // B, t0, seed, 0)
+        tol = 3e-2 if dt == "bf16" else 3e-3
+        torch.testing.assert_close(outs[1].float().cpu().permute(0, 3, 1, 2), ref, rtol=tol, atol=tol)
