@@ -128,6 +128,28 @@ class EngineModelMixin:
                           f"Set model.engine_dtype = {fast!r} to force the fast engine.", stacklevel=3)
         return rec
 
+    def agree_engine_dtype(self, device, dtype, group=None):
+        """The ranks of one sharded walk run ONE engine type: a tiny all-reduce (MAX) of "my calibration kept the safe engine"; if any rank did,
+        every rank in auto mode runs it (a rank that calibrated on another slice of the batch, or a borderline decision that fell the other
+        way, must not leave the step waiting for the one rank on the 0.3x engine — nor make the result depend on which rank drew which samples).
+        COLLECTIVE: every rank of ``group`` calls it at the same point (FullAnalysis and evaluate do, when they build their engines on the
+        first batch), whatever its ``engine_dtype``; a rank with an explicit engine type votes 0 and keeps its own."""
+        import warnings
+
+        import torch.distributed as dist
+        auto = (getattr(self, "engine_dtype", "auto") or "auto") == "auto"
+        fast, safe = self.auto_candidates
+        flag = torch.tensor([1 if (auto and dtype == safe) else 0], dtype=torch.int32)
+        if dist.get_backend(group) == "nccl":
+            flag = flag.to(device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if auto and int(flag.item()) and dtype != safe:
+            rec = self._auto.setdefault(str(device), {})
+            rec.update(dtype=safe, fast=fast, safe=safe, agreed_with_ranks=True)
+            warnings.warn(f"{type(self).__name__}: engine_dtype='auto' follows another rank's calibration onto the split engine {safe!r}", stacklevel=3)
+            return safe
+        return dtype
+
     def engine(self, device, max_batch=None, chunk_samples=None, dtype=None, calib=None):
         """The compiled HIP engine for ``device`` (built on first use, rebuilt when it must grow).
         ``dtype``: "f16" / "bf16" (16-bit activations and conv weights), "f16x2" / "bf16x3" (the split engines: the reference's fp32

@@ -153,10 +153,12 @@ def _evaluate_folded(loss_fn, test_iter, model, dev, T, group=None, shard=None):
     for k, (X, y) in enumerate(test_iter):
         Bk = int(X.shape[0])
         Xd, yd = X.to(dev, non_blocking=True), y.to(dev, non_blocking=True)      # (on the caller's stream: the slot's stream waits for it)
-        if Tl == 0:
-            continue
         if dtype is None:
             dtype = model.resolve_engine_dtype(dev, None, calib=Xd, samples=T)   # engine_dtype = "auto": decided on the first batch, at the caller's T
+            if world > 1:            # (collective, on every rank's first batch — also a rank without passes of its own)
+                dtype = model.agree_engine_dtype(dev, dtype, group)
+        if Tl == 0:
+            continue
         if pipe is None or pipe.engines[0].max_batch < Bk:
             flush()
             pipe = _eval_pipe(model, dev, dtype, Bk)

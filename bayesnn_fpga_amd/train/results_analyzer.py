@@ -140,6 +140,8 @@ class FullAnalysis:
         device = b_x.device
         dtype = self.model.resolve_engine_dtype(device, None, calib=b_x, samples=self.mc_passes)
         rank, world = self._ranks()
+        if world > 1:                # (collective: every rank builds its pipe on the same batch of the walk)
+            dtype = self.model.agree_engine_dtype(device, dtype, getattr(self, "group", None) or _default_group())
         pipes = self.model.__dict__.setdefault("_fa_pipes", {})
         key = (str(device), dtype, rank, world, self.mc_passes)
         pipe = pipes.get(key)

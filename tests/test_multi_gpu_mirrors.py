@@ -118,3 +118,46 @@ def test_macro_batches_carry_k_loader_batches_per_engine_step():
     assert not np.array_equal(f.preds[:, :2 * B], e.preds[:, :2 * B])  # other draws ...
     assert float(np.abs(f.preds - e.preds).mean()) < 0.05              # ... of the same distribution (T = 6 samples: noisy per element)
     np.testing.assert_array_equal(f.labels, e.labels)
+
+
+def _rank_agree(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import warnings
+
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from bayesnn_fpga_amd.train.evaluate import MultiExitAccuracy, evaluate
+    from bayesnn_fpga_amd.train.results_analyzer import FullAnalysis
+    m = _model(KW_MC)
+    if rank == 1:
+        m.auto_tol = 0.0                 # this rank's calibration rejects fp16 (as a borderline model, or another slice of the batch, could)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        acc = evaluate(MultiExitAccuracy(4, acc_tops=(1, 5)), _loader(), m, 0, "exp", T, create_log=False)
+        fa = FullAnalysis(m, _loader(), gpu=0, mc_dropout=True, mc_passes=T, ece="hist")
+    rec = m._auto["cuda:0"]
+    with open(os.path.join(out_dir, f"agree_{rank}.txt"), "w") as f:
+        f.write(f"{rec['dtype']},{fa._pipe.engines[0].dtype},{bool(rec.get('agreed_with_ranks', False))}")
+    np.save(os.path.join(out_dir, f"preds_{rank}.npy"), fa.preds)
+    np.save(os.path.join(out_dir, f"acc_{rank}.npy"), np.array(acc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_agree_on_one_engine_type_when_one_calibration_rejects_fp16(tmp_path):
+    """``engine_dtype = "auto"`` under a process group: rank 1's calibration keeps the split engine (forced: ``auto_tol = 0``), rank 0's keeps
+    fp16; the entry points' one-int all-reduce at pipe-build time (``EngineModelMixin.agree_engine_dtype``) moves rank 0 onto the split engine
+    too, so the walk's result is the one-rank f16x2 walk's (fp32-equivalent: 1e-5), not a per-rank mixture of engines."""
+    from bayesnn_fpga_amd.train.results_analyzer import FullAnalysis
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_agree, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "agree_0.txt").read_text() == "f16x2,f16x2,True"
+    assert (tmp_path / "agree_1.txt").read_text() == "f16x2,f16x2,False"
+    one = FullAnalysis(_model(KW_MC, "f16x2"), _loader(), gpu=0, mc_dropout=True, mc_passes=T, ece="hist")
+    for r in (0, 1):
+        np.testing.assert_allclose(np.load(tmp_path / f"preds_{r}.npy"), one.preds, rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(np.load(tmp_path / "acc_0.npy"), np.load(tmp_path / "acc_1.npy"))

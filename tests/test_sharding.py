@@ -326,3 +326,58 @@ def test_two_rank_gloo_full_analysis_collates_a_sharded_walk(tmp_path):
     with open(two / "test_predictions_exp.npy", "rb") as f, open(one / "test_predictions_exp.npy", "rb") as g:
         for _ in range(3):                                     # preds, ensemble_preds, labels
             np.testing.assert_allclose(np.load(f), np.load(g), rtol=0, atol=1e-12)
+
+
+def _agree_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import warnings
+
+    import torch.distributed as dist
+    from bayesnn_fpga_amd.models._engine_mixin import EngineModelMixin
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class M(EngineModelMixin):
+        pass
+
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # (1) rank 1's calibration kept the safe engine: rank 0 follows and its record says why
+        m = M()
+        m._init_engine_state()
+        m._auto["cpu"] = dict(dtype="f16" if rank == 0 else "f16x2")
+        out.append(m.agree_engine_dtype("cpu", m._auto["cpu"]["dtype"]))
+        out.append(str(bool(m._auto["cpu"].get("agreed_with_ranks", False))))
+        # (2) both kept the fast one: nothing changes
+        m2 = M()
+        m2._init_engine_state()
+        out.append(m2.agree_engine_dtype("cpu", "f16"))
+        # (3) an explicit engine type votes 0 and is never overridden; the auto rank is not dragged by it either
+        m3 = M()
+        m3._init_engine_state()
+        if rank == 1:
+            m3.engine_dtype = "f16x2"
+        out.append(m3.agree_engine_dtype("cpu", "f16x2" if rank == 1 else "f16"))
+        # (4) the bf16 pipe's candidates
+        m4 = M()
+        m4._init_engine_state()
+        m4.auto_candidates = ("bf16", "bf16x3")
+        out.append(m4.agree_engine_dtype("cpu", "bf16x3" if rank == 0 else "bf16"))
+    with open(os.path.join(out_dir, f"agree_{rank}.txt"), "w") as f:
+        f.write(",".join(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_auto_engine_choice_is_agreed_between_the_ranks(tmp_path):
+    """``EngineModelMixin.agree_engine_dtype``: one MAX all-reduce at pipe-build time; any rank whose calibration kept the split engine moves
+    every rank in auto mode onto it (FullAnalysis._make_pipe / _evaluate_folded call it on the first batch of a sharded walk)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "agree_0.txt").read_text().split(",")
+    r1 = (tmp_path / "agree_1.txt").read_text().split(",")
+    assert r0 == ["f16x2", "True", "f16", "f16", "bf16x3"]
+    assert r1 == ["f16x2", "False", "f16", "f16x2", "bf16x3"]
