@@ -598,6 +598,8 @@ def main():
             warnings.simplefilter("ignore")
             auto_rec = model.calibrate_engine_dtype(dev, x, samples=min(T, 32))      # at the caller's T like FullAnalysis / evaluate (capped at 32)
         a.dtype = auto_rec["dtype"]
+        if world > 1:                # one engine type per job: any rank on the split engine moves all of them (same inputs and seeds: a formality)
+            a.dtype = model.agree_engine_dtype(dev, a.dtype)
     pipe = BatchesInFlight(model, dev, n=1, max_batch=B, chunk_samples=a.chunk or None, dtype=a.dtype)
     eng = pipe.engines[0]
     pkind = None if a.partition == "auto" else a.partition
